@@ -1,0 +1,193 @@
+"""ctypes binding of the CPU oracle (oracle/rto_oracle.c).
+
+TEST INFRASTRUCTURE: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+only.  The product package (rt-octree_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "_build", "liborc.so")
+
+MATH_DET, MATH_LIBM = 0, 1
+FMT_RGBA, FMT_SH = 0, 1
+
+
+class Pcg32(C.Structure):
+    _fields_ = [("state", C.c_uint64), ("inc", C.c_uint64)]
+
+
+class Tree(C.Structure):
+    _fields_ = [
+        ("data", C.c_void_p), ("child", C.c_void_p),
+        ("offset", C.c_float * 3), ("scale", C.c_float * 3),
+        ("N", C.c_int), ("data_dim", C.c_int), ("format", C.c_int), ("basis_dim", C.c_int),
+        ("ndc_width", C.c_float), ("ndc_height", C.c_float), ("ndc_focal", C.c_float),
+    ]
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("step_size", C.c_float), ("sigma_thresh", C.c_float), ("stop_thresh", C.c_float),
+        ("background_brightness", C.c_float), ("render_bbox", C.c_float * 6),
+        ("basis_minmax", C.c_int * 2), ("rot_dirs", C.c_float * 3),
+        ("denoise", C.c_int), ("spp", C.c_int),
+    ]
+
+
+class Camera(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("fx", C.c_float), ("fy", C.c_float),
+                ("transform", C.c_float * 12)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("rays_in_box", C.c_uint64), ("steps", C.c_uint64),
+                ("levels", C.c_uint64), ("hit_leaves", C.c_uint64), ("hit_rays", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+def build(force=False):
+    """Compile the oracle (gcc).  Building the checker is not using it."""
+    src = [os.path.join(ORACLE_DIR, f) for f in ("rto_oracle.c", "rto_oracle.h", "Makefile")]
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in src)):
+        return LIB_PATH
+    subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        L.orc_pcg32_next_uint.restype = C.c_uint32
+        L.orc_pcg32_next_float.restype = C.c_float
+        L.orc_pcg32_advance.argtypes = [C.POINTER(Pcg32), C.c_int64]
+        L.orc_pcg32_seed.argtypes = [C.POINTER(Pcg32), C.c_uint64, C.c_uint64]
+        L.orc_det_logf.restype = C.c_float
+        L.orc_det_logf.argtypes = [C.c_float]
+        L.orc_det_expf.restype = C.c_float
+        L.orc_det_expf.argtypes = [C.c_float]
+        L.orc_half2float.restype = C.c_float
+        L.orc_half2float.argtypes = [C.c_uint16]
+        L.orc_query.restype = C.c_int64
+        L.orc_render_frame.restype = C.c_int
+        L.orc_render_pixel.restype = C.c_int
+        L.orc_filter.restype = C.c_int
+        L.orc_rgba8.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        _lib = L
+    return _lib
+
+
+def rng(seed=20230418, frame=0):
+    """RenderContext.rng (render_context.hpp:16) advanced by `frame` per-frame jumps of 2^32."""
+    r = Pcg32()
+    lib().orc_pcg32_seed(C.byref(r), seed, 1)
+    for _ in range(frame):
+        lib().orc_pcg32_advance(C.byref(r), 1 << 32)
+    return r
+
+
+def default_options(spp=1, **kw):
+    o = Options()
+    lib().orc_options_default(C.byref(o))
+    o.spp = spp
+    for k, v in kw.items():
+        if k in ("render_bbox", "basis_minmax", "rot_dirs"):
+            for i, x in enumerate(v):
+                getattr(o, k)[i] = x
+        else:
+            setattr(o, k, v)
+    return o
+
+
+class HostTree:
+    """Keeps the numpy arrays alive next to the orc_tree view."""
+
+    def __init__(self, child, data, scale, offset, data_format="SH9", ndc=None):
+        child = np.ascontiguousarray(child, dtype=np.int32)
+        data = np.ascontiguousarray(data)
+        if data.dtype == np.float16:
+            data = data.view(np.uint16)
+        assert data.dtype == np.uint16
+        self.child, self.data = child, data
+        self.N = int(child.shape[1]) if child.ndim == 4 else 2
+        self.capacity = int(child.shape[0]) if child.ndim == 4 else child.size // 8
+        self.data_dim = int(data.shape[-1]) if data.ndim == 5 else data.size // child.size
+        self.data_format = data_format
+        alpha = "".join(ch for ch in data_format if ch.isalpha())
+        digits = data_format[len(alpha):]
+        self.format = {"RGBA": 0, "SH": 1, "SG": 2, "ASG": 3}.get(alpha, 0) if digits else 0
+        self.basis_dim = int(digits) if digits else -1
+        t = Tree()
+        t.data = data.ctypes.data
+        t.child = child.ctypes.data
+        for i in range(3):
+            t.offset[i] = float(offset[i])
+            t.scale[i] = float(scale[i])
+        t.N, t.data_dim, t.format, t.basis_dim = self.N, self.data_dim, self.format, self.basis_dim
+        t.ndc_width, t.ndc_height, t.ndc_focal = (-1.0, 0.0, 0.0) if ndc is None else ndc
+        self.c = t
+        self.scale = np.asarray(scale, np.float32)
+        self.offset = np.asarray(offset, np.float32)
+
+
+def camera(width, height, fx, fy, c2w12):
+    cam = Camera()
+    cam.width, cam.height, cam.fx, cam.fy = width, height, fx, fy
+    for i, v in enumerate(np.asarray(c2w12, np.float32).reshape(-1)):
+        cam.transform[i] = float(v)
+    return cam
+
+
+def render_frame(tree, cam, opt, rng_base, threads=0, want_stats=True):
+    """-> aux [8,H,W] f32, rgba [H,W,4] f32, stats dict"""
+    H, W = cam.height, cam.width
+    aux = np.empty((8, H, W), np.float32)
+    rgba = np.empty((H, W, 4), np.float32)
+    st = Stats()
+    rc = lib().orc_render_frame(C.byref(tree.c), C.byref(cam), C.byref(opt), C.byref(rng_base),
+                                C.c_void_p(aux.ctypes.data), C.c_void_p(rgba.ctypes.data),
+                                C.byref(st) if want_stats else None, C.c_int(threads))
+    if rc:
+        raise RuntimeError("orc_render_frame failed: %d" % rc)
+    return aux, rgba, st.as_dict()
+
+
+def filter_levels(weight, guidance, noisy, threads=0):
+    """weight, guidance [L,H,W]; noisy [H,W,4] -> out [H,W,4]"""
+    weight = np.ascontiguousarray(weight, np.float32)
+    guidance = np.ascontiguousarray(guidance, np.float32)
+    noisy = np.ascontiguousarray(noisy, np.float32)
+    L, H, W = guidance.shape
+    out = np.zeros((H, W, 4), np.float32)
+    rc = lib().orc_filter(C.c_int(L), C.c_int(H), C.c_int(W), C.c_void_p(weight.ctypes.data),
+                          C.c_void_p(guidance.ctypes.data), C.c_void_p(noisy.ctypes.data),
+                          C.c_void_p(out.ctypes.data), C.c_int(threads))
+    if rc:
+        raise RuntimeError("orc_filter failed: %d" % rc)
+    return out
+
+
+def rgba8(rgba):
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    out = np.empty(rgba.shape, np.uint8)
+    lib().orc_rgba8(C.c_void_p(rgba.ctypes.data), C.c_void_p(out.ctypes.data), C.c_int64(rgba.size))
+    return out
+
+
+def algorithmic_bytes(stats, data_dim, pixels):
+    """child int32 per level + sigma fp16 per step, SH coeffs per distinct hit
+    leaf, 48 B of aux+RGBA32F stores per pixel."""
+    return (4 * stats["levels"] + 2 * stats["steps"]
+            + 2 * (data_dim - 1) * stats["hit_leaves"] + 48 * pixels)

@@ -1,0 +1,185 @@
+/*
+ * rto.h -- C ABI of the MI355X-native RT-Octree render path (librto.so).
+ *
+ * Drop-in boundary for the reference's operator `volrend::launch_renderer` and the objects it
+ * takes (reference paths are relative to /root/reference):
+ *
+ *   rto_tree      <- volrend::N3Tree            renderer/include/volrend/n3tree.hpp, src/n3tree.cpp:111-362,
+ *                                               src/cuda/n3tree.cu:9-49   (tree.npz -> device arrays)
+ *   rto_camera    <- internal::CameraSpec       renderer/include/volrend/internal/data_spec.hpp:11-24
+ *   rto_options   <- volrend::RenderOptions     renderer/include/volrend/render_options.hpp:13-78
+ *   rto_ctx       <- volrend::RenderContext     renderer/include/volrend/render_context.hpp:14-214
+ *   rto_launch_renderer <- launch_renderer      renderer/include/volrend/cuda/renderer_kernel.hpp:11-16,
+ *                                               src/cuda/volrend.cu:236-285
+ *   rto_filtering <- denoiser::filtering        denoiser/extension/filtering.h:7-13, filtering.cu:701-717
+ *   rto_ctx_download_rgba8 <- the u8 conversion renderer/main_headless.cpp:521-538
+ *
+ * Plain pointers and sizes only; no torch / HIP types in the signatures (streams are passed as
+ * `void*` = hipStream_t, NULL = the default stream).  All device pointers returned by the
+ * accessors are plain linear hipMalloc memory (the reference's cudaArray/surface/texture objects
+ * are replaced by linear buffers with the same logical layout).
+ *
+ * Error convention: every function returning int returns RTO_OK (0) or a negative RTO_E_* code;
+ * rto_last_error() gives the message for the calling thread.  The library never calls exit()
+ * (the reference does: src/cuda/common.cu:8-21) and never falls back to a CPU path: without a
+ * usable HIP device every entry point that needs one fails with RTO_E_HIP.
+ */
+#ifndef RTO_H
+#define RTO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTO_OK 0
+#define RTO_E_INVALID -1     /* bad argument */
+#define RTO_E_SPP -2         /* spp not in {1,2,3,4,6,8,16,32} (volrend.cu:266-278) */
+#define RTO_E_UNSUPPORTED -3 /* feature outside the headless path (probe, rot_dirs, SG/ASG) */
+#define RTO_E_HIP -4         /* HIP runtime error / no device */
+#define RTO_E_IO -5          /* file missing / malformed */
+#define RTO_E_FORMAT -6      /* npz content violates the tree schema (n3tree.cpp:283-291,345) */
+
+#define RTO_AUX_CHANNELS 8   /* render_context.hpp:23 */
+#define RTO_BASIS_MAX 25     /* render_options.hpp:7 */
+
+/* data_format.hpp:8-14 */
+enum { RTO_FMT_RGBA = 0, RTO_FMT_SH = 1, RTO_FMT_SG = 2, RTO_FMT_ASG = 3 };
+
+/* RenderOptions, field for field (render_options.hpp:13-78).  bools are ints. */
+typedef struct rto_options {
+    float step_size;              /* 1e-4 */
+    float sigma_thresh;           /* 1e-2 */
+    float stop_thresh;            /* 1e-2; parsed, unused by regular tracking */
+    float background_brightness;  /* 1.0 */
+    float render_bbox[6];         /* {0,0,0,1,1,1} */
+    int basis_minmax[2];          /* {0,24} */
+    float rot_dirs[3];            /* {0,0,0} */
+    int show_grid;                /* false; GUI */
+    int grid_max_depth;           /* 4; GUI */
+    int render_depth;             /* false; unused by the kernel */
+    int enable_probe;             /* false; GUI probe -> RTO_E_UNSUPPORTED when set */
+    float probe[3];               /* {0,0,1} */
+    int probe_disp_size;          /* 100 */
+    int denoise;                  /* true: kernel writes the noisy image, else the final image */
+    int spp;                      /* 1 */
+} rto_options;
+
+/* CameraSpec (data_spec.hpp:11-24).  transform = 4x3 column-major camera-to-world
+ * (camera.hpp: glm::mat4x3): [0..8] rotation columns, [9..11] centre.  Passed to the kernel by
+ * value: no per-frame H2D copy (camera.cpp:67-75 in the reference). */
+typedef struct rto_camera {
+    int width, height;
+    float fx, fy;
+    float transform[12];
+} rto_camera;
+
+typedef struct rto_tree_info {
+    int64_t capacity;   /* nodes */
+    int N;              /* branching per axis (2) */
+    int data_dim;       /* 3*basis_dim+1, or 4 for RGBA */
+    int format;         /* RTO_FMT_* */
+    int basis_dim;      /* -1 for RGBA */
+    float scale[3];     /* invradius3 */
+    float offset[3];
+    int use_ndc;
+    float ndc_width, ndc_height, ndc_focal;
+    int max_depth;      /* deepest leaf level (levels of child[] visited to reach it) */
+    int64_t device_bytes;
+} rto_tree_info;
+
+typedef struct rto_tree rto_tree; /* opaque */
+typedef struct rto_ctx rto_ctx;   /* opaque */
+
+/* Which traversal kernel rto_launch_renderer uses.  Results are bit-identical. */
+enum {
+    RTO_KERNEL_AUTO = 0,    /* fast path when the tree allows it (N == 2), else generic */
+    RTO_KERNEL_GENERIC = 1, /* root-restart descent, one thread per pixel (any N) */
+    RTO_KERNEL_FAST = 2     /* integer descent + ancestor stack (N == 2) */
+};
+
+const char* rto_version(void);
+const char* rto_last_error(void);
+/* number of HIP devices visible, or RTO_E_HIP */
+int rto_device_count(void);
+
+/* ---- options (render_options.hpp) ---- */
+void rto_options_default(rto_options* o);
+/* Parses the reference's options JSON (options/opt.json).  Like NLOHMANN_DEFINE_TYPE_INTRUSIVE
+ * (render_options.hpp:61-77) all 11 keys are required; render_bbox/basis_minmax/rot_dirs keep
+ * their defaults. */
+int rto_options_from_json_file(const char* path, rto_options* o);
+int rto_options_from_json(const char* text, rto_options* o);
+
+/* ---- tree (N3Tree) ---- */
+/* N3Tree::open (n3tree.cpp:111-154) + load_cuda (n3tree.cu:9-41).  Reads `tree.npz` (dense fp16
+ * `data`, or the quantised set quant_colors/quant_map/sigma[/data_retained]) and uploads it. */
+int rto_tree_load_npz(const char* path, int device, rto_tree** out);
+/* Same upload from host arrays: child int32 [capacity*N^3], data fp16 bits
+ * [capacity*N^3*data_dim], data_format like "SH9"/"SH16"/"RGBA" (DataFormat::parse,
+ * n3tree.cpp:55-78). */
+int rto_tree_from_arrays(const int32_t* child, const uint16_t* data, int64_t capacity, int N,
+                         int data_dim, const char* data_format, const float scale[3],
+                         const float offset[3], int device, rto_tree** out);
+/* main_headless.cpp:400-405 (llff): switch the NDC warp on. width <= 0 turns it off. */
+int rto_tree_set_ndc(rto_tree* t, float ndc_width, float ndc_height, float ndc_focal);
+int rto_tree_get_info(const rto_tree* t, rto_tree_info* info);
+void rto_tree_free(rto_tree* t);
+
+/* ---- render context (RenderContext) ---- */
+/* RenderContext::update (render_context.hpp:70-91): aux [8][H][W] f32, noisy and final images
+ * [H][W][4] f32, rng = pcg32(20230418) (:16).  offscreen is always true (headless path). */
+int rto_ctx_create(int width, int height, int device, rto_ctx** out);
+void rto_ctx_free(rto_ctx* c);
+int rto_ctx_width(const rto_ctx* c);
+int rto_ctx_height(const rto_ctx* c);
+float* rto_ctx_aux(rto_ctx* c);    /* device, planar [8][H][W]: r,g,b,a,r^2,g^2,b^2,a^2 */
+float* rto_ctx_noisy(rto_ctx* c);  /* device, [H][W][4] (reference: noisy_image_arr) */
+float* rto_ctx_image(rto_ctx* c);  /* device, [H][W][4] (reference: image_arr / surf_obj) */
+/* ctx.rng (pcg32): seed(initstate, initseq) pcg32.h:53-59; advance(delta) :145-166 (the
+ * reference's per-frame `ctx.rng.advance()` is delta = 1<<32) */
+void rto_ctx_rng_seed(rto_ctx* c, uint64_t initstate, uint64_t initseq);
+void rto_ctx_rng_advance(rto_ctx* c, int64_t delta);
+void rto_ctx_rng_set(rto_ctx* c, uint64_t state, uint64_t inc);
+void rto_ctx_rng_get(const rto_ctx* c, uint64_t* state, uint64_t* inc);
+/* choose the traversal kernel (RTO_KERNEL_*); default AUTO */
+int rto_ctx_set_kernel(rto_ctx* c, int kernel);
+
+/* ---- the operator ---- */
+/* launch_renderer(tree, cam, options, ctx, stream, offscreen=true) (volrend.cu:236-285).
+ * Asynchronous on `stream`.  Writes ctx aux + (options->denoise ? noisy : image).
+ * cam->width/height must equal the ctx size. */
+int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_options* options,
+                        rto_ctx* ctx, void* stream);
+
+/* denoiser::filtering(stream, weight_map[L,H,W], guidance_map[L,H,W], img_in, img_out)
+ * (filtering.cu:701-717).  All pointers are device pointers; img_in/img_out are [H][W][4] f32
+ * (the reference passes ctx.noisy_tex_obj / ctx.surf_obj, denoiser.cpp:56-57).  L in 1..6. */
+int rto_filtering(void* stream, const float* weight_map, const float* guidance_map, int L, int H,
+                  int W, const float* img_in, float* img_out);
+/* convenience: filtering from ctx noisy -> ctx image */
+int rto_ctx_filtering(rto_ctx* c, void* stream, const float* weight_map, const float* guidance_map, int L);
+
+/* ---- outputs (main_headless.cpp:508-540) ---- */
+/* final image -> RGBA8 on the device ((uint8_t)(f*255), truncation) -> host [H][W][4];
+ * synchronises `stream`.  which: 0 = final image, 1 = noisy image */
+int rto_ctx_download_rgba8(rto_ctx* c, void* stream, int which, uint8_t* host_out);
+int rto_ctx_download_image(rto_ctx* c, void* stream, int which, float* host_out); /* [H][W][4] f32 */
+int rto_ctx_download_aux(rto_ctx* c, void* stream, float* host_out);              /* [8][H][W] f32 */
+
+/* ---- event timer (RenderContext::Timer, render_context.hpp:122-213) ---- */
+enum { RTO_T_RENDER = 0, RTO_T_TORCH = 1, RTO_T_FILTER = 2 };
+int rto_timer_reset(rto_ctx* c, void* stream);
+int rto_timer_start(rto_ctx* c, int which);
+int rto_timer_stop(rto_ctx* c, int which);
+/* Timer::record(denoise): synchronise on the last stop event and accumulate */
+int rto_timer_record(rto_ctx* c, int denoise);
+/* Timer::report: mean ms per bucket and FPS = 1000/(render+torch+filter) */
+int rto_timer_report(const rto_ctx* c, float ms_out[3], float* fps_out, int* frames_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTO_H */

@@ -1,0 +1,112 @@
+// filter_kernels.hip -- multi-level guided softmax filter (the GuidanceNet "kernel applying" stage).
+//
+// Reference: denoiser/extension/filtering.cu:108-228 `kernel::applying<Out,16,32,SUPPORT>`, launched
+// once per level by host::forward (:440-470) with SUPPORT = level+1; level 0 overwrites the output
+// with alpha = 1 (:47-60), later levels read-modify-write rgb (:62-106) and therefore depend on
+// same-stream ordering (:224-226).
+//
+// Here all L levels run in ONE launch: a workgroup stages the noisy tile (halo = L) and the L
+// guidance tiles in LDS once, every thread walks level 0..L-1 for its pixel and adds the level
+// results in registers in level order -- the same fp32 sequence as L read-modify-write passes, so
+// the output is bit-identical to the level-by-level statement (oracle/rto_oracle.c orc_filter) while
+// the noisy image is read once instead of L times and the output is written once.
+//
+// Per level, per pixel p (support S = level+1, window (2S+1)^2, row-major tap order):
+//   m = max_q g(q);  k_q = exp(g(q) - m);  out += (sum_q k_q rgb(q)) * (w(p) / sum_q k_q)
+// Out-of-image taps: rgb = 0, g = -FLT_MAX (:140-143).
+#include <hip/hip_runtime.h>
+
+#include "rto_launch.h"
+
+#pragma clang fp contract(off)
+
+namespace rto {
+
+constexpr int kFiltW = 32, kFiltH = 8;  // output tile per 256-thread workgroup
+
+template <int L>
+__global__ void __launch_bounds__(256) filter_fused(const float* __restrict__ weight,    // [L][H][W]
+                                                     const float* __restrict__ guidance,  // [L][H][W]
+                                                     const float4* __restrict__ img_in,   // [H][W]
+                                                     float4* __restrict__ img_out,        // [H][W]
+                                                     int H, int W) {
+    constexpr int TW = kFiltW + 2 * L, TH = kFiltH + 2 * L;
+    __shared__ float4 s_rgb[TH * TW];
+    __shared__ float s_g[L][TH * TW];
+
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * kFiltW - L, y0 = blockIdx.y * kFiltH - L;
+    const int64_t HW = (int64_t)H * W;
+
+    for (int e = tid; e < TH * TW; e += 256) {
+        const int ty = e / TW, tx = e - ty * TW;
+        const int gx = x0 + tx, gy = y0 + ty;
+        const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
+        const int64_t gi = (int64_t)gy * W + gx;
+        s_rgb[e] = in ? img_in[gi] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int l = 0; l < L; ++l) s_g[l][e] = in ? guidance[l * HW + gi] : -3.402823466e+38f;
+    }
+    __syncthreads();
+
+    const int lx = tid & (kFiltW - 1), ly = tid / kFiltW;
+    const int px = blockIdx.x * kFiltW + lx, py = blockIdx.y * kFiltH + ly;
+    if (px >= W || py >= H) return;
+    const int64_t pidx = (int64_t)py * W + px;
+
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const int S = l + 1;
+        const float* g = s_g[l];
+        const int cx = lx + L, cy = ly + L;
+        float max_val = -3.402823466e+38f;
+        for (int dy = -S; dy <= S; ++dy)
+            for (int dx = -S; dx <= S; ++dx) max_val = fmaxf(max_val, g[(cy + dy) * TW + cx + dx]);
+        float r = 0.f, gg = 0.f, b = 0.f, kernel_sum = 0;
+        for (int dy = -S; dy <= S; ++dy)
+            for (int dx = -S; dx <= S; ++dx) {
+                const int e = (cy + dy) * TW + cx + dx;
+                const float k = det_expf(g[e] - max_val);
+                kernel_sum += k;
+                const float4 t = s_rgb[e];
+                r += t.x * k;
+                gg += t.y * k;
+                b += t.z * k;
+            }
+        const float inv = 1.0f / kernel_sum;
+        const float w = weight[l * HW + pidx] * inv;
+        r *= w;
+        gg *= w;
+        b *= w;
+        if (l == 0) {
+            o0 = r;
+            o1 = gg;
+            o2 = b;
+        } else {
+            o0 += r;
+            o1 += gg;
+            o2 += b;
+        }
+    }
+    img_out[pidx] = make_float4(o0, o1, o2, 1.0f);
+}
+
+hipError_t launch_filter(const float* weight, const float* guidance, int L, int H, int W, const float* img_in,
+                         float* img_out, hipStream_t stream) {
+    const dim3 grid((W + kFiltW - 1) / kFiltW, (H + kFiltH - 1) / kFiltH), block(256);
+    const float4* in4 = reinterpret_cast<const float4*>(img_in);
+    float4* out4 = reinterpret_cast<float4*>(img_out);
+    switch (L) {  // kernel_apply filtering.cu:338-367 supports SUPPORT 1..6
+        case 1: hipLaunchKernelGGL(filter_fused<1>, grid, block, 0, stream, weight, guidance, in4, out4, H, W); break;
+        case 2: hipLaunchKernelGGL(filter_fused<2>, grid, block, 0, stream, weight, guidance, in4, out4, H, W); break;
+        case 3: hipLaunchKernelGGL(filter_fused<3>, grid, block, 0, stream, weight, guidance, in4, out4, H, W); break;
+        case 4: hipLaunchKernelGGL(filter_fused<4>, grid, block, 0, stream, weight, guidance, in4, out4, H, W); break;
+        case 5: hipLaunchKernelGGL(filter_fused<5>, grid, block, 0, stream, weight, guidance, in4, out4, H, W); break;
+        case 6: hipLaunchKernelGGL(filter_fused<6>, grid, block, 0, stream, weight, guidance, in4, out4, H, W); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace rto

@@ -1,0 +1,621 @@
+// render_kernels.hip -- batched-regular-tracking octree renderer for gfx950 (MI355X).
+//
+// What the reference computes (relative to /root/reference):
+//   render_kernel<SPP>      renderer/src/cuda/volrend.cu:84-213   pixel -> ray, RNG jump, trace, bg
+//                                                                  composite, aux + image writes
+//   trace_ray<float,SPP>    renderer/include/volrend/cuda/rt_core.cuh:195-332
+//   query_single_from_root  renderer/include/volrend/internal/n3tree_query.hpp:13-48
+//   maybe_precalc_basis     renderer/include/volrend/internal/lumisphere.hpp:38-80 (SH)
+//   sample_dst<SPP>         rt_core.cuh:67-193
+//
+// Two kernels with bit-identical results (tests/test_render_parity.py):
+//   render_generic<SPP>  any N, root-restart float descent -- the plain statement of the algorithm.
+//   render_fast<SPP>     N == 2: integer descent over a 4-byte-per-slot traversal image (child
+//                        offset or leaf sigma in one word), restart from the deepest ancestor
+//                        shared with the previous step (per-lane ancestor stack in LDS),
+//                        8x8-pixel wave tiles in an XCD-interleaved strip order, register-resident
+//                        thresholds/hit lists with static indexing only, table-driven RNG jump.
+//
+// Why the descent can be done on integers (SURVEY.md section 7 "hard parts"): after the clamp to
+// [0, 1-1e-6] every operation of the reference descent (x*=2; floor; x-=floor) is exact in fp32,
+// so the child digit at level l is bit (23-l) of floor(pos*2^24) and the leaf-local coordinate is
+// frac(pos * 2^(l+1)) exactly.
+#include <hip/hip_runtime.h>
+
+#include "rto_kernel_types.h"
+
+#pragma clang fp contract(off)
+
+namespace rto {
+
+// ------------------------------------------------------------------ shared pieces
+
+// cuda/common.cuh:16-27
+RTO_DEV float norm3(const float* d) { return sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]); }
+RTO_DEV void normalize3(float* d) {
+    const float invnorm = 1.f / norm3(d);
+    d[0] *= invnorm;
+    d[1] *= invnorm;
+    d[2] *= invnorm;
+}
+
+// volrend.cu:23-56,138-144: pixel -> (dir, vdir, cen) in tree space
+RTO_DEV void ray_setup(int x, int y, const CamDev& cam, const TreeDev& tree, float* dir, float* vdir,
+                       float* cen) {
+    const float xyz[3] = {(x - 0.5f * cam.width) / cam.fx, -(y - 0.5f * cam.height) / cam.fy, -1.0f};
+    const float* m = cam.transform;
+    dir[0] = m[0] * xyz[0] + m[3] * xyz[1] + m[6] * xyz[2];
+    dir[1] = m[1] * xyz[0] + m[4] * xyz[1] + m[7] * xyz[2];
+    dir[2] = m[2] * xyz[0] + m[5] * xyz[1] + m[8] * xyz[2];
+    normalize3(dir);
+    cen[0] = m[9];
+    cen[1] = m[10];
+    cen[2] = m[11];
+    vdir[0] = dir[0];
+    vdir[1] = dir[1];
+    vdir[2] = dir[2];
+    if (tree.ndc_width > 0) {  // maybe_world2ndc :35-56
+        const float t = -(1.f + cen[2]) / dir[2];
+        for (int i = 0; i < 3; ++i) cen[i] = cen[i] + t * dir[i];
+        dir[0] = -((2 * tree.ndc_focal) / tree.ndc_width) * (dir[0] / dir[2] - cen[0] / cen[2]);
+        dir[1] = -((2 * tree.ndc_focal) / tree.ndc_height) * (dir[1] / dir[2] - cen[1] / cen[2]);
+        dir[2] = -2 / cen[2];
+        cen[0] = -((2 * tree.ndc_focal) / tree.ndc_width) * (cen[0] / cen[2]);
+        cen[1] = -((2 * tree.ndc_focal) / tree.ndc_height) * (cen[1] / cen[2]);
+        cen[2] = 1 + 2 / cen[2];
+        normalize3(dir);
+    }
+    for (int i = 0; i < 3; ++i) cen[i] = tree.offset[i] + tree.scale[i] * cen[i];
+}
+
+// rt_core.cuh:206-222: scale dir, invdir, slab test.  returns false when the ray misses the box.
+RTO_DEV bool ray_enter(const TreeDev& tree, const OptDev& opt, float* dir, const float* cen, float tmax_bg,
+                       float* invdir, float& delta_scale, float& tmin, float& tmax) {
+    dir[0] *= tree.scale[0];
+    dir[1] *= tree.scale[1];
+    dir[2] *= tree.scale[2];
+    delta_scale = 1.f / norm3(dir);
+    dir[0] *= delta_scale;
+    dir[1] *= delta_scale;
+    dir[2] *= delta_scale;
+    tmax_bg /= delta_scale;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) invdir[i] = 1.f / (dir[i] + 1e-9);  // double
+    tmin = 0.0;
+    tmax = 1e4;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {  // _dda_world :19-36, double sub-expressions
+        const float t1 = (opt.render_bbox[i] + 1e-6 - cen[i]) * invdir[i];
+        const float t2 = (opt.render_bbox[i + 3] - 1e-6 - cen[i]) * invdir[i];
+        tmin = f_max(tmin, f_min(t1, t2));
+        tmax = f_min(tmax, f_max(t1, t2));
+    }
+    tmax = f_min(tmax, tmax_bg);
+    return !(tmax < 0 || tmin > tmax);
+}
+
+// _dda_unit rt_core.cuh:38-51
+RTO_DEV float dda_unit(const float* p, const float* invdir) {
+    float tm = 1e4;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float t1 = -p[i] * invdir[i];
+        const float t2 = t1 + invdir[i];
+        tm = f_min(tm, f_max(t1, t2));
+    }
+    return tm;
+}
+
+// lumisphere.hpp:38-80; double literals, one rounding per assignment
+RTO_DEV void sh_basis(int basis_dim, const float* dir, float* out) {
+    out[0] = 0.28209479177387814;
+    const float x = dir[0], y = dir[1], z = dir[2];
+    const float xx = x * x, yy = y * y, zz = z * z;
+    const float xy = x * y, yz = y * z, xz = x * z;
+    switch (basis_dim) {
+        case 25:
+            out[16] = 2.5033429417967046 * xy * (xx - yy);
+            out[17] = -1.7701307697799304 * yz * (3 * xx - yy);
+            out[18] = 0.9461746957575601 * xy * (7 * zz - 1.f);
+            out[19] = -0.6690465435572892 * yz * (7 * zz - 3.f);
+            out[20] = 0.10578554691520431 * (zz * (35 * zz - 30) + 3);
+            out[21] = -0.6690465435572892 * xz * (7 * zz - 3);
+            out[22] = 0.47308734787878004 * (xx - yy) * (7 * zz - 1.f);
+            out[23] = -1.7701307697799304 * xz * (xx - 3 * yy);
+            out[24] = 0.6258357354491761 * (xx * (xx - 3 * yy) - yy * (3 * xx - yy));
+            [[fallthrough]];
+        case 16:
+            out[9] = -0.5900435899266435 * y * (3 * xx - yy);
+            out[10] = 2.890611442640554 * xy * z;
+            out[11] = -0.4570457994644658 * y * (4 * zz - xx - yy);
+            out[12] = 0.3731763325901154 * z * (2 * zz - 3 * xx - 3 * yy);
+            out[13] = -0.4570457994644658 * x * (4 * zz - xx - yy);
+            out[14] = 1.445305721320277 * z * (xx - yy);
+            out[15] = -0.5900435899266435 * x * (xx - 3 * yy);
+            [[fallthrough]];
+        case 9:
+            out[4] = 1.0925484305920792 * xy;
+            out[5] = -1.0925484305920792 * yz;
+            out[6] = 0.31539156525252005 * (2.0 * zz - xx - yy);
+            out[7] = -1.0925484305920792 * xz;
+            out[8] = 0.5462742152960396 * (xx - yy);
+            [[fallthrough]];
+        case 4:
+            out[1] = -0.4886025119029199 * y;
+            out[2] = 0.4886025119029199 * z;
+            out[3] = -0.4886025119029199 * x;
+    }
+}
+
+// basis for the ray + the basis_minmax mask (rt_core.cuh:277-284)
+RTO_DEV void ray_basis(const TreeDev& tree, const OptDev& opt, const float* vdir, float* basis_fn) {
+#pragma unroll
+    for (int i = 0; i < RTO_BASIS_MAX_DEV; ++i) basis_fn[i] = 0.f;
+    if (tree.format == 1 /*SH*/) sh_basis(tree.basis_dim, vdir, basis_fn);
+#pragma unroll
+    for (int i = 0; i < RTO_BASIS_MAX_DEV; ++i)
+        if (i < opt.basis_minmax[0] || i > opt.basis_minmax[1]) basis_fn[i] = 0.f;
+}
+
+// rt_core.cuh:286-325 for one hit leaf: out[0..2] += cnt * sigmoid(<basis, coeffs>), out[3] += cnt.
+// The summation order (DC, then the 16..24 group, 9..15, 4..8, 1..3, each left to right) is part of
+// the result.
+RTO_DEV void shade_leaf(const TreeDev& tree, const uint16_t* __restrict__ tv, const float* basis_fn, float cnt,
+                        float* out) {
+    const int basis_dim = tree.basis_dim;
+    if (basis_dim >= 0) {
+        int off = 0;
+#define MUL_BASIS_I(k) (basis_fn[k] * half_bits_to_float(tv[off + (k)]))
+        for (int c = 0; c < 3; ++c) {
+            float tmp = basis_fn[0] * half_bits_to_float(tv[off]);
+            switch (basis_dim) {
+                case 25:
+                    tmp += MUL_BASIS_I(16) + MUL_BASIS_I(17) + MUL_BASIS_I(18) + MUL_BASIS_I(19) + MUL_BASIS_I(20) +
+                           MUL_BASIS_I(21) + MUL_BASIS_I(22) + MUL_BASIS_I(23) + MUL_BASIS_I(24);
+                    [[fallthrough]];
+                case 16:
+                    tmp += MUL_BASIS_I(9) + MUL_BASIS_I(10) + MUL_BASIS_I(11) + MUL_BASIS_I(12) + MUL_BASIS_I(13) +
+                           MUL_BASIS_I(14) + MUL_BASIS_I(15);
+                    [[fallthrough]];
+                case 9:
+                    tmp += MUL_BASIS_I(4) + MUL_BASIS_I(5) + MUL_BASIS_I(6) + MUL_BASIS_I(7) + MUL_BASIS_I(8);
+                    [[fallthrough]];
+                case 4:
+                    tmp += MUL_BASIS_I(1) + MUL_BASIS_I(2) + MUL_BASIS_I(3);
+            }
+            out[c] += cnt / (1.f + det_expf(-tmp));
+            off += basis_dim;
+        }
+#undef MUL_BASIS_I
+    } else {
+        for (int j = 0; j < 3; ++j) out[j] += half_bits_to_float(tv[j]) * cnt;
+    }
+    out[3] += cnt;
+}
+
+// volrend.cu:174-212 (offscreen): background composite, 8 aux planes, RGBA32F image, alpha = 1
+RTO_DEV void write_pixel(const FrameOut& fo, int64_t SIZE, int idx, float bg, float* out) {
+    const float nalpha = 1.f - out[3];
+    const float remain = bg * nalpha;
+    out[0] += remain;
+    out[1] += remain;
+    out[2] += remain;
+    float* a = fo.aux + idx;
+    a[0] = out[0];
+    a[SIZE] = out[1];
+    a[2 * SIZE] = out[2];
+    a[3 * SIZE] = out[3];
+    a[4 * SIZE] = out[0] * out[0];
+    a[5 * SIZE] = out[1] * out[1];
+    a[6 * SIZE] = out[2] * out[2];
+    a[7 * SIZE] = out[3] * out[3];
+    reinterpret_cast<float4*>(fo.image)[idx] = make_float4(out[0], out[1], out[2], 1.0f);
+}
+
+// ------------------------------------------------------------------ generic kernel (any N)
+
+// n3tree_query.hpp:13-48
+RTO_DEV int64_t query_from_root(const TreeDev& tree, float* xyz, float& cube_sz) {
+    const float fN = (float)tree.N;
+    xyz[0] = f_max(f_min(xyz[0], 1.f - 1e-6f), 0.f);
+    xyz[1] = f_max(f_min(xyz[1], 1.f - 1e-6f), 0.f);
+    xyz[2] = f_max(f_min(xyz[2], 1.f - 1e-6f), 0.f);
+    int64_t ptr = 0;
+    cube_sz = fN;
+    while (true) {
+        float index = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            xyz[i] *= fN;
+            const float idx_dimi = floorf(xyz[i]);
+            index = index * fN + idx_dimi;
+            xyz[i] -= idx_dimi;
+        }
+        const int64_t sub_ptr = ptr + (int32_t)index;
+        const int64_t skip = tree.child[sub_ptr];
+        if (skip == 0) return sub_ptr;
+        cube_sz *= fN;
+        ptr += skip * tree.N3;
+    }
+}
+
+template <int SPP>
+__global__ void __launch_bounds__(256) render_generic(const TreeDev tree, const CamDev cam, const OptDev opt,
+                                                       const Pcg32 rng_base, const FrameOut fo) {
+    const int64_t SIZE = (int64_t)cam.width * cam.height;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= SIZE) return;
+    const int x = idx % cam.width, y = idx / cam.width;
+    float out[4] = {0.f, 0.f, 0.f, 0.f};
+
+    if (tree.N > 0) {  // enable_draw volrend.cu:98
+        float dir[3], vdir[3], cen[3], invdir[3];
+        ray_setup(x, y, cam, tree, dir, vdir, cen);
+        Pcg32 rng = rng_base;
+        pcg_advance(rng, (int64_t)(idx * SPP));  // volrend.cu:157
+        float delta_scale, tmin, tmax;
+        if (ray_enter(tree, opt, dir, cen, 1e9f, invdir, delta_scale, tmin, tmax)) {
+            // sample_dst rt_core.cuh:67-193
+            float dst[SPP + 1];
+            for (int n = 1; n <= SPP; ++n) {
+                const float tv = -det_logf(1.0f - pcg_next_float(rng));
+                if (n == 1) {
+                    dst[0] = tv;
+                } else if (tv <= dst[0]) {
+                    for (int i = n - 1; i > 0; i--) dst[i] = dst[i - 1];
+                    dst[0] = tv;
+                } else {
+                    int i = n - 1;
+                    while (dst[i - 1] > tv) {
+                        dst[i] = dst[i - 1];
+                        i--;
+                    }
+                    dst[i] = tv;
+                }
+            }
+            dst[SPP] = 3.402823466e+38f;
+
+            int64_t tree_vals[SPP];
+            float cnts[SPP];
+            for (int i = 0; i < SPP; ++i) cnts[i] = 0.f;
+            uint32_t spp = 0, sh_nums = 0;
+            float src = 0;
+            float t = tmin;
+            while (t < tmax) {  // rt_core.cuh:241-270
+                float pos[3] = {cen[0] + t * dir[0], cen[1] + t * dir[1], cen[2] + t * dir[2]};
+                float cube_sz;
+                const int64_t leaf = query_from_root(tree, pos, cube_sz);
+                const float t_subcube = dda_unit(pos, invdir) / cube_sz;
+                const float delta_t = t_subcube + opt.step_size;
+                const float sigma = half_bits_to_float(tree.data[leaf * tree.data_dim + tree.data_dim - 1]);
+                if (sigma > opt.sigma_thresh) {
+                    const float delta = delta_t * delta_scale * sigma;
+                    if (src + delta >= dst[spp]) {
+                        float& cnt = cnts[sh_nums];
+                        tree_vals[sh_nums] = leaf;
+                        ++sh_nums;
+                        do {
+                            ++cnt;
+                            ++spp;
+                        } while (src + delta >= dst[spp]);
+                        if (spp == SPP) break;
+                    }
+                    src += delta;
+                }
+                t += delta_t;
+            }
+            if (sh_nums != 0) {
+                float basis_fn[RTO_BASIS_MAX_DEV];
+                ray_basis(tree, opt, vdir, basis_fn);
+                for (uint32_t i = 0; i < sh_nums; i++)
+                    shade_leaf(tree, tree.data + tree_vals[i] * tree.data_dim, basis_fn, cnts[i], out);
+                constexpr float INV_SPP = 1.0f / SPP;
+                out[0] *= INV_SPP;
+                out[1] *= INV_SPP;
+                out[2] *= INV_SPP;
+                out[3] *= INV_SPP;
+            }
+        }
+    }
+    write_pixel(fo, SIZE, idx, opt.background_brightness, out);
+}
+
+// ------------------------------------------------------------------ traversal image
+
+// One word per child slot: internal -> child[] value, leaf -> kLeafTag | sigma fp16 bits.
+// Derived data (like the reference's commented-out occupancy LUT, n3tree.cpp:206-225): it only
+// re-packs what child[]/data[] already say, so traversal decisions cannot change.
+__global__ void build_nodew_kernel(const int32_t* __restrict__ child, const uint16_t* __restrict__ data,
+                                   int64_t n_slots, int data_dim, uint32_t* __restrict__ nodew,
+                                   int* __restrict__ bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    const int32_t c = child[i];
+    if (c == 0) {
+        nodew[i] = kLeafTag | (uint32_t)data[i * data_dim + data_dim - 1];
+    } else {
+        if (nodew_is_leaf((uint32_t)c)) atomicExch(bad, 1);  // |offset| >= 2^30: not encodable
+        nodew[i] = (uint32_t)c;
+    }
+}
+
+// ------------------------------------------------------------------ fast kernel (N == 2)
+
+constexpr int kTileW = 32, kTileH = 8;  // workgroup tile; each wave owns an 8x8 sub-tile
+
+// workgroup -> tile (XCD-interleaved strips, rto_kernel_types.h TileMap)
+RTO_DEV bool block_tile(const TileMap& tm, int b, int& tx, int& ty) {
+    const int xcd = b & 7, q = b >> 3;
+    const int per_strip = tm.strip_rows * tm.tiles_x;
+    const int j = q / per_strip, rem = q - j * per_strip;
+    ty = (j * 8 + xcd) * tm.strip_rows + rem / tm.tiles_x;
+    tx = rem % tm.tiles_x;
+    return ty < tm.tiles_y;
+}
+
+// Hit list entry: leaf slot in the low 27 bits, (count - 1) in the top 5.
+RTO_DEV uint32_t hit_pack(uint32_t slot, uint32_t cnt) { return slot | ((cnt - 1u) << 27); }
+
+// Loads the `DD` fp16 values of one leaf record with aligned dword loads and shades it.
+// DD = data_dim (28 for SH9, 49 for SH16); the record starts at a 2-byte aligned address.
+template <int DD>
+RTO_DEV void shade_leaf_packed(const TreeDev& tree, uint32_t slot, const float* basis_fn, float cnt, float* out) {
+    constexpr int B = (DD - 1) / 3;
+    constexpr int NDW = (DD + 2) / 2;  // dwords covering DD halves at either alignment
+    const uint64_t hoff = (uint64_t)slot * DD;  // in halves
+    const uint32_t odd = (uint32_t)hoff & 1u;
+    const uint32_t* __restrict__ p = reinterpret_cast<const uint32_t*>(tree.data + (hoff - odd));
+    uint32_t dw[NDW];
+#pragma unroll
+    for (int i = 0; i < NDW; ++i) dw[i] = p[i];
+    // half k of the record is packed half (k + odd)
+    auto coef = [&](int k) -> float {
+        const uint32_t a = (k & 1) ? (dw[k >> 1] >> 16) : (dw[k >> 1] & 0xffffu);
+        const uint32_t b = ((k + 1) & 1) ? (dw[(k + 1) >> 1] >> 16) : (dw[(k + 1) >> 1] & 0xffffu);
+        return half_bits_to_float((uint16_t)(odd ? b : a));
+    };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int off = c * B;
+        float tmp = basis_fn[0] * coef(off);
+        if constexpr (B >= 25) {
+            tmp += basis_fn[16] * coef(off + 16) + basis_fn[17] * coef(off + 17) + basis_fn[18] * coef(off + 18) +
+                   basis_fn[19] * coef(off + 19) + basis_fn[20] * coef(off + 20) + basis_fn[21] * coef(off + 21) +
+                   basis_fn[22] * coef(off + 22) + basis_fn[23] * coef(off + 23) + basis_fn[24] * coef(off + 24);
+        }
+        if constexpr (B >= 16) {
+            tmp += basis_fn[9] * coef(off + 9) + basis_fn[10] * coef(off + 10) + basis_fn[11] * coef(off + 11) +
+                   basis_fn[12] * coef(off + 12) + basis_fn[13] * coef(off + 13) + basis_fn[14] * coef(off + 14) +
+                   basis_fn[15] * coef(off + 15);
+        }
+        if constexpr (B >= 9) {
+            tmp += basis_fn[4] * coef(off + 4) + basis_fn[5] * coef(off + 5) + basis_fn[6] * coef(off + 6) +
+                   basis_fn[7] * coef(off + 7) + basis_fn[8] * coef(off + 8);
+        }
+        if constexpr (B >= 4) {
+            tmp += basis_fn[1] * coef(off + 1) + basis_fn[2] * coef(off + 2) + basis_fn[3] * coef(off + 3);
+        }
+        out[c] += cnt / (1.f + det_expf(-tmp));
+    }
+    out[3] += cnt;
+}
+
+template <int SPP>
+__global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const CamDev cam, const OptDev opt,
+                                                    const Pcg32 rng_base, const PcgJumpEntry* __restrict__ jump,
+                                                    const TileMap tm, const FrameOut fo) {
+    extern __shared__ uint32_t s_stack[];  // [max_depth][256] ancestor node indices, level-major
+
+    int tx, ty;
+    if (!block_tile(tm, blockIdx.x, tx, ty)) return;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int x = tx * kTileW + wave * 8 + (lane & 7);
+    const int y = ty * kTileH + (lane >> 3);
+    if (x >= cam.width || y >= cam.height) return;
+    const int64_t SIZE = (int64_t)cam.width * cam.height;
+    const int idx = y * cam.width + x;
+
+    float out[4] = {0.f, 0.f, 0.f, 0.f};
+    float dir[3], vdir[3], cen[3], invdir[3];
+    ray_setup(x, y, cam, tree, dir, vdir, cen);
+    float delta_scale, tmin, tmax;
+    if (ray_enter(tree, opt, dir, cen, 1e9f, invdir, delta_scale, tmin, tmax)) {
+        Pcg32 rng = rng_base;
+        pcg_advance_tab(rng, (uint32_t)(idx * SPP), jump);
+
+        // thresholds, ascending; dst[0] is always the next one to cross (consumed ones shift out)
+        float dst[SPP + 1];
+#pragma unroll
+        for (int n = 0; n < SPP; ++n) {
+            float tv = -det_logf(1.0f - pcg_next_float(rng));
+#pragma unroll
+            for (int i = 0; i < n; ++i) {  // static-index insertion: same sorted array
+                const float lo = f_min(dst[i], tv), hi = f_max(dst[i], tv);
+                dst[i] = lo;
+                tv = hi;
+            }
+            dst[n] = tv;
+        }
+        dst[SPP] = 3.402823466e+38f;
+
+        uint32_t hits[SPP];
+#pragma unroll
+        for (int i = 0; i < SPP; ++i) hits[i] = 0;
+        uint32_t spp = 0, sh_nums = 0;
+        float src = 0;
+        float t = tmin;
+
+        uint32_t pix = 0, piy = 0, piz = 0;
+        int prev_lvl = 0;
+        uint32_t* stack = s_stack + tid;
+
+        while (t < tmax) {
+            float pos[3] = {cen[0] + t * dir[0], cen[1] + t * dir[1], cen[2] + t * dir[2]};
+            pos[0] = f_max(f_min(pos[0], 1.f - 1e-6f), 0.f);
+            pos[1] = f_max(f_min(pos[1], 1.f - 1e-6f), 0.f);
+            pos[2] = f_max(f_min(pos[2], 1.f - 1e-6f), 0.f);
+            const uint32_t ix = (uint32_t)(pos[0] * 16777216.f);
+            const uint32_t iy = (uint32_t)(pos[1] * 16777216.f);
+            const uint32_t iz = (uint32_t)(pos[2] * 16777216.f);
+            // levels whose child digit is unchanged since the previous step
+            const uint32_t diff = (ix ^ pix) | (iy ^ piy) | (iz ^ piz);
+            int lvl = __clz((int)diff) - 8;
+            lvl = lvl < prev_lvl ? lvl : prev_lvl;
+            uint32_t node = lvl ? stack[lvl * 256] : 0u;
+            uint32_t w, slot;
+            for (;;) {
+                const int sh = 23 - lvl;
+                const uint32_t ci = (((ix >> sh) & 1u) << 2) | (((iy >> sh) & 1u) << 1) | ((iz >> sh) & 1u);
+                slot = node * 8u + ci;
+                w = tree.nodew[slot];
+                if (nodew_is_leaf(w)) break;
+                node += w;  // two's complement add of the relative offset
+                ++lvl;
+                stack[lvl * 256] = node;
+            }
+            pix = ix;
+            piy = iy;
+            piz = iz;
+            prev_lvl = lvl;
+
+            const float cube_sz = (float)(2u << lvl);
+            float loc[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float s = pos[i] * cube_sz;
+                loc[i] = s - floorf(s);
+            }
+            const float t_subcube = dda_unit(loc, invdir) / cube_sz;
+            const float delta_t = t_subcube + opt.step_size;
+            const float sigma = half_bits_to_float((uint16_t)(w & 0xffffu));
+            if (sigma > opt.sigma_thresh) {
+                const float delta = delta_t * delta_scale * sigma;
+                if (src + delta >= dst[0]) {
+                    uint32_t cnt = 0;
+                    do {
+                        ++cnt;
+                        ++spp;
+#pragma unroll
+                        for (int i = 0; i < SPP; ++i) dst[i] = dst[i + 1];
+                    } while (src + delta >= dst[0]);
+                    const uint32_t h = hit_pack(slot, cnt);
+#pragma unroll
+                    for (int i = 0; i < SPP; ++i) hits[i] = (i == (int)sh_nums) ? h : hits[i];
+                    ++sh_nums;
+                    if (spp == SPP) break;
+                }
+                src += delta;
+            }
+            t += delta_t;
+        }
+
+        if (sh_nums != 0) {
+            float basis_fn[RTO_BASIS_MAX_DEV];
+            ray_basis(tree, opt, vdir, basis_fn);
+#pragma unroll
+            for (int i = 0; i < SPP; ++i) {
+                if (i < (int)sh_nums) {
+                    const uint32_t slot = hits[i] & 0x07ffffffu;
+                    const float cnt = (float)((hits[i] >> 27) + 1u);
+                    if (tree.format == 1 && tree.data_dim == 28)
+                        shade_leaf_packed<28>(tree, slot, basis_fn, cnt, out);
+                    else if (tree.format == 1 && tree.data_dim == 49)
+                        shade_leaf_packed<49>(tree, slot, basis_fn, cnt, out);
+                    else
+                        shade_leaf(tree, tree.data + (uint64_t)slot * tree.data_dim, basis_fn, cnt, out);
+                }
+            }
+            constexpr float INV_SPP = 1.0f / SPP;
+            out[0] *= INV_SPP;
+            out[1] *= INV_SPP;
+            out[2] *= INV_SPP;
+            out[3] *= INV_SPP;
+        }
+    }
+    write_pixel(fo, SIZE, idx, opt.background_brightness, out);
+}
+
+// ------------------------------------------------------------------ u8 conversion
+// main_headless.cpp:535-538: (uint8_t)(f * 255), truncation, all four channels
+__global__ void rgba8_kernel(const float4* __restrict__ in, uchar4* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 v = in[i];
+    uchar4 o;
+    o.x = (unsigned char)(v.x * 255);
+    o.y = (unsigned char)(v.y * 255);
+    o.z = (unsigned char)(v.z * 255);
+    o.w = (unsigned char)(v.w * 255);
+    out[i] = o;
+}
+
+}  // namespace rto
+
+// ------------------------------------------------------------------ host launchers (C++ linkage,
+// declared in rto_launch.h)
+#include "rto_launch.h"
+
+namespace rto {
+
+hipError_t launch_build_nodew(const int32_t* child, const uint16_t* data, int64_t n_slots, int data_dim,
+                              uint32_t* nodew, int* bad_flag, hipStream_t stream) {
+    const int threads = 256;
+    const int64_t blocks = (n_slots + threads - 1) / threads;
+    hipLaunchKernelGGL(build_nodew_kernel, dim3((unsigned)blocks), dim3(threads), 0, stream, child, data, n_slots,
+                       data_dim, nodew, bad_flag);
+    return hipGetLastError();
+}
+
+TileMap make_tile_map(int width, int height, int strip_rows) {
+    TileMap tm;
+    tm.tiles_x = (width + kTileW - 1) / kTileW;
+    tm.tiles_y = (height + kTileH - 1) / kTileH;
+    tm.strip_rows = strip_rows < 1 ? 1 : strip_rows;
+    const int strips = (tm.tiles_y + tm.strip_rows - 1) / tm.strip_rows;
+    const int strips_per_xcd = (strips + 7) / 8;
+    tm.per_xcd = strips_per_xcd * tm.strip_rows * tm.tiles_x;
+    return tm;
+}
+
+template <int SPP>
+static hipError_t launch_spp(int kernel, const TreeDev& tree, const CamDev& cam, const OptDev& opt,
+                             const Pcg32& rng, const PcgJumpEntry* jump, const FrameOut& fo, int strip_rows,
+                             hipStream_t stream) {
+    if (kernel == 2) {
+        const TileMap tm = make_tile_map(cam.width, cam.height, strip_rows);
+        const size_t lds = (size_t)(tree.max_depth + 1) * 256 * sizeof(uint32_t);
+        hipLaunchKernelGGL(render_fast<SPP>, dim3(8 * tm.per_xcd), dim3(256), lds, stream, tree, cam, opt, rng, jump,
+                           tm, fo);
+    } else {
+        const int64_t size = (int64_t)cam.width * cam.height;
+        hipLaunchKernelGGL(render_generic<SPP>, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, stream, tree, cam,
+                           opt, rng, fo);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev& cam, const OptDev& opt,
+                         const Pcg32& rng, const PcgJumpEntry* jump, const FrameOut& fo, int strip_rows,
+                         hipStream_t stream) {
+    switch (spp) {  // volrend.cu:266-278
+        case 1: return launch_spp<1>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
+        case 2: return launch_spp<2>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
+        case 3: return launch_spp<3>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
+        case 4: return launch_spp<4>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
+        case 6: return launch_spp<6>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
+        case 8: return launch_spp<8>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
+        case 16: return launch_spp<16>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
+        case 32: return launch_spp<32>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_rgba8(const float* rgba, uint8_t* out, int64_t n_pixels, hipStream_t stream) {
+    const int threads = 256;
+    hipLaunchKernelGGL(rgba8_kernel, dim3((unsigned)((n_pixels + threads - 1) / threads)), dim3(threads), 0, stream,
+                       reinterpret_cast<const float4*>(rgba), reinterpret_cast<uchar4*>(out), n_pixels);
+    return hipGetLastError();
+}
+
+}  // namespace rto

@@ -1,0 +1,613 @@
+// rto_abi.cpp -- implementation of the C ABI declared in include/rto.h.
+// Host logic only; every computation on frame data happens in the gfx950 kernels
+// (render_kernels.hip, filter_kernels.hip).  There is no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "host/mini_json.h"
+#include "host/n3tree_host.h"
+#include "rto.h"
+#include "rto_launch.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int set_err(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                        \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return set_err(RTO_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + \
+                                          std::to_string(__LINE__) + ")");                                   \
+    } while (0)
+
+// set the device for the scope of one ABI call, restore the caller's device afterwards
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) {
+            ok = false;
+            return;
+        }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+bool spp_supported(int spp) {  // volrend.cu:266-278
+    return spp == 1 || spp == 2 || spp == 3 || spp == 4 || spp == 6 || spp == 8 || spp == 16 || spp == 32;
+}
+
+}  // namespace
+
+struct rto_tree {
+    int device = 0;
+    rto::TreeDev dev{};
+    rto_tree_info info{};
+    void* d_data = nullptr;
+    void* d_child = nullptr;
+    void* d_nodew = nullptr;
+    bool fast_ok = false;
+};
+
+struct rto_ctx {
+    int device = 0;
+    int width = 0, height = 0;
+    float* aux = nullptr;
+    float* noisy = nullptr;
+    float* image = nullptr;
+    uint8_t* rgba8 = nullptr;
+    rto::Pcg32 rng{};
+    rto::PcgJumpEntry* jump = nullptr;
+    uint64_t jump_inc = 0;
+    bool jump_valid = false;
+    int kernel = RTO_KERNEL_AUTO;
+    int strip_rows = 1;
+    // Timer (render_context.hpp:122-213)
+    hipStream_t t_stream = nullptr;
+    hipEvent_t t_start[3] = {nullptr, nullptr, nullptr}, t_stop[3] = {nullptr, nullptr, nullptr};
+    bool t_used[3] = {false, false, false};
+    float t_sum[3] = {0, 0, 0};
+    int t_cnt = 0;
+};
+
+namespace {
+
+void pcg_seed(rto::Pcg32& r, uint64_t initstate, uint64_t initseq) {  // pcg32.h:53-59
+    auto next = [&]() { r.state = r.state * rto::kPcgMult + r.inc; };
+    r.state = 0U;
+    r.inc = (initseq << 1u) | 1u;
+    next();
+    r.state += initstate;
+    next();
+}
+
+// (mult, plus) of the affine map "advance by delta" for increment `inc` (pcg32.h:145-166)
+rto::PcgJumpEntry pcg_jump(uint64_t inc, uint64_t delta) {
+    uint64_t cur_mult = rto::kPcgMult, cur_plus = inc, acc_mult = 1u, acc_plus = 0u;
+    while (delta > 0) {
+        if (delta & 1) {
+            acc_mult *= cur_mult;
+            acc_plus = acc_plus * cur_mult + cur_plus;
+        }
+        cur_plus = (cur_mult + 1) * cur_plus;
+        cur_mult *= cur_mult;
+        delta /= 2;
+    }
+    return {acc_mult, acc_plus};
+}
+
+int ensure_jump_table(rto_ctx* c, hipStream_t stream) {
+    if (c->jump_valid && c->jump_inc == c->rng.inc) return RTO_OK;
+    std::vector<rto::PcgJumpEntry> tab(4 * 256);
+    for (int ch = 0; ch < 4; ++ch)
+        for (int j = 0; j < 256; ++j) tab[ch * 256 + j] = pcg_jump(c->rng.inc, (uint64_t)j << (8 * ch));
+    if (!c->jump) HIP_TRY(hipMalloc((void**)&c->jump, tab.size() * sizeof(rto::PcgJumpEntry)));
+    // synchronous copy from a stack-lifetime vector; happens once per `inc`
+    HIP_TRY(hipMemcpy(c->jump, tab.data(), tab.size() * sizeof(rto::PcgJumpEntry), hipMemcpyHostToDevice));
+    (void)stream;
+    c->jump_inc = c->rng.inc;
+    c->jump_valid = true;
+    return RTO_OK;
+}
+
+int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, int N, int data_dim,
+                const rto::DataFormat& fmt, const float scale[3], const float offset[3], int device,
+                rto_tree** out) {
+    if (!child || !data || capacity <= 0 || N < 1 || data_dim < 1 || !out)
+        return set_err(RTO_E_INVALID, "rto_tree: null array or non-positive size");
+    if (fmt.format == RTO_FMT_SH || fmt.format == RTO_FMT_SG || fmt.format == RTO_FMT_ASG) {
+        if (fmt.basis_dim < 1 || data_dim != 3 * fmt.basis_dim + 1)
+            return set_err(RTO_E_FORMAT, "rto_tree: data_dim " + std::to_string(data_dim) + " does not match format " +
+                                             fmt.to_string());
+        if (fmt.basis_dim > RTO_BASIS_MAX)
+            return set_err(RTO_E_FORMAT, "rto_tree: basis_dim above " + std::to_string(RTO_BASIS_MAX));
+    } else if (data_dim < 4) {
+        return set_err(RTO_E_FORMAT, "rto_tree: RGBA trees need data_dim >= 4");
+    }
+    int max_depth = 0;
+    try {
+        max_depth = rto::tree_max_depth(child, capacity, N);
+    } catch (const std::exception& e) {
+        return set_err(RTO_E_FORMAT, e.what());
+    }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return set_err(RTO_E_HIP, "no HIP device available (librto has no CPU fallback)");
+    if (device < 0 || device >= ndev) return set_err(RTO_E_INVALID, "device index out of range");
+    DeviceGuard guard(device);
+    if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");
+
+    auto t = new rto_tree();
+    t->device = device;
+    const int64_t N3 = (int64_t)N * N * N;
+    const int64_t n_slots = capacity * N3;
+    const size_t data_bytes = (size_t)n_slots * data_dim * sizeof(uint16_t);
+    const size_t child_bytes = (size_t)n_slots * sizeof(int32_t);
+    auto fail = [&](int code, const std::string& msg) {
+        rto_tree_free(t);
+        return set_err(code, msg);
+    };
+    // +16 B: shade_leaf_packed reads whole dwords around a record and may touch up to 4 B past it
+    if (hipMalloc(&t->d_data, data_bytes + 16) != hipSuccess) return fail(RTO_E_HIP, "hipMalloc(tree.data) failed");
+    if (hipMalloc(&t->d_child, child_bytes) != hipSuccess) return fail(RTO_E_HIP, "hipMalloc(tree.child) failed");
+    if (hipMemcpy(t->d_data, data, data_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset((char*)t->d_data + data_bytes, 0, 16) != hipSuccess ||
+        hipMemcpy(t->d_child, child, child_bytes, hipMemcpyHostToDevice) != hipSuccess)
+        return fail(RTO_E_HIP, "tree upload failed");
+
+    size_t dev_bytes = data_bytes + 16 + child_bytes;
+    // traversal image for the fast kernel: N == 2, depth within the 24 fixed-point bits, slot index
+    // within the 27 bits of a hit-list entry
+    if (N == 2 && max_depth <= 24 && n_slots <= (int64_t(1) << 27)) {
+        int* d_bad = nullptr;
+        if (hipMalloc(&t->d_nodew, (size_t)n_slots * 4) != hipSuccess || hipMalloc((void**)&d_bad, 4) != hipSuccess ||
+            hipMemset(d_bad, 0, 4) != hipSuccess)
+            return fail(RTO_E_HIP, "hipMalloc(nodew) failed");
+        hipError_t e = rto::launch_build_nodew((const int32_t*)t->d_child, (const uint16_t*)t->d_data, n_slots,
+                                               data_dim, (uint32_t*)t->d_nodew, d_bad, nullptr);
+        int bad = 0;
+        if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost);
+        (void)hipFree(d_bad);
+        if (e != hipSuccess) return fail(RTO_E_HIP, std::string("build_nodew failed: ") + hipGetErrorString(e));
+        t->fast_ok = !bad;
+        if (bad) {
+            (void)hipFree(t->d_nodew);
+            t->d_nodew = nullptr;
+        } else {
+            dev_bytes += (size_t)n_slots * 4;
+        }
+    }
+
+    rto::TreeDev& d = t->dev;
+    d.data = (const uint16_t*)t->d_data;
+    d.child = (const int32_t*)t->d_child;
+    d.nodew = (const uint32_t*)t->d_nodew;
+    for (int i = 0; i < 3; ++i) {
+        d.offset[i] = offset[i];
+        d.scale[i] = scale[i];
+    }
+    d.N = N;
+    d.N3 = (int)N3;
+    d.data_dim = data_dim;
+    d.format = fmt.format;
+    d.basis_dim = fmt.basis_dim;
+    d.ndc_width = -1.f;  // data_spec.hpp:49
+    d.ndc_height = 0.f;
+    d.ndc_focal = 0.f;
+    d.max_depth = max_depth;
+
+    rto_tree_info& inf = t->info;
+    inf.capacity = capacity;
+    inf.N = N;
+    inf.data_dim = data_dim;
+    inf.format = fmt.format;
+    inf.basis_dim = fmt.basis_dim;
+    for (int i = 0; i < 3; ++i) {
+        inf.scale[i] = scale[i];
+        inf.offset[i] = offset[i];
+    }
+    inf.use_ndc = 0;
+    inf.ndc_width = inf.ndc_height = inf.ndc_focal = 0.f;
+    inf.max_depth = max_depth;
+    inf.device_bytes = (int64_t)dev_bytes;
+    *out = t;
+    return RTO_OK;
+}
+
+int options_from_value(const rto::json::Value& j, rto_options* o) {
+    rto_options r;
+    rto_options_default(&r);
+    try {
+        // NLOHMANN_DEFINE_TYPE_INTRUSIVE (render_options.hpp:61-77): every listed key is required
+        r.step_size = (float)j.at("step_size").as_number();
+        r.sigma_thresh = (float)j.at("sigma_thresh").as_number();
+        r.stop_thresh = (float)j.at("stop_thresh").as_number();
+        r.background_brightness = (float)j.at("background_brightness").as_number();
+        r.show_grid = j.at("show_grid").as_bool();
+        r.grid_max_depth = (int)j.at("grid_max_depth").as_number();
+        r.enable_probe = j.at("enable_probe").as_bool();
+        const auto& p = j.at("probe");
+        if (p.size() != 3) throw std::runtime_error("json: 'probe' must have 3 elements");
+        for (int i = 0; i < 3; ++i) r.probe[i] = (float)p.at(i).as_number();
+        r.probe_disp_size = (int)j.at("probe_disp_size").as_number();
+        r.denoise = j.at("denoise").as_bool();
+        r.spp = (int)j.at("spp").as_number();
+    } catch (const std::exception& e) {
+        return set_err(RTO_E_FORMAT, std::string("render options: ") + e.what());
+    }
+    *o = r;
+    return RTO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rto_version(void) { return "rt-octree_amd 0.1 (gfx950)"; }
+const char* rto_last_error(void) { return g_err.c_str(); }
+
+int rto_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return set_err(RTO_E_HIP, "hipGetDeviceCount failed");
+    return n;
+}
+
+void rto_options_default(rto_options* o) {  // render_options.hpp:15-58
+    if (!o) return;
+    o->step_size = 1e-4f;
+    o->sigma_thresh = 1e-2f;
+    o->stop_thresh = 1e-2f;
+    o->background_brightness = 1.f;
+    const float bb[6] = {0.f, 0.f, 0.f, 1.f, 1.f, 1.f};
+    std::memcpy(o->render_bbox, bb, sizeof(bb));
+    o->basis_minmax[0] = 0;
+    o->basis_minmax[1] = RTO_BASIS_MAX - 1;
+    o->rot_dirs[0] = o->rot_dirs[1] = o->rot_dirs[2] = 0.f;
+    o->show_grid = 0;
+    o->grid_max_depth = 4;
+    o->render_depth = 0;
+    o->enable_probe = 0;
+    o->probe[0] = 0.f;
+    o->probe[1] = 0.f;
+    o->probe[2] = 1.f;
+    o->probe_disp_size = 100;
+    o->denoise = 1;
+    o->spp = 1;
+}
+
+int rto_options_from_json(const char* text, rto_options* o) {
+    if (!text || !o) return set_err(RTO_E_INVALID, "rto_options_from_json: null argument");
+    rto::json::ValuePtr v;
+    try {
+        v = rto::json::parse(text);
+    } catch (const std::exception& e) {
+        return set_err(RTO_E_FORMAT, e.what());
+    }
+    return options_from_value(*v, o);
+}
+
+int rto_options_from_json_file(const char* path, rto_options* o) {
+    if (!path || !o) return set_err(RTO_E_INVALID, "rto_options_from_json_file: null argument");
+    std::ifstream f(path);
+    if (!f) return set_err(RTO_E_IO, std::string("cannot open options file '") + path + "'");
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return rto_options_from_json(ss.str().c_str(), o);
+}
+
+int rto_tree_load_npz(const char* path, int device, rto_tree** out) {
+    if (!path || !out) return set_err(RTO_E_INVALID, "rto_tree_load_npz: null argument");
+    rto::HostTree h;
+    try {
+        if (!h.open(path)) return set_err(RTO_E_IO, std::string("file does not exist: ") + path);
+    } catch (const std::exception& e) {
+        return set_err(RTO_E_FORMAT, e.what());
+    }
+    std::fprintf(stdout, "INFO: Scale %f %f %f\n", h.scale[0], h.scale[1], h.scale[2]);  // n3tree.cpp:264
+    int rc = upload_tree(h.child, h.data, h.capacity, h.N, h.data_dim, h.data_format, h.scale, h.offset, device, out);
+    if (rc != RTO_OK) return rc;
+    if (h.use_ndc) rto_tree_set_ndc(*out, h.ndc_width, h.ndc_height, h.ndc_focal);
+    return RTO_OK;
+}
+
+int rto_tree_from_arrays(const int32_t* child, const uint16_t* data, int64_t capacity, int N, int data_dim,
+                         const char* data_format, const float scale[3], const float offset[3], int device,
+                         rto_tree** out) {
+    if (!scale || !offset) return set_err(RTO_E_INVALID, "rto_tree_from_arrays: null scale/offset");
+    rto::DataFormat fmt;
+    if (data_format && data_format[0]) {
+        fmt.parse(data_format);
+    } else if (data_dim == 4) {  // n3tree.cpp:241-254 legacy autodetect
+        fmt.format = RTO_FMT_RGBA;
+        fmt.basis_dim = -1;
+    } else {
+        fmt.format = RTO_FMT_SH;
+        fmt.basis_dim = (data_dim - 1) / 3;
+    }
+    return upload_tree(child, data, capacity, N, data_dim, fmt, scale, offset, device, out);
+}
+
+int rto_tree_set_ndc(rto_tree* t, float w, float h, float focal) {
+    if (!t) return set_err(RTO_E_INVALID, "rto_tree_set_ndc: null tree");
+    t->info.use_ndc = w > 0;
+    t->info.ndc_width = w;
+    t->info.ndc_height = h;
+    t->info.ndc_focal = focal;
+    t->dev.ndc_width = w > 0 ? w : -1.f;
+    t->dev.ndc_height = h;
+    t->dev.ndc_focal = focal;
+    return RTO_OK;
+}
+
+int rto_tree_get_info(const rto_tree* t, rto_tree_info* info) {
+    if (!t || !info) return set_err(RTO_E_INVALID, "rto_tree_get_info: null argument");
+    *info = t->info;
+    return RTO_OK;
+}
+
+void rto_tree_free(rto_tree* t) {
+    if (!t) return;
+    DeviceGuard guard(t->device);
+    if (t->d_data) (void)hipFree(t->d_data);
+    if (t->d_child) (void)hipFree(t->d_child);
+    if (t->d_nodew) (void)hipFree(t->d_nodew);
+    delete t;
+}
+
+int rto_ctx_create(int width, int height, int device, rto_ctx** out) {
+    if (width <= 0 || height <= 0 || !out) return set_err(RTO_E_INVALID, "rto_ctx_create: bad size");
+    if ((int64_t)width * height * 32 > 0x7fffffffLL)
+        return set_err(RTO_E_INVALID, "rto_ctx_create: width*height*32 exceeds the int range of idx*SPP (volrend.cu:157)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return set_err(RTO_E_HIP, "no HIP device available (librto has no CPU fallback)");
+    if (device < 0 || device >= ndev) return set_err(RTO_E_INVALID, "device index out of range");
+    DeviceGuard guard(device);
+    if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");
+    auto c = new rto_ctx();
+    c->device = device;
+    c->width = width;
+    c->height = height;
+    const size_t px = (size_t)width * height;
+    if (hipMalloc((void**)&c->aux, px * RTO_AUX_CHANNELS * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&c->noisy, px * 4 * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&c->image, px * 4 * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&c->rgba8, px * 4) != hipSuccess) {
+        rto_ctx_free(c);
+        return set_err(RTO_E_HIP, "hipMalloc(ctx buffers) failed");
+    }
+    (void)hipMemset(c->aux, 0, px * RTO_AUX_CHANNELS * sizeof(float));
+    (void)hipMemset(c->noisy, 0, px * 4 * sizeof(float));
+    (void)hipMemset(c->image, 0, px * 4 * sizeof(float));
+    pcg_seed(c->rng, 20230418ULL, 1);  // render_context.hpp:16
+    for (int i = 0; i < 3; ++i) {
+        if (hipEventCreate(&c->t_start[i]) != hipSuccess || hipEventCreate(&c->t_stop[i]) != hipSuccess) {
+            rto_ctx_free(c);
+            return set_err(RTO_E_HIP, "hipEventCreate failed");
+        }
+    }
+    *out = c;
+    return RTO_OK;
+}
+
+void rto_ctx_free(rto_ctx* c) {
+    if (!c) return;
+    DeviceGuard guard(c->device);
+    if (c->aux) (void)hipFree(c->aux);
+    if (c->noisy) (void)hipFree(c->noisy);
+    if (c->image) (void)hipFree(c->image);
+    if (c->rgba8) (void)hipFree(c->rgba8);
+    if (c->jump) (void)hipFree(c->jump);
+    for (int i = 0; i < 3; ++i) {
+        if (c->t_start[i]) (void)hipEventDestroy(c->t_start[i]);
+        if (c->t_stop[i]) (void)hipEventDestroy(c->t_stop[i]);
+    }
+    delete c;
+}
+
+int rto_ctx_width(const rto_ctx* c) { return c ? c->width : 0; }
+int rto_ctx_height(const rto_ctx* c) { return c ? c->height : 0; }
+float* rto_ctx_aux(rto_ctx* c) { return c ? c->aux : nullptr; }
+float* rto_ctx_noisy(rto_ctx* c) { return c ? c->noisy : nullptr; }
+float* rto_ctx_image(rto_ctx* c) { return c ? c->image : nullptr; }
+
+void rto_ctx_rng_seed(rto_ctx* c, uint64_t initstate, uint64_t initseq) {
+    if (c) pcg_seed(c->rng, initstate, initseq);
+}
+void rto_ctx_rng_advance(rto_ctx* c, int64_t delta) {
+    if (!c) return;
+    const rto::PcgJumpEntry j = pcg_jump(c->rng.inc, (uint64_t)delta);
+    c->rng.state = j.mult * c->rng.state + j.plus;
+}
+void rto_ctx_rng_set(rto_ctx* c, uint64_t state, uint64_t inc) {
+    if (!c) return;
+    c->rng.state = state;
+    c->rng.inc = inc;
+}
+void rto_ctx_rng_get(const rto_ctx* c, uint64_t* state, uint64_t* inc) {
+    if (!c) return;
+    if (state) *state = c->rng.state;
+    if (inc) *inc = c->rng.inc;
+}
+
+int rto_ctx_set_kernel(rto_ctx* c, int kernel) {
+    if (!c || kernel < RTO_KERNEL_AUTO || kernel > RTO_KERNEL_FAST)
+        return set_err(RTO_E_INVALID, "rto_ctx_set_kernel: bad argument");
+    c->kernel = kernel;
+    return RTO_OK;
+}
+
+int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_options* o, rto_ctx* ctx,
+                        void* stream_) {
+    if (!tree || !cam || !o || !ctx) return set_err(RTO_E_INVALID, "rto_launch_renderer: null argument");
+    if (!spp_supported(o->spp))  // volrend.cu:275-277
+        return set_err(RTO_E_SPP, "spp == " + std::to_string(o->spp) + " not supported. (supported: 1,2,3,4,6,8,16,32)");
+    if (cam->width != ctx->width || cam->height != ctx->height)
+        return set_err(RTO_E_INVALID, "camera size does not match the render context");
+    if (tree->device != ctx->device) return set_err(RTO_E_INVALID, "tree and context live on different devices");
+    if (o->enable_probe)
+        return set_err(RTO_E_UNSUPPORTED, "enable_probe is a GUI feature (volrend.cu:100-134), not on the headless path");
+    {
+        const float* a = o->rot_dirs;
+        if (!(std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) < 1e-6))  // rodrigues volrend.cu:62-63
+            return set_err(RTO_E_UNSUPPORTED, "rot_dirs is a GUI feature (volrend.cu:58-73), not on the headless path");
+    }
+    if (tree->dev.format == RTO_FMT_SG || tree->dev.format == RTO_FMT_ASG)
+        return set_err(RTO_E_UNSUPPORTED, "SG/ASG bases are untested upstream (lumisphere.hpp:14-37) and not built");
+    if (!(cam->fx != 0.f) || !(cam->fy != 0.f)) return set_err(RTO_E_INVALID, "camera focal length is zero");
+
+    int kernel = ctx->kernel;
+    if (kernel == RTO_KERNEL_AUTO) kernel = tree->fast_ok ? RTO_KERNEL_FAST : RTO_KERNEL_GENERIC;
+    if (kernel == RTO_KERNEL_FAST && !tree->fast_ok)
+        return set_err(RTO_E_UNSUPPORTED, "fast kernel needs an N == 2 tree of depth <= 24 and <= 2^27 slots");
+
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (kernel == RTO_KERNEL_FAST) {
+        int rc = ensure_jump_table(ctx, stream);
+        if (rc != RTO_OK) return rc;
+    }
+
+    rto::CamDev cd;
+    cd.width = cam->width;
+    cd.height = cam->height;
+    cd.fx = cam->fx;
+    cd.fy = cam->fy;
+    std::memcpy(cd.transform, cam->transform, sizeof(cd.transform));
+    rto::OptDev od;
+    od.step_size = o->step_size;
+    od.sigma_thresh = o->sigma_thresh;
+    od.background_brightness = o->background_brightness;
+    std::memcpy(od.render_bbox, o->render_bbox, sizeof(od.render_bbox));
+    od.basis_minmax[0] = o->basis_minmax[0];
+    od.basis_minmax[1] = o->basis_minmax[1];
+    rto::FrameOut fo;
+    fo.aux = ctx->aux;
+    fo.image = o->denoise ? ctx->noisy : ctx->image;  // volrend.cu:206
+
+    hipError_t e = rto::launch_render(kernel, o->spp, tree->dev, cd, od, ctx->rng, ctx->jump, fo, ctx->strip_rows, stream);
+    if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("render launch failed: ") + hipGetErrorString(e));
+    return RTO_OK;
+}
+
+int rto_filtering(void* stream, const float* weight_map, const float* guidance_map, int L, int H, int W,
+                  const float* img_in, float* img_out) {
+    if (!weight_map || !guidance_map || !img_in || !img_out || H <= 0 || W <= 0)
+        return set_err(RTO_E_INVALID, "rto_filtering: null pointer or bad size");
+    if (L < 1 || L > 6)  // filtering.cu:362-366
+        return set_err(RTO_E_INVALID, "Kernel size == " + std::to_string(L * 2 + 1) + " not supported.");
+    if (img_in == img_out) return set_err(RTO_E_INVALID, "rto_filtering: img_in and img_out must differ");
+    hipError_t e = rto::launch_filter(weight_map, guidance_map, L, H, W, img_in, img_out, (hipStream_t)stream);
+    if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("filter launch failed: ") + hipGetErrorString(e));
+    return RTO_OK;
+}
+
+int rto_ctx_filtering(rto_ctx* c, void* stream, const float* weight_map, const float* guidance_map, int L) {
+    if (!c) return set_err(RTO_E_INVALID, "rto_ctx_filtering: null context");
+    DeviceGuard guard(c->device);
+    return rto_filtering(stream, weight_map, guidance_map, L, c->height, c->width, c->noisy, c->image);
+}
+
+int rto_ctx_download_rgba8(rto_ctx* c, void* stream_, int which, uint8_t* host_out) {
+    if (!c || !host_out) return set_err(RTO_E_INVALID, "rto_ctx_download_rgba8: null argument");
+    DeviceGuard guard(c->device);
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t px = (int64_t)c->width * c->height;
+    HIP_TRY(rto::launch_rgba8(which ? c->noisy : c->image, c->rgba8, px, stream));
+    HIP_TRY(hipMemcpyAsync(host_out, c->rgba8, (size_t)px * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return RTO_OK;
+}
+
+int rto_ctx_download_image(rto_ctx* c, void* stream_, int which, float* host_out) {
+    if (!c || !host_out) return set_err(RTO_E_INVALID, "rto_ctx_download_image: null argument");
+    DeviceGuard guard(c->device);
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t bytes = (size_t)c->width * c->height * 4 * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(host_out, which ? c->noisy : c->image, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return RTO_OK;
+}
+
+int rto_ctx_download_aux(rto_ctx* c, void* stream_, float* host_out) {
+    if (!c || !host_out) return set_err(RTO_E_INVALID, "rto_ctx_download_aux: null argument");
+    DeviceGuard guard(c->device);
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t bytes = (size_t)c->width * c->height * RTO_AUX_CHANNELS * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(host_out, c->aux, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return RTO_OK;
+}
+
+// ---- Timer (render_context.hpp:122-213) ----
+int rto_timer_reset(rto_ctx* c, void* stream) {
+    if (!c) return set_err(RTO_E_INVALID, "rto_timer_reset: null context");
+    c->t_stream = (hipStream_t)stream;
+    c->t_cnt = 0;
+    for (int i = 0; i < 3; ++i) {
+        c->t_sum[i] = 0;
+        c->t_used[i] = false;
+    }
+    return RTO_OK;
+}
+int rto_timer_start(rto_ctx* c, int which) {
+    if (!c || which < 0 || which > 2) return set_err(RTO_E_INVALID, "rto_timer_start: bad argument");
+    DeviceGuard guard(c->device);
+    HIP_TRY(hipEventRecord(c->t_start[which], c->t_stream));
+    return RTO_OK;
+}
+int rto_timer_stop(rto_ctx* c, int which) {
+    if (!c || which < 0 || which > 2) return set_err(RTO_E_INVALID, "rto_timer_stop: bad argument");
+    DeviceGuard guard(c->device);
+    HIP_TRY(hipEventRecord(c->t_stop[which], c->t_stream));
+    c->t_used[which] = true;
+    return RTO_OK;
+}
+int rto_timer_record(rto_ctx* c, int denoise) {
+    if (!c) return set_err(RTO_E_INVALID, "rto_timer_record: null context");
+    DeviceGuard guard(c->device);
+    const int last = denoise ? RTO_T_FILTER : RTO_T_RENDER;
+    if (!c->t_used[last]) return set_err(RTO_E_INVALID, "rto_timer_record: the closing event was never recorded");
+    HIP_TRY(hipEventSynchronize(c->t_stop[last]));
+    c->t_cnt++;
+    for (int i = 0; i < 3; ++i) {
+        // the reference reads all three pairs every frame; buckets that never ran stay at 0 here
+        if (!c->t_used[i] || (!denoise && i != RTO_T_RENDER)) continue;
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->t_start[i], c->t_stop[i]));
+        c->t_sum[i] += ms;
+    }
+    return RTO_OK;
+}
+int rto_timer_report(const rto_ctx* c, float ms_out[3], float* fps_out, int* frames_out) {
+    if (!c) return set_err(RTO_E_INVALID, "rto_timer_report: null context");
+    float all = 0;
+    for (int i = 0; i < 3; ++i) {
+        const float t = c->t_cnt ? c->t_sum[i] / c->t_cnt : 0.f;
+        if (ms_out) ms_out[i] = t;
+        all += t;
+    }
+    if (fps_out) *fps_out = all > 0 ? 1000.f / all : 0.f;
+    if (frames_out) *frames_out = c->t_cnt;
+    return RTO_OK;
+}
+
+}  // extern "C"

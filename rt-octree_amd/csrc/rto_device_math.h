@@ -1,0 +1,140 @@
+// rto_device_math.h -- device-side scalar helpers shared by the gfx950 kernels.
+//
+// The arithmetic here is the *definition* the CPU oracle checks bit for bit, so:
+//   * no FMA contraction (file-level pragma below + -ffp-contract=off on the command line),
+//   * logf/expf are built from IEEE double + - * / only (the reference's __logf/__expf,
+//     rt_core.cuh:74,95,314 and filtering.cu:191, are NVIDIA approximations that cannot be
+//     reproduced; DESIGN.md "Math"),
+//   * fp32 divide / sqrt stay correctly rounded (hipcc default).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace rto {
+
+#define RTO_DEV __device__ __forceinline__
+
+// ---- pcg32 (renderer/3rdparty/pcg32.h:39-201) ----
+struct Pcg32 {
+    uint64_t state, inc;
+};
+constexpr uint64_t kPcgMult = 0x5851f42d4c957f2dULL;  // pcg32.h:35
+
+RTO_DEV uint32_t pcg_next_uint(Pcg32& r) {  // pcg32.h:62-68
+    const uint64_t oldstate = r.state;
+    r.state = oldstate * kPcgMult + r.inc;
+    const uint32_t xorshifted = (uint32_t)(((oldstate >> 18u) ^ oldstate) >> 27u);
+    const uint32_t rot = (uint32_t)(oldstate >> 59u);
+    return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+}
+
+RTO_DEV float pcg_next_float(Pcg32& r) {  // pcg32.h:103-112
+    return __uint_as_float((pcg_next_uint(r) >> 9) | 0x3f800000u) - 1.0f;
+}
+
+// pcg32.h:145-166, Brown's O(log n) jump
+RTO_DEV void pcg_advance(Pcg32& r, int64_t delta_) {
+    uint64_t cur_mult = kPcgMult, cur_plus = r.inc, acc_mult = 1u, acc_plus = 0u;
+    uint64_t delta = (uint64_t)delta_;
+    while (delta > 0) {
+        if (delta & 1) {
+            acc_mult *= cur_mult;
+            acc_plus = acc_plus * cur_mult + cur_plus;
+        }
+        cur_plus = (cur_mult + 1) * cur_plus;
+        cur_mult *= cur_mult;
+        delta /= 2;
+    }
+    r.state = acc_mult * r.state + acc_plus;
+}
+
+// Same jump through four 256-entry tables of (mult, plus) for delta = j << (8*c): the affine
+// maps commute, so applying the four byte-chunks in any order lands on the identical state
+// (arithmetic mod 2^64 is exact).  Tables are built on the host per `inc` (rto_abi.hip).
+struct PcgJumpEntry {
+    uint64_t mult, plus;
+};
+RTO_DEV void pcg_advance_tab(Pcg32& r, uint32_t delta, const PcgJumpEntry* __restrict__ tab) {
+    uint64_t s = r.state;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t j = (delta >> (8 * c)) & 255u;
+        const PcgJumpEntry e = tab[c * 256 + j];
+        s = e.mult * s + e.plus;
+    }
+    r.state = s;
+}
+
+// ---- fp16 -> fp32 (exact) ----
+RTO_DEV float half_bits_to_float(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+
+// ---- deterministic logf / expf: constants and operation order identical to
+//      oracle/rto_oracle.c orc_det_logf / orc_det_expf ----
+RTO_DEV float det_logf(float x) {
+    const uint32_t u = __float_as_uint(x);
+    if (x != x) return x;
+    if (u == 0x7f800000u) return x;
+    if ((u << 1) == 0) return -__builtin_inff();
+    if (u >> 31) return __builtin_nanf("");
+    int e = (int)(u >> 23) - 127;
+    uint32_t man = u & 0x7fffffu;
+    if ((u >> 23) == 0) {
+        int sh = 0;
+        while (!(man & 0x800000u)) {
+            man <<= 1;
+            ++sh;
+        }
+        man &= 0x7fffffu;
+        e = -126 - sh;
+    }
+    double md = (double)__uint_as_float(man | 0x3f800000u);
+    if (md > 1.4142135623730951) {
+        md = md * 0.5;
+        e += 1;
+    }
+    const double s = (md - 1.0) / (md + 1.0);
+    const double s2 = s * s;
+    double p = 1.0 / 15.0;
+    p = p * s2 + 1.0 / 13.0;
+    p = p * s2 + 1.0 / 11.0;
+    p = p * s2 + 1.0 / 9.0;
+    p = p * s2 + 1.0 / 7.0;
+    p = p * s2 + 1.0 / 5.0;
+    p = p * s2 + 1.0 / 3.0;
+    p = p * s2;
+    const double lm = 2.0 * s + (2.0 * s) * p;
+    const double r = (double)e * 0.6931471805599453 + lm;
+    return (float)r;
+}
+
+RTO_DEV float det_expf(float x) {
+    if (x != x) return x;
+    if (x > 88.72283935546875f) return __builtin_inff();
+    if (x < -103.97208404541016f) return 0.0f;
+    const double xd = (double)x;
+    const double z = xd * 1.4426950408889634;
+    const double kd = (z + 6755399441055744.0) - 6755399441055744.0;
+    const double r = (xd - kd * 0.693147180558298016) - kd * 1.6465949582897082e-12;
+    double p = 1.0 / 39916800.0;
+    p = p * r + 1.0 / 3628800.0;
+    p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0;
+    p = p * r + 1.0 / 5040.0;
+    p = p * r + 1.0 / 720.0;
+    p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0;
+    p = p * r + 1.0 / 6.0;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    const int k = (int)kd;
+    const double sc = __longlong_as_double((long long)((uint64_t)(k + 1023) << 52));
+    return (float)(p * sc);
+}
+
+RTO_DEV float f_min(float a, float b) { return a < b ? a : b; }
+RTO_DEV float f_max(float a, float b) { return a > b ? a : b; }
+
+}  // namespace rto

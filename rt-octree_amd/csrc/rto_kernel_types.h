@@ -1,0 +1,56 @@
+// rto_kernel_types.h -- POD kernel-argument views (the role of the reference's
+// internal/data_spec.hpp:11-52 TreeSpec / CameraSpec), passed to the kernels BY VALUE.
+#pragma once
+#include <stdint.h>
+
+#include "rto_device_math.h"
+
+namespace rto {
+
+#define RTO_BASIS_MAX_DEV 25  // render_options.hpp:7 VOLREND_GLOBAL_BASIS_MAX
+
+// Leaf tag of the traversal image `nodew` (see build_nodew_kernel in render_kernels.hip):
+//   internal slot: the reference's child[] value (relative node offset, |v| < 2^30)
+//   leaf slot:     0x80000000 | fp16 bits of the slot's sigma  -> top two bits are 0b10
+constexpr uint32_t kLeafTag = 0x80000000u;
+__host__ __device__ inline bool nodew_is_leaf(uint32_t w) { return (w >> 30) == 2u; }
+
+struct TreeDev {
+    const uint16_t* data;   // fp16 bits [capacity*N3*data_dim]   (reference tree.data)
+    const int32_t* child;   // [capacity*N3]                        (reference tree.child)
+    const uint32_t* nodew;  // [capacity*8] traversal image (N == 2 only), else nullptr
+    float offset[3];
+    float scale[3];
+    int N, N3, data_dim;
+    int format, basis_dim;
+    float ndc_width, ndc_height, ndc_focal;  // ndc_width <= 0: off (data_spec.hpp:49)
+    int max_depth;                            // levels of child[] visited to reach the deepest leaf
+};
+
+struct CamDev {
+    int width, height;
+    float fx, fy;
+    float transform[12];
+};
+
+// The RenderOptions fields the offscreen kernel reads (render_options.hpp:13-78)
+struct OptDev {
+    float step_size, sigma_thresh, background_brightness;
+    float render_bbox[6];
+    int basis_minmax[2];
+};
+
+// Strip-interleaved tile order: tile-row r belongs to XCD ((r / strip_rows) % 8); workgroup b
+// runs on XCD (b % 8) (observed round-robin placement; speed only, never correctness).
+struct TileMap {
+    int tiles_x, tiles_y;  // 32x8-pixel tiles
+    int strip_rows;        // tile rows per strip
+    int per_xcd;           // workgroups per XCD (grid = 8 * per_xcd)
+};
+
+struct FrameOut {
+    float* aux;    // [8][H][W]
+    float* image;  // [H][W][4]: noisy image when opt.denoise, else final (volrend.cu:206)
+};
+
+}  // namespace rto

@@ -1,0 +1,27 @@
+// rto_launch.h -- host-callable launchers of the gfx950 kernels (defined in *.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rto_kernel_types.h"
+
+namespace rto {
+
+// traversal image for N == 2 trees; *bad_flag (device int, pre-zeroed) is set if an offset cannot
+// be encoded
+hipError_t launch_build_nodew(const int32_t* child, const uint16_t* data, int64_t n_slots, int data_dim,
+                              uint32_t* nodew, int* bad_flag, hipStream_t stream);
+
+TileMap make_tile_map(int width, int height, int strip_rows);
+
+// kernel: 1 = generic, 2 = fast.  spp must be one of {1,2,3,4,6,8,16,32} (hipErrorInvalidValue otherwise)
+hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev& cam, const OptDev& opt,
+                         const Pcg32& rng, const PcgJumpEntry* jump, const FrameOut& fo, int strip_rows,
+                         hipStream_t stream);
+
+hipError_t launch_rgba8(const float* rgba, uint8_t* out, int64_t n_pixels, hipStream_t stream);
+
+// denoiser/extension/filtering.cu:108-228,440-470: L levels, support = level + 1
+hipError_t launch_filter(const float* weight, const float* guidance, int L, int H, int W, const float* img_in,
+                         float* img_out, hipStream_t stream);
+
+}  // namespace rto

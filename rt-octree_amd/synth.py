@@ -1,0 +1,235 @@
+"""Seeded synthetic inputs in the reference's own file formats (no dataset
+ships with the reference and none exists on the GPU box).
+
+  * a "lego-like" PlenOctree: N = 2, refined only around a thin shell of an analytic SDF scene
+    (plates, boxes, studs, wheels, a boom), sigma > 0 only in shell leaves, SH-9 / SH-16 colours;
+    written with the key schema N3Tree::load_npz reads (n3tree.cpp:228-362);
+  * blender-schema camera paths (main_headless.cpp:255-272), T&T-style pose directories
+    (:273-297) and the reference's options/opt.json.
+
+Pure numpy; used by bench.py, the tests and tools/.  Not part of the render path.
+"""
+import json
+import os
+
+import numpy as np
+
+CAMERA_ANGLE_X = 0.6911112070083618  # NeRF-synthetic; fx = 0.5*W/tan(0.5*angle) = 1111.11 @ 800
+
+
+# ------------------------------------------------------------------ scene SDF (world units)
+def _sd_box(p, c, h):
+    q = np.abs(p - np.asarray(c, np.float32)) - np.asarray(h, np.float32)
+    return np.linalg.norm(np.maximum(q, 0), axis=-1) + np.minimum(np.max(q, axis=-1), 0)
+
+
+def _sd_cyl(p, c, r, hh, axis):
+    d = p - np.asarray(c, np.float32)
+    other = [i for i in range(3) if i != axis]
+    dr = np.sqrt(d[..., other[0]] ** 2 + d[..., other[1]] ** 2) - r
+    da = np.abs(d[..., axis]) - hh
+    return np.minimum(np.maximum(dr, da), 0) + np.sqrt(np.maximum(dr, 0) ** 2 + np.maximum(da, 0) ** 2)
+
+
+def scene_sdf(p):
+    """Union of primitives, roughly a toy bulldozer inside [-1.1, 1.1]^3 (z up)."""
+    p = p.astype(np.float32, copy=False)
+    d = _sd_box(p, (0, 0, -0.52), (1.05, 0.65, 0.05))                       # base plate
+    d = np.minimum(d, _sd_box(p, (-0.05, 0, -0.22), (0.62, 0.36, 0.22)))    # body
+    d = np.minimum(d, _sd_box(p, (-0.25, 0, 0.2), (0.3, 0.3, 0.2)))         # cab
+    d = np.minimum(d, _sd_box(p, (0.78, 0, -0.28), (0.06, 0.55, 0.2)))      # blade
+    for sy in (-0.5, 0.5):                                                    # tracks + wheels
+        d = np.minimum(d, _sd_box(p, (-0.05, sy, -0.36), (0.7, 0.09, 0.1)))
+        for wx in (-0.6, -0.2, 0.2, 0.6):
+            d = np.minimum(d, _sd_cyl(p, (wx, sy, -0.36), 0.13, 0.11, 1))
+    # boom: a thin box rotated about y
+    ang = np.float32(0.6)
+    ca, sa = np.cos(ang), np.sin(ang)
+    q = p - np.asarray((0.25, 0.0, 0.25), np.float32)
+    qr = np.stack([ca * q[..., 0] + sa * q[..., 2], q[..., 1], -sa * q[..., 0] + ca * q[..., 2]], -1)
+    d = np.minimum(d, _sd_box(qr, (0, 0, 0), (0.5, 0.05, 0.05)))
+    # studs on the plate and on the cab roof
+    for sx in np.arange(-0.9, 0.91, 0.3):
+        for sy in (-0.3, 0.0, 0.3):
+            d = np.minimum(d, _sd_cyl(p, (sx, sy, -0.44), 0.06, 0.035, 2))
+    for sx in (-0.4, -0.1):
+        for sy in (-0.15, 0.15):
+            d = np.minimum(d, _sd_cyl(p, (sx, sy, 0.43), 0.06, 0.035, 2))
+    return d
+
+
+# ------------------------------------------------------------------ tree
+class SynthTree:
+    """Host arrays of a synthetic PlenOctree, in the reference's layout."""
+
+    def __init__(self, child, data, scale, offset, data_format, depth_limit, stats):
+        self.child, self.data = child, data
+        self.scale = np.asarray(scale, np.float32)
+        self.offset = np.asarray(offset, np.float32)
+        self.data_format = data_format
+        self.depth_limit = depth_limit
+        self.stats = stats
+
+    @property
+    def capacity(self):
+        return self.child.shape[0]
+
+    @property
+    def data_dim(self):
+        return self.data.shape[-1]
+
+    def save_npz(self, path, compressed=False):
+        """Key schema of svox / N3Tree::load_npz (n3tree.cpp:228-362)."""
+        kw = dict(data_dim=np.int64(self.data_dim), data_format=np.array(self.data_format),
+                  invradius3=self.scale.astype(np.float32), offset=self.offset.astype(np.float32),
+                  child=self.child, data=self.data)
+        (np.savez_compressed if compressed else np.savez)(path, **kw)
+        return path
+
+
+def make_tree(depth_limit=6, basis_dim=9, seed=20230418, shell=1.25, radius=1.5, sdf=scene_sdf,
+              max_nodes=None):
+    """Refine cells whose centre lies within (half-diagonal + shell*finest_cell) of the surface.
+
+    depth_limit D: nodes live at levels 0..D-1, finest cells are 2^-D (tree units) across.
+    Node order is breadth-first, children appended behind their parents, child[] holds the
+    relative node offset (0 = leaf) exactly as svox writes it.
+    """
+    rng = np.random.default_rng(seed)
+    offset = np.full(3, 0.5, np.float32)
+    scale = np.full(3, 1.0 / (2.0 * radius), np.float32)  # invradius3
+    data_dim = 3 * basis_dim + 1
+    fine = 2.0 ** -depth_limit
+    tau = shell * fine  # shell half-thickness, tree units
+
+    def sdf_tree(pt):  # tree units in, tree units out (uniform scale)
+        return sdf((pt - offset) / scale) * scale[0]
+
+    corner = np.array([[i, j, k] for i in (0, 1) for j in (0, 1) for k in (0, 1)], np.int64)  # x major
+    child_levels, occ_levels, ctr_levels = [], [], []
+    coords = np.zeros((1, 3), np.int64)  # integer cell coords of the nodes at this level
+    n_nodes_before = 0
+    for lvl in range(depth_limit):
+        n = coords.shape[0]
+        cell = 2.0 ** -(lvl + 1)
+        sub = (coords[:, None, :] * 2 + corner[None, :, :])                     # [n,8,3]
+        centers = ((sub.astype(np.float32) + 0.5) * np.float32(cell)).reshape(-1, 3)
+        dist = np.abs(sdf_tree(centers)).reshape(n, 8)
+        half_diag = np.float32(cell * 0.8660254)
+        refine = (dist <= half_diag + tau) if lvl + 1 < depth_limit else np.zeros((n, 8), bool)
+        if max_nodes is not None and n_nodes_before + n + int(refine.sum()) > max_nodes:
+            refine[:] = False
+        occupied = (~refine) & (dist <= tau)
+        child = np.zeros((n, 8), np.int32)
+        n_new = int(refine.sum())
+        if n_new:
+            first_child = n_nodes_before + n                       # BFS: next level starts here
+            new_ids = first_child + np.arange(n_new, dtype=np.int64)
+            node_ids = n_nodes_before + np.arange(n, dtype=np.int64)
+            rel = np.zeros((n, 8), np.int64)
+            rel[refine] = new_ids
+            rel -= np.where(refine, node_ids[:, None], 0)
+            child = rel.astype(np.int32)
+        child_levels.append(child)
+        occ_levels.append(occupied)
+        ctr_levels.append(centers.reshape(n, 8, 3))
+        n_nodes_before += n
+        coords = sub[refine]
+        if n_new == 0:
+            break
+
+    capacity = n_nodes_before
+    child = np.concatenate(child_levels, 0).reshape(capacity, 2, 2, 2)
+    occupied = np.concatenate(occ_levels, 0).reshape(-1)
+    centers = np.concatenate(ctr_levels, 0).reshape(-1, 3)
+    data = np.zeros((capacity * 8, data_dim), np.float16)
+    occ_idx = np.flatnonzero(occupied)
+    B = basis_dim
+    # SH band of each coefficient index -> amplitude decay
+    band = np.array([0] + [1] * 3 + [2] * 5 + [3] * 7 + [4] * 9, np.float32)[:B]
+    amp = np.where(band == 0, 0.0, 0.6 / (1.0 + band) ** 1.5).astype(np.float32)
+    CH = 1 << 20
+    for s in range(0, occ_idx.size, CH):
+        idx = occ_idx[s:s + CH]
+        c = centers[idx]
+        m = idx.size
+        coef = rng.standard_normal((m, 3, B), dtype=np.float32) * amp[None, None, :]
+        # smooth DC colour field + a little per-leaf noise (pre-sigmoid, DC basis = 0.282)
+        for ch, (fx, fy, fz, ph) in enumerate(((9.0, 5.0, 7.0, 0.0), (6.0, 11.0, 4.0, 1.3), (5.0, 8.0, 10.0, 2.1))):
+            dc = 2.2 * np.sin(fx * c[:, 0] + ph) * np.cos(fy * c[:, 1] - ph) + 1.5 * np.sin(fz * c[:, 2] + 2 * ph)
+            coef[:, ch, 0] = (dc + 0.3 * rng.standard_normal(m, dtype=np.float32)) / 0.28209479
+        sigma = np.exp(rng.uniform(np.log(5.0), np.log(300.0), m)).astype(np.float32)
+        rec = np.concatenate([coef.reshape(m, 3 * B), sigma[:, None]], 1)
+        data[idx] = rec.astype(np.float16)
+    data = data.reshape(capacity, 2, 2, 2, data_dim)
+    stats = {"capacity": int(capacity), "leaf_slots": int((child == 0).sum()),
+             "occupied_leaves": int(occ_idx.size), "depth_limit": int(depth_limit),
+             "levels": [int(c.shape[0]) for c in child_levels]}
+    return SynthTree(child, data, scale, offset, "SH%d" % basis_dim, depth_limit, stats)
+
+
+# ------------------------------------------------------------------ cameras
+def look_at_c2w(cam_pos, target=(0, 0, 0), up=(0, 0, 1)):
+    """NeRF/blender convention: camera looks along -z, +y is up.  Returns a row-major 4x4."""
+    c = np.asarray(cam_pos, np.float64)
+    back = c - np.asarray(target, np.float64)
+    back /= np.linalg.norm(back)
+    right = np.cross(np.asarray(up, np.float64), back)
+    right /= np.linalg.norm(right)
+    upv = np.cross(back, right)
+    m = np.eye(4)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = right, upv, back, c
+    return m
+
+
+def orbit_poses(n=200, radius=4.0311, elev_deg=(30.0, 20.0)):
+    """n camera-to-world matrices on an upper-hemisphere orbit (deterministic, no RNG)."""
+    out = []
+    for i in range(n):
+        az = 2.0 * np.pi * i / n
+        el = np.deg2rad(elev_deg[0] + elev_deg[1] * np.sin(4.0 * np.pi * i / n))
+        pos = radius * np.array([np.cos(az) * np.cos(el), np.sin(az) * np.cos(el), np.sin(el)])
+        out.append(look_at_c2w(pos))
+    return np.stack(out)
+
+
+def write_transforms_json(path, poses, camera_angle_x=CAMERA_ANGLE_X):
+    """Blender schema read by main_headless.cpp:255-272."""
+    frames = [{"file_path": "./test/r_%d" % i, "rotation": 0.0,
+               "transform_matrix": [[float(v) for v in row] for row in p]} for i, p in enumerate(poses)]
+    with open(path, "w") as f:
+        json.dump({"camera_angle_x": camera_angle_x, "frames": frames}, f)
+    return path
+
+
+def blender_focal(width, camera_angle_x=CAMERA_ANGLE_X):
+    """fx = fy = 0.5f * width / tanf(0.5f * camera_angle_x) (main_headless.cpp:258), in fp32."""
+    a = np.float32(camera_angle_x)
+    return float(np.float32(0.5) * np.float32(width) / np.tan(np.float32(0.5) * a, dtype=np.float32))
+
+
+def write_tt_dataset(root, poses, fx=1160.0, fy=1160.0, cx=960.0, cy=540.0):
+    """TanksAndTemple layout: <root>/intrinsics.txt + <root>/pose/*.txt with 4x4 OpenCV-convention
+    c2w matrices (main_headless.cpp:273-297; the loader flips y,z: :373-384)."""
+    os.makedirs(os.path.join(root, "pose"), exist_ok=True)
+    with open(os.path.join(root, "intrinsics.txt"), "w") as f:
+        f.write("%f 0 %f 0\n0 %f %f 0\n0 0 1 0\n0 0 0 1\n" % (fx, cx, fy, cy))
+    flip = np.diag([1.0, -1.0, -1.0, 1.0])
+    for i, p in enumerate(poses):
+        np.savetxt(os.path.join(root, "pose", "%06d.txt" % i), p @ flip, fmt="%.8f")
+    return os.path.join(root, "pose")
+
+
+OPT_JSON = {  # renderer/options/opt.json
+    "background_brightness": 1.0, "denoise": True, "spp": 6, "enable_probe": False, "grid_max_depth": 4,
+    "probe": [0.0, 0.0, 1.0], "probe_disp_size": 100, "show_grid": False, "sigma_thresh": 0.01,
+    "step_size": 0.0001, "stop_thresh": 0.01,
+}
+
+
+def write_opt_json(path, **overrides):
+    d = dict(OPT_JSON)
+    d.update(overrides)
+    with open(path, "w") as f:
+        json.dump(d, f, indent=2)
+    return path

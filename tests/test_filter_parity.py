@@ -1,0 +1,57 @@
+"""HIP guided-softmax filter (rto_filtering, all levels fused in one launch) vs the oracle's
+level-by-level restatement of filtering.cu:108-228: bit-exact fp32 output."""
+import numpy as np
+import pytest
+
+import orc
+import rt_octree_amd as R
+from helpers import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _inputs(L, H, W, seed):
+    rs = np.random.RandomState(seed)
+    g = (rs.randn(L, H, W) * 3).astype(np.float32)
+    w = rs.rand(L, H, W).astype(np.float32)
+    w /= w.sum(0, keepdims=True)
+    noisy = rs.rand(H, W, 4).astype(np.float32)
+    noisy[..., 3] = 1
+    return w, g, noisy
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("shape", [(48, 40), (33, 71), (8, 8), (3, 5)])
+def test_filter_bit_exact(L, shape):
+    H, W = shape
+    w, g, noisy = _inputs(L, H, W, seed=L * 100 + H)
+    ref = orc.filter_levels(w, g, noisy)
+    dev = torch.device("cuda:0")
+    tw, tg, tn = (torch.from_numpy(a).to(dev) for a in (w, g, noisy))
+    out = torch.full((H, W, 4), -7.0, device=dev)
+    R.filtering(torch.cuda.current_stream(), tw, tg, tn, out)
+    torch.cuda.synchronize()
+    assert_bits_equal(out.cpu().numpy(), ref, "filter L=%d %dx%d" % (L, H, W))
+
+
+def test_filter_extreme_guidance():
+    """huge logit spread: exp underflows to 0 for most taps, borders see -FLT_MAX taps."""
+    L, H, W = 4, 40, 48
+    w, g, noisy = _inputs(L, H, W, seed=9)
+    g *= 40.0
+    ref = orc.filter_levels(w, g, noisy)
+    dev = torch.device("cuda:0")
+    out = torch.empty((H, W, 4), device=dev)
+    R.filtering(None, torch.from_numpy(w).to(dev), torch.from_numpy(g).to(dev), torch.from_numpy(noisy).to(dev), out)
+    torch.cuda.synchronize()
+    assert_bits_equal(out.cpu().numpy(), ref)
+
+
+def test_filter_rejects_bad_levels():
+    dev = torch.device("cuda:0")
+    t = torch.zeros((7, 8, 8), device=dev)
+    img = torch.zeros((8, 8, 4), device=dev)
+    with pytest.raises(R.RtoError) as e:
+        R.filtering(None, t, t, img, torch.zeros_like(img))
+    assert "Kernel size == 15 not supported" in str(e.value)

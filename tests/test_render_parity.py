@@ -1,0 +1,135 @@
+"""HIP render path (through the C ABI) vs the CPU oracle: bit-exact fp32 aux planes, RGBA32F image
+and RGBA8 bytes on the same seeded inputs.  Tolerance: none (0 ulp) -- both sides evaluate the same
+IEEE expression sequence with the shared deterministic logf/expf definition (DESIGN.md "Math")."""
+import numpy as np
+import pytest
+
+import orc
+import rt_octree_amd as R
+from helpers import assert_bits_equal, cameras, hip_frame, make_pair, oracle_frame, rgba_tree
+from rt_octree_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+POSES = synth.orbit_poses(5)
+
+
+@pytest.mark.parametrize("spp", R.SUPPORTED_SPP)
+@pytest.mark.parametrize("kernel", [R.KERNEL_GENERIC, R.KERNEL_FAST])
+def test_sh9_all_spp_bit_exact(small_tree_sh9, spp, kernel):
+    ht, dt = make_pair(small_tree_sh9)
+    W, H = 96, 80  # ragged vs the 32x8 tiles
+    ocam, cam = cameras(W, H, POSES[1])
+    aux_o, rgba_o, st = oracle_frame(ht, ocam, spp, frame=3)
+    aux_h, rgba_h, ctx = hip_frame(dt, cam, spp, frame=3, kernel=kernel)
+    assert st["hit_rays"] > 100
+    assert_bits_equal(aux_h, aux_o, "aux spp=%d" % spp)
+    assert_bits_equal(rgba_h, rgba_o, "rgba spp=%d" % spp)
+    assert np.array_equal(ctx.download_rgba8(), orc.rgba8(rgba_o))
+
+
+@pytest.mark.parametrize("kernel", [R.KERNEL_GENERIC, R.KERNEL_FAST])
+@pytest.mark.parametrize("pose", range(len(POSES)))
+def test_sh16_poses_bit_exact(small_tree_sh16, pose, kernel):
+    ht, dt = make_pair(small_tree_sh16)
+    W, H = 100, 60
+    ocam, cam = cameras(W, H, POSES[pose])
+    aux_o, rgba_o, _ = oracle_frame(ht, ocam, 6, frame=pose)
+    aux_h, rgba_h, _ = hip_frame(dt, cam, 6, frame=pose, kernel=kernel)
+    assert_bits_equal(aux_h, aux_o, "aux")
+    assert_bits_equal(rgba_h, rgba_o, "rgba")
+
+
+@pytest.mark.parametrize("kernel", [R.KERNEL_GENERIC, R.KERNEL_FAST])
+def test_rgba_format_bit_exact(small_tree_sh9, kernel):
+    tree = rgba_tree(small_tree_sh9)
+    ht, dt = make_pair(tree)
+    ocam, cam = cameras(64, 64, POSES[2])
+    aux_o, rgba_o, _ = oracle_frame(ht, ocam, 4)
+    aux_h, rgba_h, _ = hip_frame(dt, cam, 4, kernel=kernel)
+    assert_bits_equal(aux_h, aux_o, "aux")
+    assert_bits_equal(rgba_h, rgba_o, "rgba")
+
+
+def test_options_paths_bit_exact(small_tree_sh9):
+    """render_bbox crop, basis_minmax mask, background, sigma_thresh, step_size."""
+    ht, dt = make_pair(small_tree_sh9)
+    ocam, cam = cameras(72, 72, POSES[0])
+    kw = dict(render_bbox=[0.1, 0.2, 0.0, 0.9, 0.8, 0.7], basis_minmax=[1, 5], background_brightness=0.25,
+              sigma_thresh=8.0, step_size=3e-4)
+    aux_o, rgba_o, _ = oracle_frame(ht, ocam, 3, **kw)
+    for kernel in (R.KERNEL_GENERIC, R.KERNEL_FAST):
+        aux_h, rgba_h, _ = hip_frame(dt, cam, 3, kernel=kernel, **kw)
+        assert_bits_equal(aux_h, aux_o, "aux")
+        assert_bits_equal(rgba_h, rgba_o, "rgba")
+
+
+def test_camera_inside_box_and_miss(small_tree_sh9):
+    """tmin clamps at 0 for a camera inside the volume; rays that miss return background
+    (rt_core.cuh:219-222; SURVEY appendix B 3,4)."""
+    ht, dt = make_pair(small_tree_sh9)
+    inside = synth.look_at_c2w((0.3, 0.2, 0.4), target=(0, 0, -0.2))
+    away = synth.look_at_c2w((4, 0, 0), target=(8, 0, 0))
+    for pose in (inside, away):
+        ocam, cam = cameras(48, 40, pose)
+        aux_o, rgba_o, _ = oracle_frame(ht, ocam, 2)
+        for kernel in (R.KERNEL_GENERIC, R.KERNEL_FAST):
+            aux_h, rgba_h, _ = hip_frame(dt, cam, 2, kernel=kernel)
+            assert_bits_equal(aux_h, aux_o, "aux")
+            assert_bits_equal(rgba_h, rgba_o, "rgba")
+    assert np.all(aux_h[3] == 0) and np.all(rgba_h[..., :3] == 1.0)
+
+
+def test_denoise_flag_selects_noisy_target(small_tree_sh9):
+    """opt.denoise routes the image write to the noisy buffer (volrend.cu:206)."""
+    _, dt = make_pair(small_tree_sh9)
+    _, cam = cameras(32, 32, POSES[0])
+    ctx = R.RenderContext(32, 32)
+    aux1, img_final, _ = hip_frame(dt, cam, 1, ctx=ctx, denoise=False)
+    aux2, img_noisy, _ = hip_frame(dt, cam, 1, ctx=ctx, denoise=True)
+    assert_bits_equal(aux1, aux2)
+    assert_bits_equal(img_final, img_noisy)
+
+
+def test_unsupported_spp_raises(small_tree_sh9):
+    _, dt = make_pair(small_tree_sh9)
+    _, cam = cameras(16, 16, POSES[0])
+    ctx = R.RenderContext(16, 16)
+    with pytest.raises(R.RtoError) as e:
+        R.launch_renderer(dt, cam, R.RenderOptions(spp=5), ctx)
+    assert "spp == 5 not supported" in str(e.value)
+
+
+def test_full_size_properties(small_tree_sh9):
+    """800x800 SPP 6 (BASELINE config size): size-independent properties + generic == fast."""
+    tree = synth.make_tree(depth_limit=8, basis_dim=9, seed=5)
+    _, dt = make_pair(tree)
+    _, cam = cameras(800, 800, POSES[3])
+    aux_f, rgba_f, ctx = hip_frame(dt, cam, 6, frame=100, kernel=R.KERNEL_FAST)
+    aux_g, rgba_g, _ = hip_frame(dt, cam, 6, frame=100, kernel=R.KERNEL_GENERIC)
+    assert_bits_equal(aux_f, aux_g, "fast vs generic aux")
+    assert_bits_equal(rgba_f, rgba_g, "fast vs generic rgba")
+    alpha = aux_f[3]
+    assert np.all(np.isin(np.round(alpha * 6).astype(int), range(7))) and np.all(np.abs(alpha * 6 - np.round(alpha * 6)) < 1e-5)
+    assert np.all(aux_f[4:] == aux_f[:4] ** 2)                     # squares planes
+    assert np.all(rgba_f[..., 3] == 1.0)                           # alpha forced to 1
+    assert np.all((rgba_f[..., :3] >= 0) & (rgba_f[..., :3] <= 1.0 + 1e-6))
+    assert np.all(rgba_f[..., :3][alpha == 0] == 1.0)              # misses = background
+    aux_r, _, _ = hip_frame(dt, cam, 6, frame=100, kernel=R.KERNEL_FAST, ctx=ctx)
+    assert_bits_equal(aux_r, aux_f, "re-render determinism")
+    aux_n, _, _ = hip_frame(dt, cam, 6, frame=101, kernel=R.KERNEL_FAST, ctx=ctx)
+    assert not np.array_equal(aux_n, aux_f)                        # per-frame RNG jump changes the noise
+    # spot-check 64 pixels of the full-size frame against the oracle
+    ht = orc.HostTree(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+    ocam, _ = cameras(800, 800, POSES[3])
+    import ctypes as C
+    opt = orc.default_options(spp=6)
+    base = orc.rng(frame=100)
+    rs = np.random.RandomState(0)
+    for idx in rs.randint(0, 640000, 64):
+        a8 = (C.c_float * 8)()
+        px = (C.c_float * 4)()
+        rc = orc.lib().orc_render_pixel(C.byref(ht.c), C.byref(ocam), C.byref(opt), C.byref(base), int(idx), a8, px, None)
+        assert rc == 0
+        got = aux_f[:, idx // 800, idx % 800]
+        assert np.array_equal(np.array(a8[:], np.float32).view(np.uint32), got.view(np.uint32)), idx

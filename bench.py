@@ -1,0 +1,271 @@
+"""bench.py -- FPS of the RT-Octree hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame of config C2: batched-regular-tracking render (800x800, SPP 6) + GuidanceNet
+(PyTorch-ROCm) + guided filter, i.e. what one iteration of the reference's timed loop does
+(main_headless.cpp:485-543).  Inputs are synthetic (no dataset exists on either machine): a seeded
+lego-like SH16 PlenOctree of ~2.5 M nodes, a 200-pose blender orbit, GuidanceNet(8,32,5,2,4) with
+seeded default init folded to the compact fp16 network.  Everything is resident in HBM before the
+timed region.  Frames shard across ranks (pose i -> rank i mod N, RNG jump-ahead per pose so every
+image is bit-identical to the 1-GPU run); no data-path collective exists or is invented -- the
+only collectives are the barrier and the max-reduction of the elapsed time.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     -- traversal kernel: ALGORITHMIC bytes (SURVEY.md 8d formula, units counted by the
+                  kernel's counting instantiation in an untimed pass over the same frames) /
+                  average launch duration (HIP events on the launch stream), against 8 TB/s HBM.
+  cpu_baseline -- the CPU oracle (oracle/, kind "port": the reference has no CPU renderer) on a
+                  bounded sample of the same frames, all host cores.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
+WARM_FRAMES_REF = 100  # main_headless.cpp:469-479: 100 warm-up frames each advance the RNG
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--size", type=int, default=800)
+    ap.add_argument("--spp", type=int, default=6)
+    ap.add_argument("--basis", type=int, default=16, help="SH basis per channel (16 = the NeRF-synthetic PlenOctrees)")
+    ap.add_argument("--depth", type=int, default=10)
+    ap.add_argument("--shell", type=float, default=2.5)
+    ap.add_argument("--no-denoise", action="store_true", help="config C5: raw SPP render only")
+    ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--tree", default="", help="render this tree.npz instead of the synthetic one")
+    return ap.parse_args()
+
+
+def tree_cache_path(args):
+    key = "d%d_s%g_b%d" % (args.depth, args.shell, args.basis)
+    tag = hashlib.sha1(open(os.path.join(ROOT, "rt-octree_amd", "synth.py"), "rb").read()).hexdigest()[:10]
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    return os.path.join(base, "rto_bench_tree_%s_%s.npz" % (key, tag))
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    import rt_octree_amd as R
+    from rt_octree_amd import denoiser, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---------------- inputs (untimed) ----------------
+    W = H = args.size
+    tree_host = None
+    if args.tree:
+        path = args.tree
+    else:
+        path = tree_cache_path(args)
+        if rank == 0 and not os.path.exists(path):
+            t0 = time.time()
+            tree_host = synth.make_tree(depth_limit=args.depth, basis_dim=args.basis, shell=args.shell)
+            tree_host.save_npz(path + ".tmp.npz")
+            os.replace(path + ".tmp.npz", path)
+            print("[bench] generated %s: %s in %.1fs" % (path, tree_host.stats, time.time() - t0), file=sys.stderr)
+    barrier()
+    tree = R.N3Tree(path, device=local_rank)  # the reference's own input path: tree.npz -> device
+    poses = synth.orbit_poses(200)
+    fx = synth.blender_focal(W)
+    cam = R.Camera(W, H, fx, fx)
+    ctx = R.RenderContext(W, H, device=local_rank)
+    denoise = not args.no_denoise
+    opt = R.RenderOptions(spp=args.spp, denoise=denoise)
+    dn = None
+    if denoise:
+        torch.manual_seed(0)
+        full = denoiser.GuidanceNet(8, 32, 5, 2, 4)
+        net = denoiser.GuidanceNetCompact.from_full(full).half().to(dev)
+        dn = denoiser.Denoiser(net, device=local_rank)
+    stream = torch.cuda.current_stream(dev)
+
+    def pose_of(step):  # global frame index of this rank's `step`-th frame
+        return (step * world + rank) % len(poses)
+
+    def set_frame(step):
+        i = pose_of(step)
+        cam.set_c2w(poses[i])
+        ctx.rng_seed()
+        ctx.rng_advance((WARM_FRAMES_REF + i) << 32)  # frame i of the reference run
+
+    aux_t = torch.as_tensor(ctx.aux_view(), device=dev) if denoise else None  # zero-copy [1,8,H,W]
+    net = dn.module if denoise else None
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+
+    def frame(step, ev):
+        """launch_renderer -> GuidanceNet -> filtering, all asynchronous on `stream`; no host sync
+        inside the loop (the reference synchronises once per frame, render_context.hpp:179-188)."""
+        set_frame(step)
+        if ev:
+            ev[0].record(stream)
+        R.launch_renderer(tree, cam, opt, ctx, stream)
+        if ev:
+            ev[1].record(stream)
+        if denoise:
+            with torch.no_grad():
+                wm, gm = net(aux_t)
+            wm, gm = wm.squeeze(0), gm.squeeze(0)
+            if ev:
+                ev[2].record(stream)
+            R.filtering(stream, wm, gm, ctx.noisy_ptr, ctx.image_ptr)
+            if ev:
+                ev[3].record(stream)
+
+    # ---------------- warm-up + timed region ----------------
+    for s in range(args.warmup):
+        frame(s, None)
+    torch.cuda.synchronize(dev)
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        frame(s, events[s])
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # Timer::report formula (render_context.hpp:190-206) from the per-frame event pairs
+    render_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
+    torch_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps if denoise else 0.0
+    filter_ms = sum(e[2].elapsed_time(e[3]) for e in events) / args.steps if denoise else 0.0
+    all_ms = render_ms + torch_ms + filter_ms
+    tstats = {"render_ms": render_ms, "torch_ms": torch_ms, "filter_ms": filter_ms,
+              "fps": 1000.0 / all_ms if all_ms > 0 else 0.0, "frames": args.steps}
+
+    # ---------------- untimed: work units of the same frames -> algorithmic bytes ----------------
+    ctx.enable_stats(True)
+    ctx.get_stats(reset=True)
+    for s in range(args.steps):
+        set_frame(s)
+        R.launch_renderer(tree, cam, opt, ctx, stream)
+    units = ctx.get_stats(reset=True)
+    ctx.enable_stats(False)
+    px = W * H
+    alg_bytes = (4 * units["levels"] + 2 * units["steps"] + 2 * (tree.data_dim - 1) * units["hit_leaves"]
+                 + 48 * px * args.steps) / args.steps
+    render_s = tstats["render_ms"] * 1e-3
+    achieved = alg_bytes / render_s / 1e9 if render_s > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---------------- CPU baseline (rank 0, N == 1 only; bounded sample) ----------------
+    cpu = None
+    if world == 1 and args.cpu_frames > 0:
+        import orc
+        if tree_host is None:
+            z = np.load(path)
+            child, data, scale, offset = z["child"], z["data"], z["invradius3"], z["offset"]
+            fmt = str(z["data_format"])
+        else:
+            child, data, scale, offset, fmt = tree_host.child, tree_host.data, tree_host.scale, tree_host.offset, tree_host.data_format
+        ht = orc.HostTree(child, data, scale, offset, fmt)
+        cores = os.cpu_count() or 1
+        oopt = orc.default_options(spp=args.spp, denoise=int(denoise))
+        cpu_net = denoiser.GuidanceNetCompact.from_full(full).float() if denoise else None
+        torch.set_num_threads(cores)
+        tc = 0.0
+        cpu_units = None
+        for s in range(args.cpu_frames):
+            i = pose_of(s)
+            ocam = orc.camera(W, H, fx, fx, np.ascontiguousarray(poses[i][:3, :4].T, np.float32).reshape(-1))
+            t1 = time.perf_counter()
+            aux, rgba, st = orc.render_frame(ht, ocam, oopt, orc.rng(frame=WARM_FRAMES_REF + i), threads=cores)
+            if denoise:
+                with torch.no_grad():
+                    wm, gm = cpu_net(torch.from_numpy(aux)[None])
+                orc.filter_levels(wm[0].numpy(), gm[0].numpy(), rgba, threads=cores)
+            tc += time.perf_counter() - t1
+            cpu_units = st if cpu_units is None else {k: cpu_units[k] + st[k] for k in st}
+        cpu = {"value": args.cpu_frames / tc, "unit": "frames/s", "cores": cores, "kind": "port",
+               "sample": "%d of the same %dx%d SPP%d frames (poses 0..%d)%s, CPU oracle with OpenMP over rows"
+                         % (args.cpu_frames, W, H, args.spp, args.cpu_frames - 1,
+                            " + fp32 PyTorch-CPU GuidanceNet + oracle filter" if denoise else ""),
+               "steps_per_frame": cpu_units["steps"] / args.cpu_frames}
+
+    total_frames = args.steps * world
+    out = {
+        "metric": "FPS @ 800x800 (Lego SPP=6) + PSNR vs ref; 1/2/4/8 GPU scaling",
+        "value": total_frames / elapsed,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32" if not denoise else "f32 (traversal, filter) + f16 (GuidanceNet conv)",
+        "data": "synthetic",
+        "config": {
+            "workload": "configs[1]: lego-like synthetic PlenOctree %s (%d nodes, depth %d), %dx%d SPP=%d%s, 1 frame per step, frames sharded pose i -> rank i mod N"
+                        % (tree.data_format, tree.capacity, tree.max_depth, W, H, args.spp,
+                           " + GuidanceNet(8,32,5,2,4) denoise" if denoise else " raw (no denoise)"),
+            "tree_nodes": int(tree.capacity), "tree_device_mb": tree.device_bytes / 1e6,
+            "parallelism": "frames x%d" % world,
+        },
+        "reference_timer": {  # Timer::report formula (render_context.hpp:190-206), rank 0
+            "render_ms": tstats["render_ms"], "torch_ms": tstats["torch_ms"], "filter_ms": tstats["filter_ms"],
+            "fps": tstats["fps"], "frames": tstats["frames"]},
+        "roofline": {
+            "kernel": "render_fast<%d>" % args.spp, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": tstats["render_ms"],
+            "units_per_launch": {k: v / args.steps for k, v in units.items()},
+        },
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

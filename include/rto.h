@@ -126,6 +126,10 @@ int rto_tree_from_arrays(const int32_t* child, const uint16_t* data, int64_t cap
 /* main_headless.cpp:400-405 (llff): switch the NDC warp on. width <= 0 turns it off. */
 int rto_tree_set_ndc(rto_tree* t, float ndc_width, float ndc_height, float ndc_focal);
 int rto_tree_get_info(const rto_tree* t, rto_tree_info* info);
+/* Host-only: runs the same npz parsing + N3Tree::load_npz decode as rto_tree_load_npz (no device
+ * needed) and writes a JSON description into json_out: schema fields plus FNV-1a-64 checksums of
+ * the child[] and (decoded) data[] arrays.  Returns RTO_E_INVALID if `cap` is too small. */
+int rto_tree_probe_npz(const char* path, char* json_out, size_t cap);
 void rto_tree_free(rto_tree* t);
 
 /* ---- render context (RenderContext) ---- */
@@ -146,6 +150,12 @@ void rto_ctx_rng_set(rto_ctx* c, uint64_t state, uint64_t inc);
 void rto_ctx_rng_get(const rto_ctx* c, uint64_t* state, uint64_t* inc);
 /* choose the traversal kernel (RTO_KERNEL_*); default AUTO */
 int rto_ctx_set_kernel(rto_ctx* c, int kernel);
+/* Work counters for the roofline's ALGORITHMIC byte count.  When enabled, the fast
+ * kernel's counting instantiation runs instead of the timed one and accumulates, over the launches
+ * since the last rto_ctx_get_stats(reset=1): {rays, rays_in_box, march steps, descent levels a
+ * root-restart walk visits, distinct hit leaves, rays with a hit}.  Never enable it in a timed run. */
+int rto_ctx_enable_stats(rto_ctx* c, int enable);
+int rto_ctx_get_stats(rto_ctx* c, void* stream, uint64_t out[6], int reset);
 
 /* ---- the operator ---- */
 /* launch_renderer(tree, cam, options, ctx, stream, offscreen=true) (volrend.cu:236-285).

@@ -60,6 +60,7 @@ SYMBOLS = {
                                        C.POINTER(_P)]),
     "rto_tree_set_ndc": (C.c_int, [_P, C.c_float, C.c_float, C.c_float]),
     "rto_tree_get_info": (C.c_int, [_P, C.POINTER(CTreeInfo)]),
+    "rto_tree_probe_npz": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
     "rto_tree_free": (None, [_P]),
     "rto_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "rto_ctx_free": (None, [_P]),
@@ -73,6 +74,8 @@ SYMBOLS = {
     "rto_ctx_rng_set": (None, [_P, C.c_uint64, C.c_uint64]),
     "rto_ctx_rng_get": (None, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rto_ctx_set_kernel": (C.c_int, [_P, C.c_int]),
+    "rto_ctx_enable_stats": (C.c_int, [_P, C.c_int]),
+    "rto_ctx_get_stats": (C.c_int, [_P, _P, C.POINTER(C.c_uint64), C.c_int]),
     "rto_launch_renderer": (C.c_int, [_P, C.POINTER(CCamera), C.POINTER(COptions), _P, _P]),
     "rto_filtering": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rto_ctx_filtering": (C.c_int, [_P, _P, _P, _P, C.c_int]),

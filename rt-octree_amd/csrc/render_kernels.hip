@@ -400,7 +400,10 @@ RTO_DEV void shade_leaf_packed(const TreeDev& tree, uint32_t slot, const float* 
     out[3] += cnt;
 }
 
-template <int SPP>
+// STATS: also count the units of SURVEY 8(d)'s algorithmic-byte formula (march steps, descent
+// levels a root-restart walk would visit, distinct hit leaves, ...) into fo.stats.  Separate
+// instantiation; the timed kernel carries none of it.
+template <int SPP, bool STATS>
 __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const CamDev cam, const OptDev opt,
                                                     const Pcg32 rng_base, const PcgJumpEntry* __restrict__ jump,
                                                     const TileMap tm, const FrameOut fo) {
@@ -420,7 +423,9 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
     float dir[3], vdir[3], cen[3], invdir[3];
     ray_setup(x, y, cam, tree, dir, vdir, cen);
     float delta_scale, tmin, tmax;
+    unsigned long long st_steps = 0, st_levels = 0, st_hits = 0, st_inbox = 0;
     if (ray_enter(tree, opt, dir, cen, 1e9f, invdir, delta_scale, tmin, tmax)) {
+        if (STATS) st_inbox = 1;
         Pcg32 rng = rng_base;
         pcg_advance_tab(rng, (uint32_t)(idx * SPP), jump);
 
@@ -478,6 +483,10 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
             piy = iy;
             piz = iz;
             prev_lvl = lvl;
+            if (STATS) {
+                ++st_steps;
+                st_levels += (unsigned)(lvl + 1);
+            }
 
             const float cube_sz = (float)(2u << lvl);
             float loc[3];
@@ -510,6 +519,7 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
             t += delta_t;
         }
 
+        if (STATS) st_hits = sh_nums;
         if (sh_nums != 0) {
             float basis_fn[RTO_BASIS_MAX_DEV];
             ray_basis(tree, opt, vdir, basis_fn);
@@ -522,6 +532,8 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
                         shade_leaf_packed<28>(tree, slot, basis_fn, cnt, out);
                     else if (tree.format == 1 && tree.data_dim == 49)
                         shade_leaf_packed<49>(tree, slot, basis_fn, cnt, out);
+                    else if (tree.format == 1 && tree.data_dim == 76)
+                        shade_leaf_packed<76>(tree, slot, basis_fn, cnt, out);
                     else
                         shade_leaf(tree, tree.data + (uint64_t)slot * tree.data_dim, basis_fn, cnt, out);
                 }
@@ -534,6 +546,14 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
         }
     }
     write_pixel(fo, SIZE, idx, opt.background_brightness, out);
+    if (STATS) {  // order as orc_stats: rays, rays_in_box, steps, levels, hit_leaves, hit_rays
+        atomicAdd(fo.stats + 0, 1ULL);
+        atomicAdd(fo.stats + 1, st_inbox);
+        atomicAdd(fo.stats + 2, st_steps);
+        atomicAdd(fo.stats + 3, st_levels);
+        atomicAdd(fo.stats + 4, st_hits);
+        atomicAdd(fo.stats + 5, st_hits ? 1ULL : 0ULL);
+    }
 }
 
 // ------------------------------------------------------------------ u8 conversion
@@ -585,8 +605,12 @@ static hipError_t launch_spp(int kernel, const TreeDev& tree, const CamDev& cam,
     if (kernel == 2) {
         const TileMap tm = make_tile_map(cam.width, cam.height, strip_rows);
         const size_t lds = (size_t)(tree.max_depth + 1) * 256 * sizeof(uint32_t);
-        hipLaunchKernelGGL(render_fast<SPP>, dim3(8 * tm.per_xcd), dim3(256), lds, stream, tree, cam, opt, rng, jump,
-                           tm, fo);
+        if (fo.stats)
+            hipLaunchKernelGGL((render_fast<SPP, true>), dim3(8 * tm.per_xcd), dim3(256), lds, stream, tree, cam, opt,
+                               rng, jump, tm, fo);
+        else
+            hipLaunchKernelGGL((render_fast<SPP, false>), dim3(8 * tm.per_xcd), dim3(256), lds, stream, tree, cam, opt,
+                               rng, jump, tm, fo);
     } else {
         const int64_t size = (int64_t)cam.width * cam.height;
         hipLaunchKernelGGL(render_generic<SPP>, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, stream, tree, cam,

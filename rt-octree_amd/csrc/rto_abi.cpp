@@ -78,6 +78,8 @@ struct rto_ctx {
     bool jump_valid = false;
     int kernel = RTO_KERNEL_AUTO;
     int strip_rows = 1;
+    bool stats_on = false;
+    unsigned long long* stats = nullptr;  // device, 6 counters
     // Timer (render_context.hpp:122-213)
     hipStream_t t_stream = nullptr;
     hipEvent_t t_start[3] = {nullptr, nullptr, nullptr}, t_stop[3] = {nullptr, nullptr, nullptr};
@@ -327,6 +329,45 @@ int rto_tree_load_npz(const char* path, int device, rto_tree** out) {
     return RTO_OK;
 }
 
+int rto_tree_probe_npz(const char* path, char* json_out, size_t cap) {
+    if (!path || !json_out || cap == 0) return set_err(RTO_E_INVALID, "rto_tree_probe_npz: null argument");
+    rto::HostTree h;
+    try {
+        if (!h.open(path)) return set_err(RTO_E_IO, std::string("file does not exist: ") + path);
+    } catch (const std::exception& e) {
+        return set_err(RTO_E_FORMAT, e.what());
+    }
+    auto fnv = [](const void* p, size_t n) {
+        const unsigned char* b = static_cast<const unsigned char*>(p);
+        uint64_t x = 1469598103934665603ULL;
+        for (size_t i = 0; i < n; ++i) {
+            x ^= b[i];
+            x *= 1099511628211ULL;
+        }
+        return x;
+    };
+    const size_t n_slots = (size_t)h.capacity * h.N * h.N * h.N;
+    int max_depth = 0;
+    try {
+        max_depth = rto::tree_max_depth(h.child, h.capacity, h.N);
+    } catch (const std::exception& e) {
+        return set_err(RTO_E_FORMAT, e.what());
+    }
+    char buf[1024];
+    const int n = std::snprintf(
+        buf, sizeof(buf),
+        "{\"capacity\": %lld, \"N\": %d, \"data_dim\": %d, \"data_format\": \"%s\", \"basis_dim\": %d, "
+        "\"scale\": [%.9g, %.9g, %.9g], \"offset\": [%.9g, %.9g, %.9g], \"use_ndc\": %d, \"max_depth\": %d, "
+        "\"quantized\": %d, \"child_fnv1a64\": \"%016llx\", \"data_fnv1a64\": \"%016llx\"}",
+        (long long)h.capacity, h.N, h.data_dim, h.data_format.to_string().c_str(), h.data_format.basis_dim,
+        h.scale[0], h.scale[1], h.scale[2], h.offset[0], h.offset[1], h.offset[2], (int)h.use_ndc, max_depth,
+        (int)!h.decoded.empty(), (unsigned long long)fnv(h.child, n_slots * 4),
+        (unsigned long long)fnv(h.data, n_slots * (size_t)h.data_dim * 2));
+    if (n < 0 || (size_t)n + 1 > cap) return set_err(RTO_E_INVALID, "rto_tree_probe_npz: output buffer too small");
+    std::memcpy(json_out, buf, (size_t)n + 1);
+    return RTO_OK;
+}
+
 int rto_tree_from_arrays(const int32_t* child, const uint16_t* data, int64_t capacity, int N, int data_dim,
                          const char* data_format, const float scale[3], const float offset[3], int device,
                          rto_tree** out) {
@@ -415,6 +456,7 @@ void rto_ctx_free(rto_ctx* c) {
     if (c->image) (void)hipFree(c->image);
     if (c->rgba8) (void)hipFree(c->rgba8);
     if (c->jump) (void)hipFree(c->jump);
+    if (c->stats) (void)hipFree(c->stats);
     for (int i = 0; i < 3; ++i) {
         if (c->t_start[i]) (void)hipEventDestroy(c->t_start[i]);
         if (c->t_stop[i]) (void)hipEventDestroy(c->t_stop[i]);
@@ -451,6 +493,28 @@ int rto_ctx_set_kernel(rto_ctx* c, int kernel) {
     if (!c || kernel < RTO_KERNEL_AUTO || kernel > RTO_KERNEL_FAST)
         return set_err(RTO_E_INVALID, "rto_ctx_set_kernel: bad argument");
     c->kernel = kernel;
+    return RTO_OK;
+}
+
+int rto_ctx_enable_stats(rto_ctx* c, int enable) {
+    if (!c) return set_err(RTO_E_INVALID, "rto_ctx_enable_stats: null context");
+    DeviceGuard guard(c->device);
+    if (enable && !c->stats) {
+        HIP_TRY(hipMalloc((void**)&c->stats, 6 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(c->stats, 0, 6 * sizeof(unsigned long long)));
+    }
+    c->stats_on = enable != 0;
+    return RTO_OK;
+}
+
+int rto_ctx_get_stats(rto_ctx* c, void* stream_, uint64_t out[6], int reset) {
+    if (!c || !out) return set_err(RTO_E_INVALID, "rto_ctx_get_stats: null argument");
+    if (!c->stats) return set_err(RTO_E_INVALID, "rto_ctx_get_stats: counters were never enabled");
+    DeviceGuard guard(c->device);
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipMemcpyAsync(out, c->stats, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    if (reset) HIP_TRY(hipMemsetAsync(c->stats, 0, 6 * sizeof(uint64_t), stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     return RTO_OK;
 }
 
@@ -502,6 +566,11 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
     rto::FrameOut fo;
     fo.aux = ctx->aux;
     fo.image = o->denoise ? ctx->noisy : ctx->image;  // volrend.cu:206
+    fo.stats = nullptr;
+    if (ctx->stats_on) {
+        if (kernel != RTO_KERNEL_FAST) return set_err(RTO_E_UNSUPPORTED, "work counters need the fast kernel");
+        fo.stats = ctx->stats;
+    }
 
     hipError_t e = rto::launch_render(kernel, o->spp, tree->dev, cd, od, ctx->rng, ctx->jump, fo, ctx->strip_rows, stream);
     if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("render launch failed: ") + hipGetErrorString(e));

@@ -51,6 +51,7 @@ struct TileMap {
 struct FrameOut {
     float* aux;    // [8][H][W]
     float* image;  // [H][W][4]: noisy image when opt.denoise, else final (volrend.cu:206)
+    unsigned long long* stats;  // nullptr, or 6 counters (fast kernel, stats instantiation)
 };
 
 }  // namespace rto

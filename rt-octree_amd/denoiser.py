@@ -1,0 +1,189 @@
+"""GuidanceNet denoise stage on PyTorch-ROCm + the HIP guided filter.
+
+Reference (relative to /root/reference):
+    denoiser/network.py:49-75    RepVGGBlock        (num_branches 3x3 + num_branches 1x1 [+ identity], ReLU6)
+    denoiser/network.py:86-121   GuidanceNet        (layers; softmax over the first kernel_levels channels)
+    denoiser/network.py:123-168  RepVGGBlockCompact / GuidanceNetCompact (branches folded into one 3x3)
+    denoiser/network.py:170-208  compact_and_compile (fp16 + torch.jit.trace of `compact(aux.half())`)
+    renderer/src/denoiser/denoiser.cpp:31-61  Denoiser::denoise (wrap aux, forward, filtering)
+
+The network is small dense convolution work that north_star leaves to PyTorch-ROCm (MIOpen);
+the filter that applies its output is the hand-written kernel in csrc/filter_kernels.hip.
+Parameter names match the reference's modules, so its checkpoints (`state_dict`) and its
+TorchScript exports (`ts_*.ts`) load unchanged.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import volrend as V
+
+
+class RepVGGBlock(nn.Module):
+    """network.py:49-75"""
+
+    def __init__(self, in_channels, out_channels, num_branches):
+        super().__init__()
+        self.in_channels, self.out_channels, self.num_branches = in_channels, out_channels, num_branches
+        self.conv3 = nn.ModuleList(nn.Conv2d(in_channels, out_channels, 3, padding="same") for _ in range(num_branches))
+        self.conv1 = nn.ModuleList(nn.Conv2d(in_channels, out_channels, 1, padding="same") for _ in range(num_branches))
+
+    def forward(self, x):
+        # summation order of network.py:66-74: last 3x3 first, then the other 3x3s, the 1x1s, identity
+        h = self.conv3[self.num_branches - 1](x)
+        for i in range(self.num_branches - 1):
+            h = h + self.conv3[i](x)
+        for i in range(self.num_branches):
+            h = h + self.conv1[i](x)
+        if self.in_channels == self.out_channels:
+            h = h + x
+        return F.relu6(h)
+
+
+class GuidanceNet(nn.Module):
+    """network.py:86-121.  forward(aux [B,8,H,W]) -> (weight_map [B,L,H,W], guidance_map [B,L,H,W])"""
+
+    def __init__(self, in_channels=8, mid_channels=32, num_branches=5, num_layers=2, kernel_levels=4):
+        super().__init__()
+        self.in_channels, self.mid_channels = in_channels, mid_channels
+        self.num_branches, self.num_layers, self.kernel_levels = num_branches, num_layers, kernel_levels
+        self.layers = nn.ModuleList(self._make_layers(RepVGGBlock))
+
+    def _make_layers(self, block, *extra):
+        layers = []
+        for i in range(self.num_layers - 1):
+            layers.append(block(self.mid_channels if i > 0 else self.in_channels, self.mid_channels, self.num_branches, *extra))
+        layers.append(block(self.mid_channels if self.num_layers > 1 else self.in_channels,
+                            self.kernel_levels * 2, self.num_branches, *extra))
+        return layers
+
+    def features(self, x):
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+    def split(self, x):
+        """network.py:111-118"""
+        x = x.float()
+        weight_map = F.softmax(x[:, :self.kernel_levels, ...].contiguous(), dim=1)
+        guidance_map = x[:, self.kernel_levels:, ...].contiguous()
+        return weight_map, guidance_map
+
+    def forward(self, aux_buffer):
+        if aux_buffer.is_cuda:
+            with torch.autocast("cuda", dtype=torch.float16):  # network.py:104-108
+                x = self.features(aux_buffer)
+        else:
+            x = self.features(aux_buffer)
+        return self.split(x)
+
+
+class RepVGGBlockCompact(nn.Module):
+    """network.py:123-154: one 3x3 conv = sum of the 3x3 branches + zero-padded 1x1 branches
+    (+ identity when Cin == Cout)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, 3, padding="same")
+
+    @classmethod
+    def from_full(cls, full):
+        blk = cls(full.in_channels, full.out_channels)
+        with torch.no_grad():
+            w = torch.zeros_like(blk.conv.weight)
+            b = torch.zeros_like(blk.conv.bias)
+            for i in range(full.num_branches):
+                w += full.conv3[i].weight
+                b += full.conv3[i].bias
+            for i in range(full.num_branches):
+                w += F.pad(full.conv1[i].weight, (1, 1, 1, 1))
+                b += full.conv1[i].bias
+            if full.in_channels == full.out_channels:
+                for i in range(full.out_channels):
+                    w[i, i % full.in_channels, 1, 1] += 1
+            blk.conv.weight.copy_(w)
+            blk.conv.bias.copy_(b)
+        blk.conv.requires_grad_(False)
+        return blk
+
+    def forward(self, x):
+        return F.relu6(self.conv(x))
+
+
+class GuidanceNetCompact(GuidanceNet):
+    """network.py:156-168: the inference network (plain conv3x3 + ReLU6 stack)."""
+
+    def __init__(self, in_channels=8, mid_channels=32, num_layers=2, kernel_levels=4):
+        nn.Module.__init__(self)
+        self.in_channels, self.mid_channels = in_channels, mid_channels
+        self.num_branches, self.num_layers, self.kernel_levels = 1, num_layers, kernel_levels
+        chans = [in_channels] + [mid_channels] * (num_layers - 1) + [kernel_levels * 2]
+        self.layers = nn.ModuleList(RepVGGBlockCompact(chans[i], chans[i + 1]) for i in range(num_layers))
+
+    @classmethod
+    def from_full(cls, full):
+        net = cls(full.in_channels, full.mid_channels, full.num_layers, full.kernel_levels)
+        net.layers = nn.ModuleList(RepVGGBlockCompact.from_full(l) for l in full.layers)
+        return net.eval()
+
+    def forward(self, aux_buffer):
+        # compact_and_compile's traced function: compact.forward(aux.half()) with fp16 weights
+        dtype = self.layers[0].conv.weight.dtype
+        return self.split(self.features(aux_buffer.to(dtype)))
+
+
+def compact_and_compile(model, device=None, example_hw=(800, 800)):
+    """network.py:170-208: fold, cast to fp16 (on GPU), trace to TorchScript.  On CPU the fold is
+    kept in fp32 (fp16 convolution is a GPU path)."""
+    compact = GuidanceNetCompact.from_full(model.eval().cpu())
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    compact = compact.to(dev)
+    if dev.type == "cuda":
+        compact = compact.half()
+    aux = torch.rand((1, model.in_channels) + tuple(example_hw), device=dev)
+    with torch.no_grad():
+        return torch.jit.trace(compact, (aux,), check_trace=False)
+
+
+class Denoiser:
+    """volrend::Denoiser (denoiser.hpp:11-21, denoiser.cpp:31-61).
+
+    `Denoiser(path)` loads a TorchScript module exactly like the reference; a torch.nn.Module with
+    the (weight_map, guidance_map) contract is accepted too.  An empty path raises the reference's
+    "No torchscript module is given to denoiser." (denoiser.cpp:13-16)."""
+
+    def __init__(self, ts_module, device=0):
+        self.device = torch.device("cuda", device)
+        if isinstance(ts_module, (str, bytes)):
+            if not ts_module:
+                raise RuntimeError("No torchscript module is given to denoiser.")
+            try:
+                self.module = torch.jit.load(ts_module, map_location=self.device)
+            except Exception as e:  # denoiser.cpp:22-26
+                raise RuntimeError("Error when loading torchscript model from %s" % ts_module) from e
+        else:
+            self.module = ts_module.to(self.device)
+        self.module.eval()
+
+    @torch.no_grad()
+    def denoise(self, cam, ctx, stream=None):
+        """aux [1,8,H,W] (zero-copy) -> module -> filtering(noisy -> image).  Timer buckets
+        torch / filter bracket the two stages like denoiser.cpp:36-60."""
+        tm = ctx.timer()
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(s) if hasattr(s, "cuda_stream") else _null():
+            tm.torch_start()
+            aux = torch.as_tensor(ctx.aux_view(), device=self.device)
+            weight_map, guidance_map = self.module(aux)
+            weight_map = weight_map.squeeze(0).contiguous()
+            guidance_map = guidance_map.squeeze(0).contiguous()
+            tm.torch_stop()
+            tm.filter_start()
+            V.filtering(s, weight_map, guidance_map, ctx.noisy_ptr, ctx.image_ptr)
+            tm.filter_stop()
+        return weight_map, guidance_map
+
+
+class _null:
+    def __enter__(self): return self
+    def __exit__(self, *a): return False

@@ -297,6 +297,16 @@ class RenderContext:
     def timer(self):
         return self._timer
 
+    def enable_stats(self, on=True):
+        """Work counters for the roofline's algorithmic byte count (never in a timed run)."""
+        check(lib().rto_ctx_enable_stats(self._h, int(bool(on))))
+
+    def get_stats(self, reset=True, stream=None):
+        out = (C.c_uint64 * 6)()
+        check(lib().rto_ctx_get_stats(self._h, _stream_ptr(stream), out, int(bool(reset))))
+        keys = ("rays", "rays_in_box", "steps", "levels", "hit_leaves", "hit_rays")
+        return {k: int(v) for k, v in zip(keys, out)}
+
     # device pointers / zero-copy views
     @property
     def aux_ptr(self): return lib().rto_ctx_aux(self._h)

@@ -1,0 +1,114 @@
+"""Regenerates the committed fixtures in tests/golden/ (authoring container only: it reads
+/root/reference; nothing under tests/ does so at test time).
+
+  pcg32_kat.json        from the reference's own pcg32.h       (oracle/ref_kat/Makefile `golden`)
+  guidance_golden.npz   GuidanceNet(8,32,5,2,4) of the imported reference module denoiser/network.py:
+                        state_dict + input -> (weight_map, guidance_map), full and compact
+  npz_dense.npz / npz_quant.npz + npz_cnpy.json
+                        trees written by numpy in the svox key schema, and what the reference's
+                        vendored cnpy reads from them (oracle/_ref/cnpy_dump)
+  frames_golden.npz     tiny frames from the CPU oracle (det math): tree arrays, poses, aux, rgba8
+
+The reference module `denoiser/network.py` tries to JIT-compile its CUDA extension when
+`_denoiser` is not importable (network.py:7-47).  An EMPTY placeholder module is registered under
+that name so the import succeeds; none of its functions exist or are called (the CUDA filter cannot
+run here) -- only the pure-PyTorch network classes are exercised.
+"""
+import json
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+REF = "/root/reference"
+
+
+def guidance_golden():
+    import torch
+    sys.modules.setdefault("_denoiser", types.ModuleType("_denoiser"))
+    sys.path.insert(0, REF)
+    from denoiser import network as refnet
+    torch.manual_seed(0)
+    model = refnet.GuidanceNet(8, 32, 5, 2, 4).eval()
+    aux = torch.rand(1, 8, 24, 20)
+    with torch.no_grad():
+        w_full, g_full = model(aux)
+        compact = refnet.GuidanceNetCompact(model).eval()
+        w_c, g_c = compact(aux)
+    out = {"aux": aux.numpy(), "weight_full": w_full.numpy(), "guidance_full": g_full.numpy(),
+           "weight_compact": w_c.numpy(), "guidance_compact": g_c.numpy()}
+    for k, v in model.state_dict().items():
+        out["sd." + k] = v.numpy()
+    for k, v in compact.state_dict().items():
+        out["csd." + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "guidance_golden.npz"), **out)
+    print("guidance_golden.npz: %d tensors" % len(out))
+
+
+def npz_goldens():
+    from rt_octree_amd import synth
+    tree = synth.make_tree(depth_limit=4, basis_dim=9, seed=1)
+    dense = os.path.join(HERE, "npz_dense.npz")
+    tree.save_npz(dense, compressed=True)
+    # quantised variant (compress_octree.py schema; decode n3tree.cpp:279-340): n_retain = 7
+    rs = np.random.RandomState(2)
+    cap = tree.capacity
+    n_basis, n_retain = 9, 7
+    nq = n_basis - n_retain
+    # a compressible codebook (the decode indexes it with a fixed 65536*3 stride per basis)
+    quant_colors = ((np.arange(nq * 65536 * 3) % 997) / 997.0 - 0.5).astype(np.float16).reshape(nq, 65536, 3)
+    quant_map = rs.randint(0, 65536, (nq, cap, 2, 2, 2)).astype(np.uint16)
+    sigma = tree.data[..., -1].copy()
+    retained = rs.randn(n_retain, cap, 2, 2, 2, 3).astype(np.float16)
+    quant = os.path.join(HERE, "npz_quant.npz")
+    np.savez_compressed(quant, data_dim=np.int64(28), data_format=np.array("SH9"), invradius3=tree.scale,
+                        offset=tree.offset, child=tree.child, quant_colors=quant_colors, quant_map=quant_map,
+                        sigma=sigma, data_retained=retained)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle", "ref_kat"), "-s"])
+    dump = os.path.join(ROOT, "oracle", "_ref", "cnpy_dump")
+    listing = {os.path.basename(p): json.loads(subprocess.check_output([dump, p])) for p in (dense, quant)}
+    with open(os.path.join(HERE, "npz_cnpy.json"), "w") as f:
+        json.dump(listing, f, indent=1, sort_keys=True)
+    print("npz goldens:", {k: sorted(v) for k, v in listing.items()})
+
+
+def frames_golden():
+    import orc
+    from rt_octree_amd import synth
+    out = {}
+    poses = synth.orbit_poses(3)
+    out["poses"] = poses
+    W, H = 48, 40
+    fx = synth.blender_focal(W)
+    out["size_fx"] = np.array([W, H, fx], np.float64)
+    for name, bd in (("sh9", 9), ("sh16", 16)):
+        tree = synth.make_tree(depth_limit=5, basis_dim=bd, seed=21 + bd)
+        out[name + ".child"], out[name + ".data"] = tree.child, tree.data
+        out[name + ".scale"], out[name + ".offset"] = tree.scale, tree.offset
+        ht = orc.HostTree(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+        for spp in (1, 6):
+            for pi in range(3):
+                cam = orc.camera(W, H, fx, fx, poses[pi][:3, :4].T.reshape(-1))
+                aux, rgba, st = orc.render_frame(ht, cam, orc.default_options(spp=spp), orc.rng(frame=100 + pi))
+                key = "%s.spp%d.pose%d" % (name, spp, pi)
+                out[key + ".aux"] = aux
+                out[key + ".rgba8"] = orc.rgba8(rgba)
+                out[key + ".stats"] = np.array([st[k] for k in ("rays", "rays_in_box", "steps", "levels", "hit_leaves", "hit_rays")], np.int64)
+    np.savez_compressed(os.path.join(HERE, "frames_golden.npz"), **out)
+    print("frames_golden.npz: %d arrays" % len(out))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["guidance", "npz", "frames"]
+    if "guidance" in which:
+        guidance_golden()
+    if "npz" in which:
+        npz_goldens()
+    if "frames" in which:
+        frames_golden()

@@ -1,0 +1,60 @@
+"""GuidanceNet / GuidanceNetCompact (PyTorch) against golden tensors produced by the imported
+reference module denoiser/network.py (tests/golden/make_goldens.py).  CPU, fp32.
+Tolerances: full net 1e-6 (same ops, same order); folded net 5e-6 (re-associated conv sums)."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+from rt_octree_amd import denoiser  # noqa: E402
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "guidance_golden.npz"))
+
+
+def _full():
+    net = denoiser.GuidanceNet(8, 32, 5, 2, 4)
+    sd = {k[3:]: torch.from_numpy(G[k]) for k in G.files if k.startswith("sd.")}
+    net.load_state_dict(sd, strict=True)  # parameter names are the reference's
+    return net.eval()
+
+
+def test_full_network_matches_reference():
+    net = _full()
+    assert sum(p.numel() for p in net.parameters()) == 26000  # SURVEY 8c probe
+    with torch.no_grad():
+        w, g = net(torch.from_numpy(G["aux"]))
+    assert np.allclose(w.numpy(), G["weight_full"], atol=1e-6) and np.allclose(g.numpy(), G["guidance_full"], atol=1e-6)
+    assert np.allclose(w.sum(1).numpy(), 1, atol=1e-6)  # softmax over the kernel levels
+
+
+def test_compact_fold_matches_reference():
+    net = _full()
+    c = denoiser.GuidanceNetCompact.from_full(net)
+    assert sum(p.numel() for p in c.parameters()) == 4648
+    for k in G.files:
+        if k.startswith("csd."):
+            assert np.allclose(c.state_dict()[k[4:]].numpy(), G[k], atol=1e-6), k
+    with torch.no_grad():
+        w, g = c(torch.from_numpy(G["aux"]))
+    assert np.allclose(w.numpy(), G["weight_compact"], atol=5e-6) and np.allclose(g.numpy(), G["guidance_compact"], atol=5e-6)
+    assert np.allclose(w.numpy(), G["weight_full"], atol=5e-6)
+    # the reference's compact state_dict loads into ours by name
+    c2 = denoiser.GuidanceNetCompact(8, 32, 2, 4)
+    c2.load_state_dict({k[4:]: torch.from_numpy(G[k]) for k in G.files if k.startswith("csd.")}, strict=True)
+
+
+def test_torchscript_export_roundtrip(tmp_path):
+    ts = denoiser.compact_and_compile(_full(), device=None, example_hw=(24, 20))
+    p = str(tmp_path / "ts_latest.ts")
+    ts.save(p)
+    m = torch.jit.load(p)
+    with torch.no_grad():
+        w, g = m(torch.from_numpy(G["aux"]))
+    assert np.allclose(w.numpy(), G["weight_compact"], atol=5e-6) and np.allclose(g.numpy(), G["guidance_compact"], atol=5e-6)
+
+
+def test_denoiser_requires_module():
+    with pytest.raises(RuntimeError) as e:
+        denoiser.Denoiser("")
+    assert "No torchscript module is given to denoiser." in str(e.value)

@@ -133,3 +133,65 @@ def test_full_size_properties(small_tree_sh9):
         assert rc == 0
         got = aux_f[:, idx // 800, idx % 800]
         assert np.array_equal(np.array(a8[:], np.float32).view(np.uint32), got.view(np.uint32)), idx
+
+
+def test_hip_matches_committed_golden_frames():
+    """HIP path vs tests/golden/frames_golden.npz (aux fp32 bits + RGBA8 bytes)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frames_golden.npz"))
+    W, H, fx = g["size_fx"]
+    W, H = int(W), int(H)
+    for name, fmt in (("sh9", "SH9"), ("sh16", "SH16")):
+        dt = R.N3Tree.from_arrays(g[name + ".child"], g[name + ".data"], g[name + ".scale"], g[name + ".offset"], fmt)
+        ctx = R.RenderContext(W, H)
+        for spp in (1, 6):
+            for pi in range(3):
+                _, cam = cameras(W, H, g["poses"][pi], fx=float(fx))
+                for kernel in (R.KERNEL_GENERIC, R.KERNEL_FAST):
+                    aux, _, _ = hip_frame(dt, cam, spp, frame=100 + pi, kernel=kernel, ctx=ctx)
+                    key = "%s.spp%d.pose%d" % (name, spp, pi)
+                    assert_bits_equal(aux, g[key + ".aux"], key)
+                    assert np.array_equal(ctx.download_rgba8(), g[key + ".rgba8"]), key
+
+
+def test_work_counters_match_oracle(small_tree_sh16):
+    """the units behind bench.py's algorithmic-byte count are the oracle's own counters"""
+    ht, dt = make_pair(small_tree_sh16)
+    ocam, cam = cameras(96, 64, POSES[4])
+    _, _, st = oracle_frame(ht, ocam, 6, frame=1)
+    ctx = R.RenderContext(96, 64)
+    ctx.enable_stats(True)
+    aux_s, _, _ = hip_frame(dt, cam, 6, frame=1, kernel=R.KERNEL_FAST, ctx=ctx)
+    assert ctx.get_stats() == st
+    ctx.enable_stats(False)
+    aux_t, _, _ = hip_frame(dt, cam, 6, frame=1, kernel=R.KERNEL_FAST, ctx=ctx)
+    assert_bits_equal(aux_s, aux_t, "counting instantiation renders the same frame")
+
+
+def test_tree_npz_roundtrip_on_device(tmp_path, small_tree_sh9):
+    """tree.npz (svox schema) -> rto_tree_load_npz renders the same bits as the in-memory upload"""
+    p = str(tmp_path / "tree.npz")
+    small_tree_sh9.save_npz(p, compressed=True)
+    dt_file = R.N3Tree(p)
+    assert (dt_file.capacity, dt_file.N, dt_file.data_dim, dt_file.data_format) == (small_tree_sh9.capacity, 2, 28, "SH9")
+    _, dt_mem = make_pair(small_tree_sh9)
+    _, cam = cameras(64, 40, POSES[1])
+    a1, _, _ = hip_frame(dt_file, cam, 4)
+    a2, _, _ = hip_frame(dt_mem, cam, 4)
+    assert_bits_equal(a1, a2)
+    with pytest.raises(R.RtoError):
+        R.N3Tree(str(tmp_path / "missing.npz"))
+
+
+def test_ndc_path_bit_exact(small_tree_sh9):
+    """LLFF NDC warp (maybe_world2ndc volrend.cu:35-56)."""
+    t = small_tree_sh9
+    ht = orc.HostTree(t.child, t.data, t.scale, t.offset, t.data_format, ndc=(64.0, 48.0, 50.0))
+    dt = R.N3Tree.from_arrays(t.child, t.data, t.scale, t.offset, t.data_format)
+    dt.set_ndc(64.0, 48.0, 50.0)
+    pose = synth.look_at_c2w((0.1, 0.05, 0.3), target=(0, 0, -1), up=(0, 1, 0))
+    ocam, cam = cameras(64, 48, pose, fx=50.0)
+    aux_o, rgba_o, st = oracle_frame(ht, ocam, 2)
+    for kernel in (R.KERNEL_GENERIC, R.KERNEL_FAST):
+        aux_h, rgba_h, _ = hip_frame(dt, cam, 2, kernel=kernel)
+        assert_bits_equal(aux_h, aux_o, "ndc aux")

@@ -136,6 +136,12 @@ void rto_tree_free(rto_tree* t);
 /* RenderContext::update (render_context.hpp:70-91): aux [8][H][W] f32, noisy and final images
  * [H][W][4] f32, rng = pcg32(20230418) (:16).  offscreen is always true (headless path). */
 int rto_ctx_create(int width, int height, int device, rto_ctx** out);
+/* The same with `frames` (1..8) frame slots: aux [frames][8][H][W], noisy / image [frames][H][W][4],
+ * contiguous.  Single-frame entry points and accessors act on the slot chosen with
+ * rto_ctx_select_frame (default 0); rto_launch_renderer_batch fills slots 0..n-1. */
+int rto_ctx_create_batch(int width, int height, int frames, int device, rto_ctx** out);
+int rto_ctx_frames(const rto_ctx* c);
+int rto_ctx_select_frame(rto_ctx* c, int frame);
 void rto_ctx_free(rto_ctx* c);
 int rto_ctx_width(const rto_ctx* c);
 int rto_ctx_height(const rto_ctx* c);
@@ -150,6 +156,9 @@ void rto_ctx_rng_set(rto_ctx* c, uint64_t state, uint64_t inc);
 void rto_ctx_rng_get(const rto_ctx* c, uint64_t* state, uint64_t* inc);
 /* choose the traversal kernel (RTO_KERNEL_*); default AUTO */
 int rto_ctx_set_kernel(rto_ctx* c, int kernel);
+/* Performance knobs of the fast kernel; never change results.  key: "variant" (bit 0 = node cache,
+ * bit 1 = priority ramp), "strip_rows" (tile rows per XCD strip, >= 1). */
+int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value);
 /* Work counters for the roofline's ALGORITHMIC byte count.  When enabled, the fast
  * kernel's counting instantiation runs instead of the timed one and accumulates, over the launches
  * since the last rto_ctx_get_stats(reset=1): {rays, rays_in_box, march steps, descent levels a
@@ -164,11 +173,22 @@ int rto_ctx_get_stats(rto_ctx* c, void* stream, uint64_t out[6], int reset);
 int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_options* options,
                         rto_ctx* ctx, void* stream);
 
+/* Throughput form of the operator: n frames (poses of the same tree) in ONE launch of the
+ * persistent ray-queue kernel.  Frame f is rendered with cams[f] into frame slot f with the RNG
+ * ctx.rng advanced by rng_jumps[f] * 2^32 (NULL: f jumps) -- bit-identical to n sequential
+ * rto_launch_renderer calls separated by rto_ctx_rng_advance(ctx, 1<<32), the reference's frame
+ * loop (main_headless.cpp:485-506).  ctx.rng itself is not modified.  Needs an N == 2 tree. */
+int rto_launch_renderer_batch(const rto_tree* tree, const rto_camera* cams, const int64_t* rng_jumps, int n,
+                              const rto_options* options, rto_ctx* ctx, void* stream);
+
 /* denoiser::filtering(stream, weight_map[L,H,W], guidance_map[L,H,W], img_in, img_out)
  * (filtering.cu:701-717).  All pointers are device pointers; img_in/img_out are [H][W][4] f32
  * (the reference passes ctx.noisy_tex_obj / ctx.surf_obj, denoiser.cpp:56-57).  L in 1..6. */
 int rto_filtering(void* stream, const float* weight_map, const float* guidance_map, int L, int H,
                   int W, const float* img_in, float* img_out);
+/* n images per launch: weight_map / guidance_map [n][L][H][W], img_in / img_out [n][H][W][4] */
+int rto_filtering_batch(void* stream, const float* weight_map, const float* guidance_map, int L, int H,
+                        int W, int n, const float* img_in, float* img_out);
 /* convenience: filtering from ctx noisy -> ctx image */
 int rto_ctx_filtering(rto_ctx* c, void* stream, const float* weight_map, const float* guidance_map, int L);
 

@@ -597,3 +597,26 @@ int orc_filter(int L, int H, int W, const float* weight, const float* guidance, 
 void orc_rgba8(const float* rgba, uint8_t* out, int64_t n) {
     for (int64_t j = 0; j < n; ++j) out[j] = (uint8_t)(rgba[j] * 255);
 }
+
+/* Instrumentation only: march steps per pixel of one frame (how unevenly the work is spread). */
+int orc_frame_steps(const orc_tree* tree, const orc_camera* cam, const orc_options* opt,
+                    const orc_pcg32* rng_base, uint32_t* steps_out, int num_threads) {
+    const int W = cam->width, H = cam->height;
+    int err = 0;
+#ifdef _OPENMP
+    if (num_threads <= 0) num_threads = omp_get_max_threads();
+#else
+    num_threads = 1;
+#endif
+#pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads)
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            orc_stats st;
+            memset(&st, 0, sizeof(st));
+            float a8[8], px[4];
+            int rc = orc_render_pixel(tree, cam, opt, rng_base, y * W + x, a8, px, &st);
+            if (rc) err = rc;
+            steps_out[y * W + x] = (uint32_t)st.steps;
+        }
+    return err;
+}

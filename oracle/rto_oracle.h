@@ -125,6 +125,10 @@ int orc_render_pixel(const orc_tree* t, const orc_camera* cam, const orc_options
 int orc_filter(int L, int H, int W, const float* weight, const float* guidance,
                const float* noisy, float* out, int num_threads);
 
+/* instrumentation: march steps per pixel */
+int orc_frame_steps(const orc_tree* t, const orc_camera* cam, const orc_options* opt,
+                    const orc_pcg32* rng_base, uint32_t* steps_out, int num_threads);
+
 /* main_headless.cpp:535-538 */
 void orc_rgba8(const float* rgba, uint8_t* out, int64_t n);
 

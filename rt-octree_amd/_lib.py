@@ -63,6 +63,9 @@ SYMBOLS = {
     "rto_tree_probe_npz": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
     "rto_tree_free": (None, [_P]),
     "rto_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "rto_ctx_create_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "rto_ctx_frames": (C.c_int, [_P]),
+    "rto_ctx_select_frame": (C.c_int, [_P, C.c_int]),
     "rto_ctx_free": (None, [_P]),
     "rto_ctx_width": (C.c_int, [_P]),
     "rto_ctx_height": (C.c_int, [_P]),
@@ -74,9 +77,12 @@ SYMBOLS = {
     "rto_ctx_rng_set": (None, [_P, C.c_uint64, C.c_uint64]),
     "rto_ctx_rng_get": (None, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rto_ctx_set_kernel": (C.c_int, [_P, C.c_int]),
+    "rto_ctx_set_tuning": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "rto_ctx_enable_stats": (C.c_int, [_P, C.c_int]),
     "rto_ctx_get_stats": (C.c_int, [_P, _P, C.POINTER(C.c_uint64), C.c_int]),
     "rto_launch_renderer": (C.c_int, [_P, C.POINTER(CCamera), C.POINTER(COptions), _P, _P]),
+    "rto_launch_renderer_batch": (C.c_int, [_P, C.POINTER(CCamera), C.POINTER(C.c_int64), C.c_int, C.POINTER(COptions), _P, _P]),
+    "rto_filtering_batch": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rto_filtering": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rto_ctx_filtering": (C.c_int, [_P, _P, _P, _P, C.c_int]),
     "rto_ctx_download_rgba8": (C.c_int, [_P, _P, C.c_int, _P]),

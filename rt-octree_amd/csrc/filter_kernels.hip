@@ -37,6 +37,11 @@ __global__ void __launch_bounds__(256) filter_fused(const float* __restrict__ we
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * kFiltW - L, y0 = blockIdx.y * kFiltH - L;
     const int64_t HW = (int64_t)H * W;
+    // image blockIdx.z of the batch
+    weight += (int64_t)blockIdx.z * L * HW;
+    guidance += (int64_t)blockIdx.z * L * HW;
+    img_in += (int64_t)blockIdx.z * HW;
+    img_out += (int64_t)blockIdx.z * HW;
 
     for (int e = tid; e < TH * TW; e += 256) {
         const int ty = e / TW, tx = e - ty * TW;
@@ -92,9 +97,9 @@ __global__ void __launch_bounds__(256) filter_fused(const float* __restrict__ we
     img_out[pidx] = make_float4(o0, o1, o2, 1.0f);
 }
 
-hipError_t launch_filter(const float* weight, const float* guidance, int L, int H, int W, const float* img_in,
+hipError_t launch_filter(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
                          float* img_out, hipStream_t stream) {
-    const dim3 grid((W + kFiltW - 1) / kFiltW, (H + kFiltH - 1) / kFiltH), block(256);
+    const dim3 grid((W + kFiltW - 1) / kFiltW, (H + kFiltH - 1) / kFiltH, n), block(256);
     const float4* in4 = reinterpret_cast<const float4*>(img_in);
     float4* out4 = reinterpret_cast<float4*>(img_out);
     switch (L) {  // kernel_apply filtering.cu:338-367 supports SUPPORT 1..6

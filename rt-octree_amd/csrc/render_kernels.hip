@@ -400,10 +400,28 @@ RTO_DEV void shade_leaf_packed(const TreeDev& tree, uint32_t slot, const float* 
     out[3] += cnt;
 }
 
+// 8-way select of a cached node's words by child index (static register indices only)
+RTO_DEV uint32_t select8(const uint32_t* cw, uint32_t ci) {
+    const uint32_t a = (ci & 1u) ? cw[1] : cw[0];
+    const uint32_t b = (ci & 1u) ? cw[3] : cw[2];
+    const uint32_t c = (ci & 1u) ? cw[5] : cw[4];
+    const uint32_t d = (ci & 1u) ? cw[7] : cw[6];
+    const uint32_t ab = (ci & 2u) ? b : a;
+    const uint32_t cd = (ci & 2u) ? d : c;
+    return (ci & 4u) ? cd : ab;
+}
+
+// Tuning variants of render_fast (bit flags, results identical):
+//   kVarNodeCache  keep the 8 words of the most recently visited node in registers (two dwordx4
+//                  loads per node): a step that lands in a sibling slot needs no memory access
+//   kVarPrio       raise the wave's issue priority as its march gets long (the frame ends with its
+//                  longest ray; short rays are many and latency-tolerant)
+constexpr int kVarNodeCache = 1, kVarPrio = 2;
+
 // STATS: also count the units of SURVEY 8(d)'s algorithmic-byte formula (march steps, descent
 // levels a root-restart walk would visit, distinct hit leaves, ...) into fo.stats.  Separate
 // instantiation; the timed kernel carries none of it.
-template <int SPP, bool STATS>
+template <int SPP, bool STATS, int VAR>
 __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const CamDev cam, const OptDev opt,
                                                     const Pcg32 rng_base, const PcgJumpEntry* __restrict__ jump,
                                                     const TileMap tm, const FrameOut fo) {
@@ -454,8 +472,17 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
         uint32_t pix = 0, piy = 0, piz = 0;
         int prev_lvl = 0;
         uint32_t* stack = s_stack + tid;
+        uint32_t cn = 0xffffffffu;  // cached node (kVarNodeCache)
+        uint32_t cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int iter = 0;  // wave-uniform loop count (kVarPrio)
 
         while (t < tmax) {
+            if (VAR & kVarPrio) {
+                ++iter;
+                if (iter == 40) __builtin_amdgcn_s_setprio(1);
+                if (iter == 80) __builtin_amdgcn_s_setprio(2);
+                if (iter == 140) __builtin_amdgcn_s_setprio(3);
+            }
             float pos[3] = {cen[0] + t * dir[0], cen[1] + t * dir[1], cen[2] + t * dir[2]};
             pos[0] = f_max(f_min(pos[0], 1.f - 1e-6f), 0.f);
             pos[1] = f_max(f_min(pos[1], 1.f - 1e-6f), 0.f);
@@ -473,7 +500,18 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
                 const int sh = 23 - lvl;
                 const uint32_t ci = (((ix >> sh) & 1u) << 2) | (((iy >> sh) & 1u) << 1) | ((iz >> sh) & 1u);
                 slot = node * 8u + ci;
-                w = tree.nodew[slot];
+                if (VAR & kVarNodeCache) {
+                    if (node != cn) {
+                        const uint4* __restrict__ np = reinterpret_cast<const uint4*>(tree.nodew + (size_t)node * 8u);
+                        const uint4 lo = np[0], hi = np[1];
+                        cw[0] = lo.x; cw[1] = lo.y; cw[2] = lo.z; cw[3] = lo.w;
+                        cw[4] = hi.x; cw[5] = hi.y; cw[6] = hi.z; cw[7] = hi.w;
+                        cn = node;
+                    }
+                    w = select8(cw, ci);
+                } else {
+                    w = tree.nodew[slot];
+                }
                 if (nodew_is_leaf(w)) break;
                 node += w;  // two's complement add of the relative offset
                 ++lvl;
@@ -488,14 +526,17 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
                 st_levels += (unsigned)(lvl + 1);
             }
 
-            const float cube_sz = (float)(2u << lvl);
+            // cube_sz = 2^(lvl+1) and its reciprocal straight from exponent bits; x / 2^k == x * 2^-k
+            // bit for bit (a pure exponent shift, or the same single rounding into the denormals)
+            const float cube_sz = __uint_as_float((uint32_t)(128 + lvl) << 23);
+            const float inv_cube = __uint_as_float((uint32_t)(126 - lvl) << 23);
             float loc[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const float s = pos[i] * cube_sz;
                 loc[i] = s - floorf(s);
             }
-            const float t_subcube = dda_unit(loc, invdir) / cube_sz;
+            const float t_subcube = dda_unit(loc, invdir) * inv_cube;
             const float delta_t = t_subcube + opt.step_size;
             const float sigma = half_bits_to_float((uint16_t)(w & 0xffffu));
             if (sigma > opt.sigma_thresh) {
@@ -518,6 +559,7 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
             }
             t += delta_t;
         }
+        if (VAR & kVarPrio) __builtin_amdgcn_s_setprio(0);
 
         if (STATS) st_hits = sh_nums;
         if (sh_nums != 0) {
@@ -554,6 +596,279 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
         atomicAdd(fo.stats + 4, st_hits);
         atomicAdd(fo.stats + 5, st_hits ? 1ULL : 0ULL);
     }
+}
+
+// ------------------------------------------------------------------ persistent kernel (N == 2)
+//
+// render_persist: the throughput form of render_fast.  One launch renders a BATCH of frames
+// (independent poses of the same tree): a frame is only ~10 k waves of very uneven length, so a
+// one-frame launch spends most of its time waiting for its longest rays on a nearly empty chip
+// (profiles/r1_a_*: mean residency 1.7 k of 8 k wave slots).  Here a fixed grid of persistent
+// waves pulls rays from one queue that spans every frame of the batch:
+//   * ray compaction: a lane whose ray ended (all SPP thresholds crossed, left the box, missed)
+//     idles only until the wave has kRefillMin such lanes; then the finished lanes shade + store
+//     together and a ballot / mbcnt prefix sum hands each idle lane the next ray of the queue
+//     (one atomicAdd per wave);
+//   * rays are queued in 8x8-pixel tile order, so a wave's 64 rays stay spatially coherent;
+//   * the end-of-queue drain happens once per batch instead of once per frame.
+// Per-ray arithmetic is exactly render_fast's; results are bit-identical.
+
+constexpr int kRefillMin = 24;  // idle lanes that trigger a retire + refill round
+
+// the per-ray state that survives between march steps
+template <int SPP>
+struct RayState {
+    float cen[3], dir[3], invdir[3];
+    float delta_scale, t, tmax, src;
+    float dst[SPP + 1];
+    uint32_t hits[SPP];
+    uint32_t spp, sh_nums;
+    uint32_t pix, piy, piz;
+    int prev_lvl;
+};
+
+// queue index -> (frame, x, y); tiles row-major, 64 rays per 8x8 tile; returns false for padding
+RTO_DEV bool ray_pixel(uint32_t r, uint32_t rays_per_frame, int tiles8_x, int width, int height, int& frame, int& x,
+                       int& y) {
+    frame = (int)(r / rays_per_frame);
+    const uint32_t q = r - (uint32_t)frame * rays_per_frame;
+    const int tile = (int)(q >> 6), l = (int)(q & 63u);
+    const int ty = tile / tiles8_x, tx = tile - ty * tiles8_x;
+    x = tx * 8 + (l & 7);
+    y = ty * 8 + (l >> 3);
+    return x < width && y < height;
+}
+
+template <int SPP>
+__global__ void __launch_bounds__(256) render_persist(const TreeDev tree, const OptDev opt, const FrameBatch fb,
+                                                       const PcgJumpEntry* __restrict__ jump,
+                                                       unsigned long long* __restrict__ queue) {
+    // queue[0]: next ray of the batch; queue[1]: waves that have left (the last one re-arms both)
+    extern __shared__ uint32_t s_mem[];  // [max_depth+1][256] ancestor stack, then the frame table
+    const int tid = threadIdx.x;
+    uint32_t* stack = s_mem + tid;
+    FrameDesc* s_frames = reinterpret_cast<FrameDesc*>(s_mem + (size_t)(tree.max_depth + 1) * 256);
+#pragma unroll
+    for (int f = 0; f < kMaxBatch; ++f)  // static indices: the kernarg struct is never address-taken
+        if (tid == f) s_frames[f] = fb.f[f];
+    __syncthreads();
+
+    const int W = fb.width, H = fb.height;
+    const int64_t SIZE = (int64_t)W * H;
+    const int tiles8_x = (W + 7) >> 3, tiles8_y = (H + 7) >> 3;
+    const uint32_t rays_per_frame = (uint32_t)(tiles8_x * tiles8_y) * 64u;
+    const uint32_t total = rays_per_frame * (uint32_t)fb.n;
+
+    RayState<SPP> rs;
+    bool active = false;         // marching
+    uint32_t ray = 0xffffffffu;  // queue index of the ray this lane owns (retire pending when !active)
+    bool drained = false;        // queue exhausted (wave-uniform)
+
+    for (;;) {
+        const unsigned long long act_mask = __ballot(active);
+        if (64 - __popcll(act_mask) >= kRefillMin || act_mask == 0ULL) {
+            for (;;) {
+                // ---- retire: hand the finished rays' hit lists to the shading kernel
+                if (!active && ray != 0xffffffffu) {
+                    int frame, x, y;
+                    ray_pixel(ray, rays_per_frame, tiles8_x, W, H, frame, x, y);
+                    uint32_t* hp = s_frames[frame].hits + (y * W + x);
+#pragma unroll
+                    for (int i = 0; i < SPP; ++i)
+                        if (i <= (int)rs.sh_nums) hp[(int64_t)i * SIZE] = (i < (int)rs.sh_nums) ? rs.hits[i] : kNoHit;
+                    ray = 0xffffffffu;
+                }
+                if (drained) break;
+                // ---- refill: hand the next queue entries to the idle lanes (ballot + prefix sum)
+                const unsigned long long need = __ballot(!active);
+                const int n_need = __popcll(need);
+                if (n_need < kRefillMin) break;
+                unsigned long long base = 0;
+                if ((tid & 63) == 0) base = atomicAdd(queue, (unsigned long long)n_need);
+                const uint32_t base32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+                if (base32 >= total) {  // the counter never exceeds total + 64 * waves: fits 32 bits
+                    drained = true;
+                    break;
+                }
+                if (!active) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                    const uint32_t r = base32 + rank;
+                    int frame, x, y;
+                    if (r < total && ray_pixel(r, rays_per_frame, tiles8_x, W, H, frame, x, y)) {
+                        const FrameDesc& fd = s_frames[frame];
+                        CamDev cam;
+                        cam.width = W;
+                        cam.height = H;
+                        cam.fx = fd.fx;
+                        cam.fy = fd.fy;
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) cam.transform[i] = fd.transform[i];
+                        float vdir[3];
+                        ray_setup(x, y, cam, tree, rs.dir, vdir, rs.cen);
+                        float tmin;
+                        ray = r;  // a ray that misses the box stays "finished": next retire stores background
+                        rs.sh_nums = 0;
+                        if (ray_enter(tree, opt, rs.dir, rs.cen, 1e9f, rs.invdir, rs.delta_scale, tmin, rs.tmax)) {
+                            Pcg32 rng;
+                            rng.state = fd.rng_state;
+                            rng.inc = fd.rng_inc;
+                            pcg_advance_tab(rng, (uint32_t)((y * W + x) * SPP), jump);
+#pragma unroll
+                            for (int n = 0; n < SPP; ++n) {
+                                float tv = -det_logf(1.0f - pcg_next_float(rng));
+#pragma unroll
+                                for (int i = 0; i < n; ++i) {
+                                    const float lo = f_min(rs.dst[i], tv), hi = f_max(rs.dst[i], tv);
+                                    rs.dst[i] = lo;
+                                    tv = hi;
+                                }
+                                rs.dst[n] = tv;
+                            }
+                            rs.dst[SPP] = 3.402823466e+38f;
+#pragma unroll
+                            for (int i = 0; i < SPP; ++i) rs.hits[i] = 0;
+                            rs.spp = 0;
+                            rs.src = 0;
+                            rs.t = tmin;
+                            rs.pix = rs.piy = rs.piz = 0;
+                            rs.prev_lvl = 0;
+                            active = rs.t < rs.tmax;
+                        }
+                    }
+                }
+            }
+            if (__ballot(active) == 0ULL) {
+                if (drained) break;
+                continue;
+            }
+        }
+
+        // ---- one march step for every active lane (rt_core.cuh:241-270; same code as render_fast)
+        if (active) {
+            float pos[3] = {rs.cen[0] + rs.t * rs.dir[0], rs.cen[1] + rs.t * rs.dir[1], rs.cen[2] + rs.t * rs.dir[2]};
+            pos[0] = f_max(f_min(pos[0], 1.f - 1e-6f), 0.f);
+            pos[1] = f_max(f_min(pos[1], 1.f - 1e-6f), 0.f);
+            pos[2] = f_max(f_min(pos[2], 1.f - 1e-6f), 0.f);
+            const uint32_t ix = (uint32_t)(pos[0] * 16777216.f);
+            const uint32_t iy = (uint32_t)(pos[1] * 16777216.f);
+            const uint32_t iz = (uint32_t)(pos[2] * 16777216.f);
+            const uint32_t diff = (ix ^ rs.pix) | (iy ^ rs.piy) | (iz ^ rs.piz);
+            int lvl = __clz((int)diff) - 8;
+            lvl = lvl < rs.prev_lvl ? lvl : rs.prev_lvl;
+            uint32_t node = lvl ? stack[lvl * 256] : 0u;
+            uint32_t w, slot;
+            for (;;) {
+                const int sh = 23 - lvl;
+                const uint32_t ci = (((ix >> sh) & 1u) << 2) | (((iy >> sh) & 1u) << 1) | ((iz >> sh) & 1u);
+                slot = node * 8u + ci;
+                w = tree.nodew[slot];
+                if (nodew_is_leaf(w)) break;
+                node += w;
+                ++lvl;
+                stack[lvl * 256] = node;
+            }
+            rs.pix = ix;
+            rs.piy = iy;
+            rs.piz = iz;
+            rs.prev_lvl = lvl;
+            const float cube_sz = __uint_as_float((uint32_t)(128 + lvl) << 23);
+            const float inv_cube = __uint_as_float((uint32_t)(126 - lvl) << 23);
+            float loc[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float s = pos[i] * cube_sz;
+                loc[i] = s - floorf(s);
+            }
+            const float t_subcube = dda_unit(loc, rs.invdir) * inv_cube;
+            const float delta_t = t_subcube + opt.step_size;
+            const float sigma = half_bits_to_float((uint16_t)(w & 0xffffu));
+            bool done = false;
+            if (sigma > opt.sigma_thresh) {
+                const float delta = delta_t * rs.delta_scale * sigma;
+                if (rs.src + delta >= rs.dst[0]) {
+                    uint32_t cnt = 0;
+                    do {
+                        ++cnt;
+                        ++rs.spp;
+#pragma unroll
+                        for (int i = 0; i < SPP; ++i) rs.dst[i] = rs.dst[i + 1];
+                    } while (rs.src + delta >= rs.dst[0]);
+                    const uint32_t h = hit_pack(slot, cnt);
+#pragma unroll
+                    for (int i = 0; i < SPP; ++i) rs.hits[i] = (i == (int)rs.sh_nums) ? h : rs.hits[i];
+                    ++rs.sh_nums;
+                    done = rs.spp == SPP;
+                }
+                rs.src += delta;
+            }
+            rs.t += delta_t;
+            active = !done && rs.t < rs.tmax;
+        }
+    }
+    // the last wave out re-arms the queue for the next launch (stream order makes it visible)
+    if ((tid & 63) == 0) {
+        const unsigned long long waves = (unsigned long long)gridDim.x * (blockDim.x >> 6);
+        if (atomicAdd(queue + 1, 1ULL) == waves - 1ULL) {
+            queue[0] = 0ULL;
+            queue[1] = 0ULL;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ shading kernel
+// Second half of trace_ray (rt_core.cuh:272-331) + the pixel epilogue (volrend.cu:174-212) for the
+// batched path: one thread per pixel, pixel-linear so the 8 aux planes and the RGBA32F image are
+// written fully coalesced.  hits: [SPP][H*W] packed entries, kNoHit-terminated.
+template <int SPP>
+__global__ void __launch_bounds__(256) shade_kernel(const TreeDev tree, const OptDev opt, const FrameBatch fb) {
+    const int W = fb.width, H = fb.height;
+    const int64_t SIZE = (int64_t)W * H;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= SIZE) return;
+    const FrameDesc& fd = fb.f[blockIdx.y];  // block-uniform index: scalar loads from the kernarg
+    float out[4] = {0.f, 0.f, 0.f, 0.f};
+    const uint32_t* hp = fd.hits + idx;
+    uint32_t h = hp[0];
+    if (h != kNoHit) {
+        const int x = idx % W, y = idx / W;
+        CamDev cam;
+        cam.width = W;
+        cam.height = H;
+        cam.fx = fd.fx;
+        cam.fy = fd.fy;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) cam.transform[i] = fd.transform[i];
+        float dir[3], vdir[3], cen[3];
+        ray_setup(x, y, cam, tree, dir, vdir, cen);  // only vdir is needed (rt_core.cuh:278)
+        float basis_fn[RTO_BASIS_MAX_DEV];
+        ray_basis(tree, opt, vdir, basis_fn);
+        for (int i = 0; i < SPP; ++i) {
+            const uint32_t slot = h & 0x07ffffffu;
+            const float cnt = (float)((h >> 27) + 1u);
+            if (tree.format == 1 && tree.data_dim == 28)
+                shade_leaf_packed<28>(tree, slot, basis_fn, cnt, out);
+            else if (tree.format == 1 && tree.data_dim == 49)
+                shade_leaf_packed<49>(tree, slot, basis_fn, cnt, out);
+            else if (tree.format == 1 && tree.data_dim == 76)
+                shade_leaf_packed<76>(tree, slot, basis_fn, cnt, out);
+            else
+                shade_leaf(tree, tree.data + (uint64_t)slot * tree.data_dim, basis_fn, cnt, out);
+            if (i + 1 == SPP) break;
+            h = hp[(int64_t)(i + 1) * SIZE];
+            if (h == kNoHit) break;
+        }
+        constexpr float INV_SPP = 1.0f / SPP;
+        out[0] *= INV_SPP;
+        out[1] *= INV_SPP;
+        out[2] *= INV_SPP;
+        out[3] *= INV_SPP;
+    }
+    FrameOut fo;
+    fo.aux = fd.aux;
+    fo.image = fd.image;
+    fo.stats = nullptr;
+    write_pixel(fo, SIZE, idx, opt.background_brightness, out);
 }
 
 // ------------------------------------------------------------------ u8 conversion
@@ -601,16 +916,24 @@ TileMap make_tile_map(int width, int height, int strip_rows) {
 template <int SPP>
 static hipError_t launch_spp(int kernel, const TreeDev& tree, const CamDev& cam, const OptDev& opt,
                              const Pcg32& rng, const PcgJumpEntry* jump, const FrameOut& fo, int strip_rows,
-                             hipStream_t stream) {
+                             int variant, hipStream_t stream) {
     if (kernel == 2) {
         const TileMap tm = make_tile_map(cam.width, cam.height, strip_rows);
         const size_t lds = (size_t)(tree.max_depth + 1) * 256 * sizeof(uint32_t);
-        if (fo.stats)
-            hipLaunchKernelGGL((render_fast<SPP, true>), dim3(8 * tm.per_xcd), dim3(256), lds, stream, tree, cam, opt,
-                               rng, jump, tm, fo);
-        else
-            hipLaunchKernelGGL((render_fast<SPP, false>), dim3(8 * tm.per_xcd), dim3(256), lds, stream, tree, cam, opt,
-                               rng, jump, tm, fo);
+        const dim3 grid(8 * tm.per_xcd), block(256);
+#define RTO_LAUNCH_FAST(ST, V) \
+    hipLaunchKernelGGL((render_fast<SPP, ST, V>), grid, block, lds, stream, tree, cam, opt, rng, jump, tm, fo)
+        if (fo.stats) {
+            RTO_LAUNCH_FAST(true, 0);
+        } else {
+            switch (variant & 3) {
+                case 0: RTO_LAUNCH_FAST(false, 0); break;
+                case 1: RTO_LAUNCH_FAST(false, 1); break;
+                case 2: RTO_LAUNCH_FAST(false, 2); break;
+                default: RTO_LAUNCH_FAST(false, 3); break;
+            }
+        }
+#undef RTO_LAUNCH_FAST
     } else {
         const int64_t size = (int64_t)cam.width * cam.height;
         hipLaunchKernelGGL(render_generic<SPP>, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, stream, tree, cam,
@@ -621,16 +944,53 @@ static hipError_t launch_spp(int kernel, const TreeDev& tree, const CamDev& cam,
 
 hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev& cam, const OptDev& opt,
                          const Pcg32& rng, const PcgJumpEntry* jump, const FrameOut& fo, int strip_rows,
-                         hipStream_t stream) {
+                         int variant, hipStream_t stream) {
     switch (spp) {  // volrend.cu:266-278
-        case 1: return launch_spp<1>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
-        case 2: return launch_spp<2>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
-        case 3: return launch_spp<3>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
-        case 4: return launch_spp<4>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
-        case 6: return launch_spp<6>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
-        case 8: return launch_spp<8>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
-        case 16: return launch_spp<16>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
-        case 32: return launch_spp<32>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
+        case 1: return launch_spp<1>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, variant, stream);
+        case 2: return launch_spp<2>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, variant, stream);
+        case 3: return launch_spp<3>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, variant, stream);
+        case 4: return launch_spp<4>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, variant, stream);
+        case 6: return launch_spp<6>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, variant, stream);
+        case 8: return launch_spp<8>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, variant, stream);
+        case 16: return launch_spp<16>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, variant, stream);
+        case 32: return launch_spp<32>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, variant, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int SPP>
+static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
+                                   const PcgJumpEntry* jump, unsigned long long* queue, int num_cus,
+                                   hipStream_t stream) {
+    const size_t lds = (size_t)(tree.max_depth + 1) * 256 * sizeof(uint32_t) + sizeof(FrameDesc) * kMaxBatch;
+    static int blocks_per_cu = 0;  // per SPP instantiation
+    if (blocks_per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_persist<SPP>, 256, lds) != hipSuccess || nb < 1) nb = 2;
+        blocks_per_cu = nb > 8 ? 8 : nb;
+    }
+    const int tiles = ((fb.width + 7) / 8) * ((fb.height + 7) / 8) * fb.n;
+    int grid = num_cus * blocks_per_cu;
+    if (grid > (tiles + 3) / 4) grid = (tiles + 3) / 4;  // never more waves than 8x8 tiles
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(render_persist<SPP>, dim3(grid), dim3(256), lds, stream, tree, opt, fb, jump, queue);
+    if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
+    const int64_t size = (int64_t)fb.width * fb.height;
+    hipLaunchKernelGGL(shade_kernel<SPP>, dim3((unsigned)((size + 255) / 256), fb.n), dim3(256), 0, stream, tree, opt, fb);
+    return hipGetLastError();
+}
+
+hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
+                               const PcgJumpEntry* jump, unsigned long long* queue, int num_cus, hipStream_t stream) {
+    switch (spp) {
+        case 1: return launch_batch_spp<1>(tree, opt, fb, jump, queue, num_cus, stream);
+        case 2: return launch_batch_spp<2>(tree, opt, fb, jump, queue, num_cus, stream);
+        case 3: return launch_batch_spp<3>(tree, opt, fb, jump, queue, num_cus, stream);
+        case 4: return launch_batch_spp<4>(tree, opt, fb, jump, queue, num_cus, stream);
+        case 6: return launch_batch_spp<6>(tree, opt, fb, jump, queue, num_cus, stream);
+        case 8: return launch_batch_spp<8>(tree, opt, fb, jump, queue, num_cus, stream);
+        case 16: return launch_batch_spp<16>(tree, opt, fb, jump, queue, num_cus, stream);
+        case 32: return launch_batch_spp<32>(tree, opt, fb, jump, queue, num_cus, stream);
         default: return hipErrorInvalidValue;
     }
 }

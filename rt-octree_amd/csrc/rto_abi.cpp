@@ -68,6 +68,12 @@ struct rto_tree {
 struct rto_ctx {
     int device = 0;
     int width = 0, height = 0;
+    int frames = 1;  // frame slots (batched launches render slots 0..n-1)
+    int sel = 0;     // slot the single-frame entry points and accessors refer to
+    int num_cus = 256;
+    unsigned long long* queue = nullptr;  // persistent-kernel ray queue {next, waves_done}
+    uint32_t* hits = nullptr;             // [frames][hits_spp][H*W] traversal -> shading hand-off
+    int hits_spp = 0;
     float* aux = nullptr;
     float* noisy = nullptr;
     float* image = nullptr;
@@ -78,6 +84,7 @@ struct rto_ctx {
     bool jump_valid = false;
     int kernel = RTO_KERNEL_AUTO;
     int strip_rows = 1;
+    int variant = 0;
     bool stats_on = false;
     unsigned long long* stats = nullptr;  // device, 6 counters
     // Timer (render_context.hpp:122-213)
@@ -177,7 +184,7 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
     size_t dev_bytes = data_bytes + 16 + child_bytes;
     // traversal image for the fast kernel: N == 2, depth within the 24 fixed-point bits, slot index
     // within the 27 bits of a hit-list entry
-    if (N == 2 && max_depth <= 24 && n_slots <= (int64_t(1) << 27)) {
+    if (N == 2 && max_depth <= 24 && n_slots < (int64_t(1) << 27)) {
         int* d_bad = nullptr;
         if (hipMalloc(&t->d_nodew, (size_t)n_slots * 4) != hipSuccess || hipMalloc((void**)&d_bad, 4) != hipSuccess ||
             hipMemset(d_bad, 0, 4) != hipSuccess)
@@ -413,7 +420,13 @@ void rto_tree_free(rto_tree* t) {
 }
 
 int rto_ctx_create(int width, int height, int device, rto_ctx** out) {
+    return rto_ctx_create_batch(width, height, 1, device, out);
+}
+
+int rto_ctx_create_batch(int width, int height, int frames, int device, rto_ctx** out) {
     if (width <= 0 || height <= 0 || !out) return set_err(RTO_E_INVALID, "rto_ctx_create: bad size");
+    if (frames < 1 || frames > rto::kMaxBatch)
+        return set_err(RTO_E_INVALID, "rto_ctx_create_batch: frames must be in 1.." + std::to_string(rto::kMaxBatch));
     if ((int64_t)width * height * 32 > 0x7fffffffLL)
         return set_err(RTO_E_INVALID, "rto_ctx_create: width*height*32 exceeds the int range of idx*SPP (volrend.cu:157)");
     int ndev = 0;
@@ -426,11 +439,19 @@ int rto_ctx_create(int width, int height, int device, rto_ctx** out) {
     c->device = device;
     c->width = width;
     c->height = height;
-    const size_t px = (size_t)width * height;
+    c->frames = frames;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            c->num_cus = prop.multiProcessorCount;
+    }
+    const size_t px = (size_t)width * height * frames;
     if (hipMalloc((void**)&c->aux, px * RTO_AUX_CHANNELS * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&c->noisy, px * 4 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&c->image, px * 4 * sizeof(float)) != hipSuccess ||
-        hipMalloc((void**)&c->rgba8, px * 4) != hipSuccess) {
+        hipMalloc((void**)&c->rgba8, px * 4) != hipSuccess ||
+        hipMalloc((void**)&c->queue, 2 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->queue, 0, 2 * sizeof(unsigned long long)) != hipSuccess) {
         rto_ctx_free(c);
         return set_err(RTO_E_HIP, "hipMalloc(ctx buffers) failed");
     }
@@ -456,6 +477,8 @@ void rto_ctx_free(rto_ctx* c) {
     if (c->image) (void)hipFree(c->image);
     if (c->rgba8) (void)hipFree(c->rgba8);
     if (c->jump) (void)hipFree(c->jump);
+    if (c->queue) (void)hipFree(c->queue);
+    if (c->hits) (void)hipFree(c->hits);
     if (c->stats) (void)hipFree(c->stats);
     for (int i = 0; i < 3; ++i) {
         if (c->t_start[i]) (void)hipEventDestroy(c->t_start[i]);
@@ -466,9 +489,16 @@ void rto_ctx_free(rto_ctx* c) {
 
 int rto_ctx_width(const rto_ctx* c) { return c ? c->width : 0; }
 int rto_ctx_height(const rto_ctx* c) { return c ? c->height : 0; }
-float* rto_ctx_aux(rto_ctx* c) { return c ? c->aux : nullptr; }
-float* rto_ctx_noisy(rto_ctx* c) { return c ? c->noisy : nullptr; }
-float* rto_ctx_image(rto_ctx* c) { return c ? c->image : nullptr; }
+static size_t frame_px(const rto_ctx* c) { return (size_t)c->width * c->height; }
+float* rto_ctx_aux(rto_ctx* c) { return c ? c->aux + (size_t)c->sel * RTO_AUX_CHANNELS * frame_px(c) : nullptr; }
+float* rto_ctx_noisy(rto_ctx* c) { return c ? c->noisy + (size_t)c->sel * 4 * frame_px(c) : nullptr; }
+float* rto_ctx_image(rto_ctx* c) { return c ? c->image + (size_t)c->sel * 4 * frame_px(c) : nullptr; }
+int rto_ctx_frames(const rto_ctx* c) { return c ? c->frames : 0; }
+int rto_ctx_select_frame(rto_ctx* c, int frame) {
+    if (!c || frame < 0 || frame >= c->frames) return set_err(RTO_E_INVALID, "rto_ctx_select_frame: frame out of range");
+    c->sel = frame;
+    return RTO_OK;
+}
 
 void rto_ctx_rng_seed(rto_ctx* c, uint64_t initstate, uint64_t initseq) {
     if (c) pcg_seed(c->rng, initstate, initseq);
@@ -493,6 +523,20 @@ int rto_ctx_set_kernel(rto_ctx* c, int kernel) {
     if (!c || kernel < RTO_KERNEL_AUTO || kernel > RTO_KERNEL_FAST)
         return set_err(RTO_E_INVALID, "rto_ctx_set_kernel: bad argument");
     c->kernel = kernel;
+    return RTO_OK;
+}
+
+int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value) {
+    if (!c || !key) return set_err(RTO_E_INVALID, "rto_ctx_set_tuning: null argument");
+    const std::string k(key);
+    if (k == "variant") {
+        c->variant = value;
+    } else if (k == "strip_rows") {
+        if (value < 1) return set_err(RTO_E_INVALID, "strip_rows must be >= 1");
+        c->strip_rows = value;
+    } else {
+        return set_err(RTO_E_INVALID, "unknown tuning key '" + k + "'");
+    }
     return RTO_OK;
 }
 
@@ -564,35 +608,106 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
     od.basis_minmax[0] = o->basis_minmax[0];
     od.basis_minmax[1] = o->basis_minmax[1];
     rto::FrameOut fo;
-    fo.aux = ctx->aux;
-    fo.image = o->denoise ? ctx->noisy : ctx->image;  // volrend.cu:206
+    fo.aux = rto_ctx_aux(ctx);
+    fo.image = o->denoise ? rto_ctx_noisy(ctx) : rto_ctx_image(ctx);  // volrend.cu:206
     fo.stats = nullptr;
     if (ctx->stats_on) {
         if (kernel != RTO_KERNEL_FAST) return set_err(RTO_E_UNSUPPORTED, "work counters need the fast kernel");
         fo.stats = ctx->stats;
     }
 
-    hipError_t e = rto::launch_render(kernel, o->spp, tree->dev, cd, od, ctx->rng, ctx->jump, fo, ctx->strip_rows, stream);
+    hipError_t e = rto::launch_render(kernel, o->spp, tree->dev, cd, od, ctx->rng, ctx->jump, fo, ctx->strip_rows, ctx->variant, stream);
     if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("render launch failed: ") + hipGetErrorString(e));
+    return RTO_OK;
+}
+
+int rto_launch_renderer_batch(const rto_tree* tree, const rto_camera* cams, const int64_t* rng_jumps, int n,
+                              const rto_options* o, rto_ctx* ctx, void* stream_) {
+    if (!tree || !cams || !o || !ctx) return set_err(RTO_E_INVALID, "rto_launch_renderer_batch: null argument");
+    if (n < 1 || n > ctx->frames) return set_err(RTO_E_INVALID, "rto_launch_renderer_batch: n exceeds the context's frame slots");
+    if (!spp_supported(o->spp))
+        return set_err(RTO_E_SPP, "spp == " + std::to_string(o->spp) + " not supported. (supported: 1,2,3,4,6,8,16,32)");
+    if (tree->device != ctx->device) return set_err(RTO_E_INVALID, "tree and context live on different devices");
+    if (o->enable_probe) return set_err(RTO_E_UNSUPPORTED, "enable_probe is a GUI feature, not on the headless path");
+    {
+        const float* a = o->rot_dirs;
+        if (!(std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) < 1e-6))
+            return set_err(RTO_E_UNSUPPORTED, "rot_dirs is a GUI feature, not on the headless path");
+    }
+    if (tree->dev.format == RTO_FMT_SG || tree->dev.format == RTO_FMT_ASG)
+        return set_err(RTO_E_UNSUPPORTED, "SG/ASG bases are untested upstream and not built");
+    if (!tree->fast_ok) return set_err(RTO_E_UNSUPPORTED, "the batched renderer needs an N == 2 tree of depth <= 24");
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");
+    if (ctx->hits_spp < o->spp) {  // grow the hit-list buffer (first use, or a larger spp); stream-ordered free
+        if (ctx->hits) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFree(ctx->hits));
+            ctx->hits = nullptr;
+        }
+        HIP_TRY(hipMalloc((void**)&ctx->hits, (size_t)ctx->frames * o->spp * frame_px(ctx) * sizeof(uint32_t)));
+        ctx->hits_spp = o->spp;
+    }
+    rto::FrameBatch fb;
+    std::memset(&fb, 0, sizeof(fb));
+    fb.n = n;
+    fb.width = ctx->width;
+    fb.height = ctx->height;
+    const size_t px = frame_px(ctx);
+    for (int f = 0; f < n; ++f) {
+        if (cams[f].width != ctx->width || cams[f].height != ctx->height)
+            return set_err(RTO_E_INVALID, "camera size does not match the render context");
+        if (!(cams[f].fx != 0.f) || !(cams[f].fy != 0.f)) return set_err(RTO_E_INVALID, "camera focal length is zero");
+        rto::FrameDesc& d = fb.f[f];
+        d.fx = cams[f].fx;
+        d.fy = cams[f].fy;
+        std::memcpy(d.transform, cams[f].transform, sizeof(d.transform));
+        // frame f = what the f-th of n sequential launch_renderer calls would see with
+        // ctx.rng.advance() in between (main_headless.cpp:494-506), or an explicit jump count
+        const int64_t jumps = rng_jumps ? rng_jumps[f] : (int64_t)f;
+        const rto::PcgJumpEntry j = pcg_jump(ctx->rng.inc, (uint64_t)jumps << 32);
+        d.rng_state = j.mult * ctx->rng.state + j.plus;
+        d.rng_inc = ctx->rng.inc;
+        d.aux = ctx->aux + (size_t)f * RTO_AUX_CHANNELS * px;
+        d.image = (o->denoise ? ctx->noisy : ctx->image) + (size_t)f * 4 * px;
+        d.hits = ctx->hits + (size_t)f * o->spp * px;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = ensure_jump_table(ctx, stream);
+    if (rc != RTO_OK) return rc;
+    rto::OptDev od;
+    od.step_size = o->step_size;
+    od.sigma_thresh = o->sigma_thresh;
+    od.background_brightness = o->background_brightness;
+    std::memcpy(od.render_bbox, o->render_bbox, sizeof(od.render_bbox));
+    od.basis_minmax[0] = o->basis_minmax[0];
+    od.basis_minmax[1] = o->basis_minmax[1];
+    hipError_t e = rto::launch_render_batch(o->spp, tree->dev, od, fb, ctx->jump, ctx->queue, ctx->num_cus, stream);
+    if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("batched render launch failed: ") + hipGetErrorString(e));
+    return RTO_OK;
+}
+
+int rto_filtering_batch(void* stream, const float* weight_map, const float* guidance_map, int L, int H, int W, int n,
+                        const float* img_in, float* img_out) {
+    if (!weight_map || !guidance_map || !img_in || !img_out || H <= 0 || W <= 0 || n < 1)
+        return set_err(RTO_E_INVALID, "rto_filtering: null pointer or bad size");
+    if (L < 1 || L > 6)  // filtering.cu:362-366
+        return set_err(RTO_E_INVALID, "Kernel size == " + std::to_string(L * 2 + 1) + " not supported.");
+    if (img_in == img_out) return set_err(RTO_E_INVALID, "rto_filtering: img_in and img_out must differ");
+    hipError_t e = rto::launch_filter(weight_map, guidance_map, L, H, W, n, img_in, img_out, (hipStream_t)stream);
+    if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("filter launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
 }
 
 int rto_filtering(void* stream, const float* weight_map, const float* guidance_map, int L, int H, int W,
                   const float* img_in, float* img_out) {
-    if (!weight_map || !guidance_map || !img_in || !img_out || H <= 0 || W <= 0)
-        return set_err(RTO_E_INVALID, "rto_filtering: null pointer or bad size");
-    if (L < 1 || L > 6)  // filtering.cu:362-366
-        return set_err(RTO_E_INVALID, "Kernel size == " + std::to_string(L * 2 + 1) + " not supported.");
-    if (img_in == img_out) return set_err(RTO_E_INVALID, "rto_filtering: img_in and img_out must differ");
-    hipError_t e = rto::launch_filter(weight_map, guidance_map, L, H, W, img_in, img_out, (hipStream_t)stream);
-    if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("filter launch failed: ") + hipGetErrorString(e));
-    return RTO_OK;
+    return rto_filtering_batch(stream, weight_map, guidance_map, L, H, W, 1, img_in, img_out);
 }
 
 int rto_ctx_filtering(rto_ctx* c, void* stream, const float* weight_map, const float* guidance_map, int L) {
     if (!c) return set_err(RTO_E_INVALID, "rto_ctx_filtering: null context");
     DeviceGuard guard(c->device);
-    return rto_filtering(stream, weight_map, guidance_map, L, c->height, c->width, c->noisy, c->image);
+    return rto_filtering(stream, weight_map, guidance_map, L, c->height, c->width, rto_ctx_noisy(c), rto_ctx_image(c));
 }
 
 int rto_ctx_download_rgba8(rto_ctx* c, void* stream_, int which, uint8_t* host_out) {
@@ -600,7 +715,7 @@ int rto_ctx_download_rgba8(rto_ctx* c, void* stream_, int which, uint8_t* host_o
     DeviceGuard guard(c->device);
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t px = (int64_t)c->width * c->height;
-    HIP_TRY(rto::launch_rgba8(which ? c->noisy : c->image, c->rgba8, px, stream));
+    HIP_TRY(rto::launch_rgba8(which ? rto_ctx_noisy(c) : rto_ctx_image(c), c->rgba8, px, stream));
     HIP_TRY(hipMemcpyAsync(host_out, c->rgba8, (size_t)px * 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return RTO_OK;
@@ -611,7 +726,7 @@ int rto_ctx_download_image(rto_ctx* c, void* stream_, int which, float* host_out
     DeviceGuard guard(c->device);
     hipStream_t stream = (hipStream_t)stream_;
     const size_t bytes = (size_t)c->width * c->height * 4 * sizeof(float);
-    HIP_TRY(hipMemcpyAsync(host_out, which ? c->noisy : c->image, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(host_out, which ? rto_ctx_noisy(c) : rto_ctx_image(c), bytes, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return RTO_OK;
 }
@@ -621,7 +736,7 @@ int rto_ctx_download_aux(rto_ctx* c, void* stream_, float* host_out) {
     DeviceGuard guard(c->device);
     hipStream_t stream = (hipStream_t)stream_;
     const size_t bytes = (size_t)c->width * c->height * RTO_AUX_CHANNELS * sizeof(float);
-    HIP_TRY(hipMemcpyAsync(host_out, c->aux, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(host_out, rto_ctx_aux(c), bytes, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return RTO_OK;
 }

@@ -48,6 +48,23 @@ struct TileMap {
     int per_xcd;           // workgroups per XCD (grid = 8 * per_xcd)
 };
 
+// One frame of a batched launch (render_persist): its camera, its RNG base state and where its
+// pixels go.  width/height are shared by the batch.
+constexpr int kMaxBatch = 8;
+struct FrameDesc {
+    float fx, fy;
+    float transform[12];
+    uint64_t rng_state, rng_inc;
+    float* aux;
+    float* image;
+    uint32_t* hits;  // [SPP][H*W] packed hit entries, kNoHit-terminated (traversal -> shading)
+};
+constexpr uint32_t kNoHit = 0xffffffffu;
+struct FrameBatch {
+    int n, width, height, pad;
+    FrameDesc f[kMaxBatch];
+};
+
 struct FrameOut {
     float* aux;    // [8][H][W]
     float* image;  // [H][W][4]: noisy image when opt.denoise, else final (volrend.cu:206)

@@ -16,12 +16,17 @@ TileMap make_tile_map(int width, int height, int strip_rows);
 // kernel: 1 = generic, 2 = fast.  spp must be one of {1,2,3,4,6,8,16,32} (hipErrorInvalidValue otherwise)
 hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev& cam, const OptDev& opt,
                          const Pcg32& rng, const PcgJumpEntry* jump, const FrameOut& fo, int strip_rows,
-                         hipStream_t stream);
+                         int variant, hipStream_t stream);
+
+// persistent batched renderer (N == 2 trees): fb.n frames in one launch; `queue` = 2 zeroed u64
+hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
+                               const PcgJumpEntry* jump, unsigned long long* queue, int num_cus, hipStream_t stream);
 
 hipError_t launch_rgba8(const float* rgba, uint8_t* out, int64_t n_pixels, hipStream_t stream);
 
 // denoiser/extension/filtering.cu:108-228,440-470: L levels, support = level + 1
-hipError_t launch_filter(const float* weight, const float* guidance, int L, int H, int W, const float* img_in,
+// n images per launch: weight/guidance [n][L][H][W], img_in/img_out [n][H][W][4]
+hipError_t launch_filter(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
                          float* img_out, hipStream_t stream);
 
 }  // namespace rto

@@ -266,12 +266,12 @@ class RenderContext:
 
     CHANNELS = AUX_CHANNELS
 
-    def __init__(self, width, height, device=0):
+    def __init__(self, width, height, device=0, frames=1):
         self._h = C.c_void_p(0)
         h = C.c_void_p(0)
-        check(lib().rto_ctx_create(int(width), int(height), int(device), C.byref(h)))
+        check(lib().rto_ctx_create_batch(int(width), int(height), int(frames), int(device), C.byref(h)))
         self._h = h
-        self.width, self.height, self.device = int(width), int(height), int(device)
+        self.width, self.height, self.device, self.frames = int(width), int(height), int(device), int(frames)
         self.offscreen = True
         self._timer = Timer(self)
 
@@ -291,11 +291,26 @@ class RenderContext:
         lib().rto_ctx_rng_get(self._h, C.byref(s), C.byref(i))
         return s.value, i.value
 
+    def select_frame(self, frame):
+        """frame slot the single-frame entry points, accessors and downloads refer to"""
+        check(lib().rto_ctx_select_frame(self._h, int(frame)))
+
+    def batch_views(self):
+        """zero-copy views over ALL frame slots: aux [F,8,H,W], noisy [F,H,W,4], image [F,H,W,4]"""
+        self.select_frame(0)
+        F, H, W = self.frames, self.height, self.width
+        return (_DevArray(self.aux_ptr, (F, AUX_CHANNELS, H, W), self), _DevArray(self.noisy_ptr, (F, H, W, 4), self),
+                _DevArray(self.image_ptr, (F, H, W, 4), self))
+
     def set_kernel(self, kernel):
         check(lib().rto_ctx_set_kernel(self._h, int(kernel)))
 
     def timer(self):
         return self._timer
+
+    def set_tuning(self, key, value):
+        """performance knobs ("variant", "strip_rows"); results never change"""
+        check(lib().rto_ctx_set_tuning(self._h, key.encode("ascii"), int(value)))
 
     def enable_stats(self, on=True):
         """Work counters for the roofline's algorithmic byte count (never in a timed run)."""
@@ -357,6 +372,19 @@ def launch_renderer(tree, cam, options, ctx, stream=None, offscreen=True):
     check(lib().rto_launch_renderer(tree._h, C.byref(cc), C.byref(co), ctx._h, _stream_ptr(stream)))
 
 
+def launch_renderer_batch(tree, cams, options, ctx, stream=None, rng_jumps=None):
+    """n frames in one launch of the persistent ray-queue kernel (rto_launch_renderer_batch):
+    cams[f] -> frame slot f, RNG = ctx.rng advanced by rng_jumps[f] (default f) jumps of 2^32.
+    Bit-identical to the reference's frame loop `launch_renderer(...); ctx.rng.advance()`."""
+    n = len(cams)
+    arr = (CCamera * n)(*[c.to_c() for c in cams])
+    jumps = None
+    if rng_jumps is not None:
+        jumps = (C.c_int64 * n)(*[int(j) for j in rng_jumps])
+    co = options.to_c()
+    check(lib().rto_launch_renderer_batch(tree._h, arr, jumps, n, C.byref(co), ctx._h, _stream_ptr(stream)))
+
+
 def _dev_ptr(t):
     if isinstance(t, int):
         return C.c_void_p(t)
@@ -375,5 +403,6 @@ def filtering(stream, weight_map, guidance_map, img_in, img_out):
         if hasattr(t, "is_contiguous") and not t.is_contiguous():
             raise RtoError(-1, "weight_map / guidance_map must be contiguous")  # CHECK_CONTIGUOUS
     L, H, W = (int(s) for s in guidance_map.shape[-3:])
-    check(lib().rto_filtering(_stream_ptr(stream), _dev_ptr(weight_map), _dev_ptr(guidance_map), L, H, W,
-                              _dev_ptr(img_in), _dev_ptr(img_out)))
+    n = int(guidance_map.shape[0]) if len(guidance_map.shape) == 4 else 1  # [n,L,H,W]: n images per launch
+    check(lib().rto_filtering_batch(_stream_ptr(stream), _dev_ptr(weight_map), _dev_ptr(guidance_map), L, H, W, n,
+                                    _dev_ptr(img_in), _dev_ptr(img_out)))

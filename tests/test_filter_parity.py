@@ -55,3 +55,19 @@ def test_filter_rejects_bad_levels():
     with pytest.raises(R.RtoError) as e:
         R.filtering(None, t, t, img, torch.zeros_like(img))
     assert "Kernel size == 15 not supported" in str(e.value)
+
+
+def test_filter_batch_bit_exact():
+    L, H, W, n = 4, 40, 56, 3
+    dev = torch.device("cuda:0")
+    ws, gs, ns, refs = [], [], [], []
+    for i in range(n):
+        w, g, noisy = _inputs(L, H, W, seed=50 + i)
+        ws.append(w); gs.append(g); ns.append(noisy)
+        refs.append(orc.filter_levels(w, g, noisy))
+    tw, tg, tn = (torch.from_numpy(np.stack(a)).to(dev) for a in (ws, gs, ns))
+    out = torch.empty((n, H, W, 4), device=dev)
+    R.filtering(None, tw, tg, tn, out)
+    torch.cuda.synchronize()
+    for i in range(n):
+        assert_bits_equal(out[i].cpu().numpy(), refs[i], "image %d" % i)

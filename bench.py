@@ -5,17 +5,23 @@
 
 A "step" is one frame of config C2: batched-regular-tracking render (800x800, SPP 6) + GuidanceNet
 (PyTorch-ROCm) + guided filter, i.e. what one iteration of the reference's timed loop does
-(main_headless.cpp:485-543).  Inputs are synthetic (no dataset exists on either machine): a seeded
-lego-like SH16 PlenOctree of ~2.5 M nodes, a 200-pose blender orbit, GuidanceNet(8,32,5,2,4) with
-seeded default init folded to the compact fp16 network.  Everything is resident in HBM before the
-timed region.  Frames shard across ranks (pose i -> rank i mod N, RNG jump-ahead per pose so every
-image is bit-identical to the 1-GPU run); no data-path collective exists or is invented -- the
-only collectives are the barrier and the max-reduction of the elapsed time.
+(main_headless.cpp:485-543).  Frames are issued in groups of --batch poses (default 8): one launch
+of the persistent ray-queue traversal kernel + one shading launch, one batched GuidanceNet forward,
+one batched filter launch per group -- a frame alone cannot fill 256 CUs (DESIGN.md "Batching").
+Every image is bit-identical to rendering the poses one by one (tests/test_render_parity.py).
+
+Inputs are synthetic (no dataset exists on either machine): a seeded lego-like SH16 PlenOctree of
+~2.1 M nodes, a 200-pose blender orbit, GuidanceNet(8,32,5,2,4) with seeded default init folded to
+the compact fp16 network.  Everything is resident in HBM before the timed region.  Frames shard
+across ranks (pose i -> rank i mod N, RNG jump-ahead per pose so every image equals the 1-GPU run);
+no data-path collective exists or is invented -- the only collectives are the barrier and the
+max-reduction of the elapsed time.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- traversal kernel: ALGORITHMIC bytes (SURVEY.md 8d formula, units counted by the
-                  kernel's counting instantiation in an untimed pass over the same frames) /
-                  average launch duration (HIP events on the launch stream), against 8 TB/s HBM.
+  roofline     -- traversal kernel (render_persist): ALGORITHMIC bytes (SURVEY.md 8d formula; the
+                  units are counted by the single-frame kernel's counting instantiation in an
+                  untimed pass over the same frames) / average launch duration (HIP events on the
+                  launch stream, recorded around that kernel inside librto), against 8 TB/s HBM.
   cpu_baseline -- the CPU oracle (oracle/, kind "port": the reference has no CPU renderer) on a
                   bounded sample of the same frames, all host cores.
 """
@@ -41,7 +47,8 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=24)
+    ap.add_argument("--batch", type=int, default=8, help="frames per launch group (1..8)")
     ap.add_argument("--size", type=int, default=800)
     ap.add_argument("--spp", type=int, default=6)
     ap.add_argument("--basis", type=int, default=16, help="SH basis per channel (16 = the NeRF-synthetic PlenOctrees)")
@@ -49,6 +56,7 @@ def parse_args():
     ap.add_argument("--shell", type=float, default=2.5)
     ap.add_argument("--no-denoise", action="store_true", help="config C5: raw SPP render only")
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores)")
     ap.add_argument("--tree", default="", help="render this tree.npz instead of the synthetic one")
     return ap.parse_args()
 
@@ -87,6 +95,7 @@ def main():
 
     # ---------------- inputs (untimed) ----------------
     W = H = args.size
+    B = max(1, min(8, args.batch))
     tree_host = None
     if args.tree:
         path = args.tree
@@ -102,59 +111,67 @@ def main():
     tree = R.N3Tree(path, device=local_rank)  # the reference's own input path: tree.npz -> device
     poses = synth.orbit_poses(200)
     fx = synth.blender_focal(W)
-    cam = R.Camera(W, H, fx, fx)
-    ctx = R.RenderContext(W, H, device=local_rank)
+    cams = []
+    for p in poses:
+        c = R.Camera(W, H, fx, fx)
+        c.set_c2w(p)
+        cams.append(c)
+    ctx = R.RenderContext(W, H, device=local_rank, frames=B)
     denoise = not args.no_denoise
     opt = R.RenderOptions(spp=args.spp, denoise=denoise)
-    dn = None
+    net = full = None
     if denoise:
         torch.manual_seed(0)
         full = denoiser.GuidanceNet(8, 32, 5, 2, 4)
-        net = denoiser.GuidanceNetCompact.from_full(full).half().to(dev)
-        dn = denoiser.Denoiser(net, device=local_rank)
+        net = denoiser.GuidanceNetCompact.from_full(full).half().to(dev).eval()
     stream = torch.cuda.current_stream(dev)
+    aux_v, noisy_v, image_v = ctx.batch_views()
+    aux_t = torch.as_tensor(aux_v, device=dev)  # zero-copy [B,8,H,W]
 
     def pose_of(step):  # global frame index of this rank's `step`-th frame
         return (step * world + rank) % len(poses)
 
-    def set_frame(step):
-        i = pose_of(step)
-        cam.set_c2w(poses[i])
+    def group(first_step, n, ev):
+        """n frames: traversal + shading, GuidanceNet, filter; all asynchronous on `stream`, no host
+        sync (the reference synchronises once per frame, render_context.hpp:179-188).  Frame i of the
+        reference run uses the RNG advanced (100 + i) times."""
+        idx = [pose_of(first_step + k) for k in range(n)]
         ctx.rng_seed()
-        ctx.rng_advance((WARM_FRAMES_REF + i) << 32)  # frame i of the reference run
-
-    aux_t = torch.as_tensor(ctx.aux_view(), device=dev) if denoise else None  # zero-copy [1,8,H,W]
-    net = dn.module if denoise else None
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-
-    def frame(step, ev):
-        """launch_renderer -> GuidanceNet -> filtering, all asynchronous on `stream`; no host sync
-        inside the loop (the reference synchronises once per frame, render_context.hpp:179-188)."""
-        set_frame(step)
         if ev:
             ev[0].record(stream)
-        R.launch_renderer(tree, cam, opt, ctx, stream)
+        R.launch_renderer_batch(tree, [cams[i] for i in idx], opt, ctx, stream,
+                                rng_jumps=[WARM_FRAMES_REF + i for i in idx])
         if ev:
             ev[1].record(stream)
         if denoise:
             with torch.no_grad():
-                wm, gm = net(aux_t)
-            wm, gm = wm.squeeze(0), gm.squeeze(0)
+                wm, gm = net(aux_t[:n])
             if ev:
                 ev[2].record(stream)
             R.filtering(stream, wm, gm, ctx.noisy_ptr, ctx.image_ptr)
             if ev:
                 ev[3].record(stream)
 
+    def run(n_frames, events):
+        s = 0
+        g = 0
+        while s < n_frames:
+            n = min(B, n_frames - s)
+            group(s, n, events[g] if events else None)
+            s += n
+            g += 1
+
+    n_groups = (args.steps + B - 1) // B
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_groups)]
+
     # ---------------- warm-up + timed region ----------------
-    for s in range(args.warmup):
-        frame(s, None)
+    run(args.warmup, None)
     torch.cuda.synchronize(dev)
+    ctx.kernel_timing(True)
     barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        frame(s, events[s])
+    run(args.steps, events)
     torch.cuda.synchronize(dev)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -162,7 +179,9 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # Timer::report formula (render_context.hpp:190-206) from the per-frame event pairs
+    kt = ctx.kernel_timing_read()
+    ctx.kernel_timing(False)
+    # Timer::report formula (render_context.hpp:190-206), per frame, from the per-group event pairs
     render_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
     torch_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps if denoise else 0.0
     filter_ms = sum(e[2].elapsed_time(e[3]) for e in events) / args.steps if denoise else 0.0
@@ -171,18 +190,24 @@ def main():
               "fps": 1000.0 / all_ms if all_ms > 0 else 0.0, "frames": args.steps}
 
     # ---------------- untimed: work units of the same frames -> algorithmic bytes ----------------
+    ctx.select_frame(0)
+    ctx.set_kernel(R.KERNEL_FAST)
     ctx.enable_stats(True)
     ctx.get_stats(reset=True)
-    for s in range(args.steps):
-        set_frame(s)
-        R.launch_renderer(tree, cam, opt, ctx, stream)
+    opt_nd = R.RenderOptions(spp=args.spp, denoise=False)
+    for s in range(args.steps):  # same poses, same RNG bases as the timed frames
+        i = pose_of(s)
+        ctx.rng_seed()
+        ctx.rng_advance((WARM_FRAMES_REF + i) << 32)
+        R.launch_renderer(tree, cams[i], opt_nd, ctx, stream)
     units = ctx.get_stats(reset=True)
     ctx.enable_stats(False)
     px = W * H
-    alg_bytes = (4 * units["levels"] + 2 * units["steps"] + 2 * (tree.data_dim - 1) * units["hit_leaves"]
-                 + 48 * px * args.steps) / args.steps
-    render_s = tstats["render_ms"] * 1e-3
-    achieved = alg_bytes / render_s / 1e9 if render_s > 0 else 0.0
+    alg_bytes_frame = (4 * units["levels"] + 2 * units["steps"] + 2 * (tree.data_dim - 1) * units["hit_leaves"]
+                       + 48 * px * args.steps) / args.steps
+    frames_per_launch = args.steps / max(kt["launches"], 1)
+    alg_bytes_launch = alg_bytes_frame * frames_per_launch
+    achieved = alg_bytes_launch / (kt["traverse_ms"] * 1e-3) / 1e9 if kt["traverse_ms"] > 0 else 0.0
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
@@ -207,28 +232,36 @@ def main():
         else:
             child, data, scale, offset, fmt = tree_host.child, tree_host.data, tree_host.scale, tree_host.offset, tree_host.data_format
         ht = orc.HostTree(child, data, scale, offset, fmt)
-        cores = os.cpu_count() or 1
+        cores = args.cpu_threads or (os.cpu_count() or 1)
         oopt = orc.default_options(spp=args.spp, denoise=int(denoise))
         cpu_net = denoiser.GuidanceNetCompact.from_full(full).float() if denoise else None
-        torch.set_num_threads(cores)
-        tc = 0.0
-        cpu_units = None
+        torch.set_num_threads(min(cores, 64))
+        t_render = t_net = t_filter = 0.0
+        cpu_steps = 0
         for s in range(args.cpu_frames):
             i = pose_of(s)
             ocam = orc.camera(W, H, fx, fx, np.ascontiguousarray(poses[i][:3, :4].T, np.float32).reshape(-1))
+            base = orc.rng(frame=WARM_FRAMES_REF + i)
             t1 = time.perf_counter()
-            aux, rgba, st = orc.render_frame(ht, ocam, oopt, orc.rng(frame=WARM_FRAMES_REF + i), threads=cores)
+            aux, rgba, st = orc.render_frame(ht, ocam, oopt, base, threads=cores)
+            t2 = time.perf_counter()
             if denoise:
                 with torch.no_grad():
                     wm, gm = cpu_net(torch.from_numpy(aux)[None])
+                t3 = time.perf_counter()
                 orc.filter_levels(wm[0].numpy(), gm[0].numpy(), rgba, threads=cores)
-            tc += time.perf_counter() - t1
-            cpu_units = st if cpu_units is None else {k: cpu_units[k] + st[k] for k in st}
+                t4 = time.perf_counter()
+                t_net += t3 - t2
+                t_filter += t4 - t3
+            t_render += t2 - t1
+            cpu_steps += st["steps"]
+        tc = t_render + t_net + t_filter
         cpu = {"value": args.cpu_frames / tc, "unit": "frames/s", "cores": cores, "kind": "port",
                "sample": "%d of the same %dx%d SPP%d frames (poses 0..%d)%s, CPU oracle with OpenMP over rows"
                          % (args.cpu_frames, W, H, args.spp, args.cpu_frames - 1,
                             " + fp32 PyTorch-CPU GuidanceNet + oracle filter" if denoise else ""),
-               "steps_per_frame": cpu_units["steps"] / args.cpu_frames}
+               "render_s_per_frame": t_render / args.cpu_frames, "net_s_per_frame": t_net / args.cpu_frames,
+               "filter_s_per_frame": t_filter / args.cpu_frames, "steps_per_frame": cpu_steps / args.cpu_frames}
 
     total_frames = args.steps * world
     out = {
@@ -245,20 +278,22 @@ def main():
         "dtype": "f32" if not denoise else "f32 (traversal, filter) + f16 (GuidanceNet conv)",
         "data": "synthetic",
         "config": {
-            "workload": "configs[1]: lego-like synthetic PlenOctree %s (%d nodes, depth %d), %dx%d SPP=%d%s, 1 frame per step, frames sharded pose i -> rank i mod N"
+            "workload": "configs[1]: lego-like synthetic PlenOctree %s (%d nodes, depth %d), %dx%d SPP=%d%s, 1 frame per step issued in groups of %d, frames sharded pose i -> rank i mod N"
                         % (tree.data_format, tree.capacity, tree.max_depth, W, H, args.spp,
-                           " + GuidanceNet(8,32,5,2,4) denoise" if denoise else " raw (no denoise)"),
+                           " + GuidanceNet(8,32,5,2,4) denoise" if denoise else " raw (no denoise)", B),
             "tree_nodes": int(tree.capacity), "tree_device_mb": tree.device_bytes / 1e6,
-            "parallelism": "frames x%d" % world,
+            "frames_per_launch": B, "parallelism": "frames x%d" % world,
         },
-        "reference_timer": {  # Timer::report formula (render_context.hpp:190-206), rank 0
+        "reference_timer": {  # Timer::report formula (render_context.hpp:190-206), rank 0, per frame
             "render_ms": tstats["render_ms"], "torch_ms": tstats["torch_ms"], "filter_ms": tstats["filter_ms"],
             "fps": tstats["fps"], "frames": tstats["frames"]},
         "roofline": {
-            "kernel": "render_fast<%d>" % args.spp, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "kernel": "render_persist<%d>" % args.spp, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": tstats["render_ms"],
-            "units_per_launch": {k: v / args.steps for k, v in units.items()},
+            "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": kt["traverse_ms"],
+            "launches": kt["launches"], "frames_per_launch": frames_per_launch,
+            "shade_kernel_avg_launch_ms": kt["shade_ms"],
+            "units_per_frame": {k: v / args.steps for k, v in units.items()},
         },
         "cpu_baseline": cpu,
     }

@@ -159,6 +159,12 @@ int rto_ctx_set_kernel(rto_ctx* c, int kernel);
 /* Performance knobs of the fast kernel; never change results.  key: "variant" (bit 0 = node cache,
  * bit 1 = priority ramp), "strip_rows" (tile rows per XCD strip, >= 1). */
 int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value);
+/* Per-kernel HIP-event timing of the batched path: when enabled, every rto_launch_renderer_batch
+ * records events before the traversal kernel, between it and the shading kernel, and after (on the
+ * launch stream; up to 256 launches between reads).  _read synchronises on the recorded events and
+ * returns the mean milliseconds per launch of each kernel, then resets the ring. */
+int rto_ctx_kernel_timing(rto_ctx* c, int enable);
+int rto_ctx_kernel_timing_read(rto_ctx* c, float* traverse_ms, float* shade_ms, int* launches);
 /* Work counters for the roofline's ALGORITHMIC byte count.  When enabled, the fast
  * kernel's counting instantiation runs instead of the timed one and accumulates, over the launches
  * since the last rto_ctx_get_stats(reset=1): {rays, rays_in_box, march steps, descent levels a

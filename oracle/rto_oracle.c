@@ -172,8 +172,39 @@ float orc_det_expf(float x) {
     return (float)(p * sc.d);
 }
 
+/*
+ * Deterministic fp32-only expf for the filter's softmax taps (164 per pixel at L = 4): the same
+ * structure in float arithmetic -- k = rint(x log2 e) by the 1.5*2^23 trick, two-term Cody-Waite
+ * reduction, degree-7 Taylor, exponent-bit scaling.  Max error 1 ulp on [-87.3, 88.7] (measured in
+ * tests/test_oracle_kat.py); results below FLT_MIN flush to 0.  The reference's __expf
+ * (filtering.cu:191) is ex2.approx(x*log2e), ~2 ulp: this definition is at least as accurate.
+ */
+float orc_fexp(float x) {
+    if (x != x) return x;
+    if (x > 88.72283935546875f) return INFINITY;
+    if (x < -87.33654022216797f) return 0.0f;
+    const float t = x * 1.44269502162933349609375f;
+    const float kf = (t + 12582912.0f) - 12582912.0f;
+    float r = x - kf * 0.693145751953125f;
+    r = r - kf * 1.42860676533018704e-06f;
+    float p = 1.0f / 5040.0f;
+    p = p * r + 1.0f / 720.0f;
+    p = p * r + 1.0f / 120.0f;
+    p = p * r + 1.0f / 24.0f;
+    p = p * r + 1.0f / 6.0f;
+    p = p * r + 0.5f;
+    p = p * r + 1.0f;
+    p = p * r + 1.0f;
+    int ki = (int)kf;
+    if (ki > 127) { ki = 127; p = p * 2.0f; } /* 2^128 has no fp32 encoding */
+    union { uint32_t u; float f; } sc;
+    sc.u = (uint32_t)(ki + 127) << 23;
+    return p * sc.f;
+}
+
 static inline float m_logf(float x) { return g_math_mode == ORC_MATH_DET ? orc_det_logf(x) : logf(x); }
 static inline float m_expf(float x) { return g_math_mode == ORC_MATH_DET ? orc_det_expf(x) : expf(x); }
+static inline float m_fexp(float x) { return g_math_mode == ORC_MATH_DET ? orc_fexp(x) : expf(x); }
 
 /* CUDA min/max on floats (rt_core.cuh:33-34,48; common.hpp VOLREND_MIN/MAX): NaN-free here */
 static inline float f_min(float a, float b) { return a < b ? a : b; }
@@ -573,7 +604,7 @@ int orc_filter(int L, int H, int W, const float* weight, const float* guidance, 
                         int qy = iy + dy, qx = ix + dx;
                         int in = (qy >= 0 && qy < H && qx >= 0 && qx < W);
                         float kv = in ? g[(int64_t)qy * W + qx] : -FLT_MAX;
-                        float k = m_expf(kv - max_val);
+                        float k = m_fexp(kv - max_val);
                         kernel_sum += k;
                         const float* t = noisy + ((int64_t)qy * W + qx) * 4;
                         float tr = in ? t[0] : 0.f, tg = in ? t[1] : 0.f, tb = in ? t[2] : 0.f;

@@ -100,6 +100,7 @@ void orc_pcg32_advance(orc_pcg32* r, int64_t delta);
 /* math */
 float orc_det_logf(float x);
 float orc_det_expf(float x);
+float orc_fexp(float x); /* fp32-only exp used by the filter */
 float orc_half2float(uint16_t h);
 
 /* pieces (exposed for known-answer tests) */

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) filter_fused(const float* __restrict__ we
         for (int dy = -S; dy <= S; ++dy)
             for (int dx = -S; dx <= S; ++dx) {
                 const int e = (cy + dy) * TW + cx + dx;
-                const float k = det_expf(g[e] - max_val);
+                const float k = fexp_f32(g[e] - max_val);
                 kernel_sum += k;
                 const float4 t = s_rgb[e];
                 r += t.x * k;

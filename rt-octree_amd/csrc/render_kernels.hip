@@ -613,89 +613,144 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
 //   * the end-of-queue drain happens once per batch instead of once per frame.
 // Per-ray arithmetic is exactly render_fast's; results are bit-identical.
 
-constexpr int kRefillMin = 24;  // idle lanes that trigger a retire + refill round
-
-// the per-ray state that survives between march steps
-template <int SPP>
+// the per-ray state that survives between march steps (thresholds live in LDS, hits go straight
+// to the hand-off buffer)
 struct RayState {
-    float cen[3], dir[3], invdir[3];
-    float delta_scale, t, tmax, src;
-    float dst[SPP + 1];
-    uint32_t hits[SPP];
+    float cen[3], dir[3], invdir[3], addv[3];  // addv[i] = invdir[i] > 0 ? invdir[i] : 0
+    float delta_scale, t, tmax, src, cur;      // cur = next threshold to cross (dst[spp])
     uint32_t spp, sh_nums;
     uint32_t pix, piy, piz;
     int prev_lvl;
+    uint32_t hoff;  // index of this pixel's first hit entry in the hand-off buffer
 };
 
-// queue index -> (frame, x, y); tiles row-major, 64 rays per 8x8 tile; returns false for padding
-RTO_DEV bool ray_pixel(uint32_t r, uint32_t rays_per_frame, int tiles8_x, int width, int height, int& frame, int& x,
-                       int& y) {
+// queue index -> (frame, x, y); 64 rays per 8x8 tile, tiles in `tile_order` (ty << 16 | tx per
+// queue position: centre-out, so a frame's queue ends on its cheap border tiles) or row-major when
+// no table is given; returns false for padding
+RTO_DEV bool ray_pixel(uint32_t r, uint32_t rays_per_frame, int tiles8_x, int width, int height,
+                       const uint32_t* __restrict__ tile_order, int& frame, int& x, int& y) {
     frame = (int)(r / rays_per_frame);
     const uint32_t q = r - (uint32_t)frame * rays_per_frame;
     const int tile = (int)(q >> 6), l = (int)(q & 63u);
-    const int ty = tile / tiles8_x, tx = tile - ty * tiles8_x;
+    int ty, tx;
+    if (tile_order) {
+        const uint32_t code = tile_order[tile];
+        ty = (int)(code >> 16);
+        tx = (int)(code & 0xffffu);
+    } else {
+        ty = tile / tiles8_x;
+        tx = tile - ty * tiles8_x;
+    }
     x = tx * 8 + (l & 7);
     y = ty * 8 + (l >> 3);
     return x < width && y < height;
 }
 
+// sample_dst (rt_core.cuh:67-193) for every pixel of the batch, at full lane utilisation: the RNG
+// jump (volrend.cu:157), SPP draws of -log(1-u) and their sort.  The thresholds go to the hand-off
+// buffer slots [i][pixel] that the traversal later overwrites with the pixel's hit list.
 template <int SPP>
-__global__ void __launch_bounds__(256) render_persist(const TreeDev tree, const OptDev opt, const FrameBatch fb,
-                                                       const PcgJumpEntry* __restrict__ jump,
-                                                       unsigned long long* __restrict__ queue) {
+__global__ void __launch_bounds__(256) sample_kernel(const FrameBatch fb, const PcgJumpEntry* __restrict__ jump) {
+    const uint32_t SIZE = (uint32_t)fb.width * (uint32_t)fb.height;
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= SIZE) return;
+    const FrameDesc& fd = fb.f[blockIdx.y];
+    Pcg32 rng;
+    rng.state = fd.rng_state;
+    rng.inc = fd.rng_inc;
+    pcg_advance_tab(rng, idx * (uint32_t)SPP, jump);
+    float dst[SPP];
+#pragma unroll
+    for (int n = 0; n < SPP; ++n) {
+        float tv = -det_logf(1.0f - pcg_next_float(rng));
+#pragma unroll
+        for (int i = 0; i < n; ++i) {  // static-index insertion: same sorted array
+            const float lo = f_min(dst[i], tv), hi = f_max(dst[i], tv);
+            dst[i] = lo;
+            tv = hi;
+        }
+        dst[n] = tv;
+    }
+    uint32_t* out = fd.hits + idx;
+#pragma unroll
+    for (int i = 0; i < SPP; ++i) out[(uint32_t)i * SIZE] = __float_as_uint(dst[i]);
+}
+
+// REFILL = idle lanes that trigger a retire + refill round
+template <int SPP, int REFILL, int WPS>
+__global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, const OptDev opt, const FrameBatch fb,
+                                                       unsigned long long* __restrict__ queue,
+                                                       uint32_t* __restrict__ hits, const uint32_t chunk) {
     // queue[0]: next ray of the batch; queue[1]: waves that have left (the last one re-arms both)
-    extern __shared__ uint32_t s_mem[];  // [max_depth+1][256] ancestor stack, then the frame table
+    // LDS: [max_depth+1][256] ancestor stack | [SPP+1][256] sorted thresholds | frame table
+    extern __shared__ uint32_t s_mem[];
     const int tid = threadIdx.x;
     uint32_t* stack = s_mem + tid;
-    FrameDesc* s_frames = reinterpret_cast<FrameDesc*>(s_mem + (size_t)(tree.max_depth + 1) * 256);
+    float* s_dst = reinterpret_cast<float*>(s_mem + (size_t)(tree.max_depth + 1) * 256) + tid;
+    FrameDesc* s_frames = reinterpret_cast<FrameDesc*>(s_mem + (size_t)(tree.max_depth + 1 + SPP + 1) * 256);
 #pragma unroll
     for (int f = 0; f < kMaxBatch; ++f)  // static indices: the kernarg struct is never address-taken
         if (tid == f) s_frames[f] = fb.f[f];
     __syncthreads();
 
     const int W = fb.width, H = fb.height;
-    const int64_t SIZE = (int64_t)W * H;
+    const uint32_t SIZE = (uint32_t)W * (uint32_t)H;
     const int tiles8_x = (W + 7) >> 3, tiles8_y = (H + 7) >> 3;
     const uint32_t rays_per_frame = (uint32_t)(tiles8_x * tiles8_y) * 64u;
     const uint32_t total = rays_per_frame * (uint32_t)fb.n;
 
-    RayState<SPP> rs;
-    bool active = false;         // marching
-    uint32_t ray = 0xffffffffu;  // queue index of the ray this lane owns (retire pending when !active)
-    bool drained = false;        // queue exhausted (wave-uniform)
+    // Loop-invariant scalars pinned in SGPRs: under the 8-waves/SIMD register budget hipcc
+    // otherwise re-loads them from the kernarg segment inside the descent loop (an s_load +
+    // lgkmcnt(0) round trip per level).
+    const uint32_t* __restrict__ nodew = tree.nodew;
+    const uint32_t* __restrict__ tile_order = fb.tile_order;
+    float step_size = opt.step_size, sigma_thresh = opt.sigma_thresh;
+    asm volatile("" : "+s"(nodew), "+s"(step_size), "+s"(sigma_thresh));
+
+    RayState rs;
+    bool active = false;    // marching
+    bool pending = false;   // finished, hit list not yet terminated
+    bool drained = false;   // queue exhausted (wave-uniform)
+    const uint32_t kChunk = chunk;           // rays per global dequeue (a multiple of the 64-ray tile)
+    uint32_t res_next = 0, res_end = 0;      // the wave's private reservoir (wave-uniform)
 
     for (;;) {
         const unsigned long long act_mask = __ballot(active);
-        if (64 - __popcll(act_mask) >= kRefillMin || act_mask == 0ULL) {
+        if (64 - __popcll(act_mask) >= REFILL || act_mask == 0ULL) {
             for (;;) {
-                // ---- retire: hand the finished rays' hit lists to the shading kernel
-                if (!active && ray != 0xffffffffu) {
-                    int frame, x, y;
-                    ray_pixel(ray, rays_per_frame, tiles8_x, W, H, frame, x, y);
-                    uint32_t* hp = s_frames[frame].hits + (y * W + x);
-#pragma unroll
-                    for (int i = 0; i < SPP; ++i)
-                        if (i <= (int)rs.sh_nums) hp[(int64_t)i * SIZE] = (i < (int)rs.sh_nums) ? rs.hits[i] : kNoHit;
-                    ray = 0xffffffffu;
+                // ---- retire: terminate the hit list of every ray that has finished
+                if (pending && !active) {
+                    if (rs.sh_nums < (uint32_t)SPP) hits[rs.hoff + rs.sh_nums * SIZE] = kNoHit;
+                    pending = false;
                 }
                 if (drained) break;
                 // ---- refill: hand the next queue entries to the idle lanes (ballot + prefix sum)
                 const unsigned long long need = __ballot(!active);
                 const int n_need = __popcll(need);
-                if (n_need < kRefillMin) break;
-                unsigned long long base = 0;
-                if ((tid & 63) == 0) base = atomicAdd(queue, (unsigned long long)n_need);
-                const uint32_t base32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
-                if (base32 >= total) {  // the counter never exceeds total + 64 * waves: fits 32 bits
-                    drained = true;
-                    break;
+                if (n_need < REFILL) break;
+                // The wave draws rays from a private reservoir [res_next, res_end) and tops it up from
+                // the global queue kChunk rays (kChunk/64 tiles) at a time: one device-scope atomic per
+                // kChunk rays instead of one per refill (a single counter sustains only ~90 dequeues/us).
+                if (res_next == res_end) {
+                    unsigned long long base = 0;
+                    if ((tid & 63) == 0) base = atomicAdd(queue, (unsigned long long)kChunk);
+                    const uint32_t base32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+                    if (base32 >= total) {  // the counter never exceeds total + kChunk * waves: fits 32 bits
+                        drained = true;
+                        break;
+                    }
+                    res_next = base32;
+                    res_end = base32 + kChunk < total ? base32 + kChunk : total;
                 }
+                const uint32_t take = (uint32_t)n_need < res_end - res_next ? (uint32_t)n_need : res_end - res_next;
+                const uint32_t first = res_next;
+                res_next += take;
                 if (!active) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32),
                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-                    const uint32_t r = base32 + rank;
+                    const uint32_t r = first + rank;
                     int frame, x, y;
-                    if (r < total && ray_pixel(r, rays_per_frame, tiles8_x, W, H, frame, x, y)) {
+                    if (rank < take && ray_pixel(r, rays_per_frame, tiles8_x, W, H, tile_order, frame, x, y)) {
                         const FrameDesc& fd = s_frames[frame];
                         CamDev cam;
                         cam.width = W;
@@ -707,27 +762,19 @@ __global__ void __launch_bounds__(256) render_persist(const TreeDev tree, const 
                         float vdir[3];
                         ray_setup(x, y, cam, tree, rs.dir, vdir, rs.cen);
                         float tmin;
-                        ray = r;  // a ray that misses the box stays "finished": next retire stores background
+                        rs.hoff = (uint32_t)frame * (uint32_t)SPP * SIZE + (uint32_t)(y * W + x);
                         rs.sh_nums = 0;
+                        pending = true;  // a ray that misses the box just gets its list terminated
                         if (ray_enter(tree, opt, rs.dir, rs.cen, 1e9f, rs.invdir, rs.delta_scale, tmin, rs.tmax)) {
-                            Pcg32 rng;
-                            rng.state = fd.rng_state;
-                            rng.inc = fd.rng_inc;
-                            pcg_advance_tab(rng, (uint32_t)((y * W + x) * SPP), jump);
+                            // sorted thresholds of this pixel (sample_kernel left them in the hand-off
+                            // buffer, where the ray's hit list will overwrite them)
+                            const uint32_t* tp = hits + rs.hoff;
+                            rs.cur = __uint_as_float(tp[0]);
 #pragma unroll
-                            for (int n = 0; n < SPP; ++n) {
-                                float tv = -det_logf(1.0f - pcg_next_float(rng));
+                            for (int i = 1; i < SPP; ++i) s_dst[i * 256] = __uint_as_float(tp[(uint32_t)i * SIZE]);
+                            s_dst[SPP * 256] = 3.402823466e+38f;
 #pragma unroll
-                                for (int i = 0; i < n; ++i) {
-                                    const float lo = f_min(rs.dst[i], tv), hi = f_max(rs.dst[i], tv);
-                                    rs.dst[i] = lo;
-                                    tv = hi;
-                                }
-                                rs.dst[n] = tv;
-                            }
-                            rs.dst[SPP] = 3.402823466e+38f;
-#pragma unroll
-                            for (int i = 0; i < SPP; ++i) rs.hits[i] = 0;
+                            for (int i = 0; i < 3; ++i) rs.addv[i] = rs.invdir[i] > 0.f ? rs.invdir[i] : 0.f;
                             rs.spp = 0;
                             rs.src = 0;
                             rs.t = tmin;
@@ -744,7 +791,7 @@ __global__ void __launch_bounds__(256) render_persist(const TreeDev tree, const 
             }
         }
 
-        // ---- one march step for every active lane (rt_core.cuh:241-270; same code as render_fast)
+        // ---- one march step for every active lane (rt_core.cuh:241-270)
         if (active) {
             float pos[3] = {rs.cen[0] + rs.t * rs.dir[0], rs.cen[1] + rs.t * rs.dir[1], rs.cen[2] + rs.t * rs.dir[2]};
             pos[0] = f_max(f_min(pos[0], 1.f - 1e-6f), 0.f);
@@ -759,11 +806,12 @@ __global__ void __launch_bounds__(256) render_persist(const TreeDev tree, const 
             uint32_t node = lvl ? stack[lvl * 256] : 0u;
             uint32_t w, slot;
             for (;;) {
-                const int sh = 23 - lvl;
-                const uint32_t ci = (((ix >> sh) & 1u) << 2) | (((iy >> sh) & 1u) << 1) | ((iz >> sh) & 1u);
-                slot = node * 8u + ci;
-                w = tree.nodew[slot];
-                if (nodew_is_leaf(w)) break;
+                const uint32_t sh = 23u - (uint32_t)lvl;
+                const uint32_t ci = (__builtin_amdgcn_ubfe(ix, sh, 1u) << 2) | (__builtin_amdgcn_ubfe(iy, sh, 1u) << 1) |
+                                    __builtin_amdgcn_ubfe(iz, sh, 1u);
+                slot = (node << 3) | ci;
+                w = nodew[slot];
+                if ((int32_t)w < -(1 << 30)) break;  // leaf tag 0b10: below every encodable offset
                 node += w;
                 ++lvl;
                 stack[lvl * 256] = node;
@@ -774,33 +822,30 @@ __global__ void __launch_bounds__(256) render_persist(const TreeDev tree, const 
             rs.prev_lvl = lvl;
             const float cube_sz = __uint_as_float((uint32_t)(128 + lvl) << 23);
             const float inv_cube = __uint_as_float((uint32_t)(126 - lvl) << 23);
-            float loc[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const float s = pos[i] * cube_sz;
-                loc[i] = s - floorf(s);
-            }
-            const float t_subcube = dda_unit(loc, rs.invdir) * inv_cube;
-            const float delta_t = t_subcube + opt.step_size;
-            const float sigma = half_bits_to_float((uint16_t)(w & 0xffffu));
+            // _dda_unit (rt_core.cuh:38-51) on the leaf-local point frac(pos * cube_sz):
+            // max(t1, t1 + invdir) is t1 + invdir for invdir > 0 and t1 otherwise, i.e. t1 + addv
+            const float a0 = -__builtin_amdgcn_fractf(pos[0] * cube_sz) * rs.invdir[0] + rs.addv[0];
+            const float a1 = -__builtin_amdgcn_fractf(pos[1] * cube_sz) * rs.invdir[1] + rs.addv[1];
+            const float a2 = -__builtin_amdgcn_fractf(pos[2] * cube_sz) * rs.invdir[2] + rs.addv[2];
+            const float tm = __builtin_fminf(1e4f, __builtin_fminf(__builtin_fminf(a0, a1), a2));
+            const float delta_t = tm * inv_cube + step_size;
+            const float sigma = half_bits_to_float((uint16_t)w);
             bool done = false;
-            if (sigma > opt.sigma_thresh) {
+            if (sigma > sigma_thresh) {
                 const float delta = delta_t * rs.delta_scale * sigma;
-                if (rs.src + delta >= rs.dst[0]) {
+                const float reach = rs.src + delta;
+                if (reach >= rs.cur) {
                     uint32_t cnt = 0;
                     do {
                         ++cnt;
                         ++rs.spp;
-#pragma unroll
-                        for (int i = 0; i < SPP; ++i) rs.dst[i] = rs.dst[i + 1];
-                    } while (rs.src + delta >= rs.dst[0]);
-                    const uint32_t h = hit_pack(slot, cnt);
-#pragma unroll
-                    for (int i = 0; i < SPP; ++i) rs.hits[i] = (i == (int)rs.sh_nums) ? h : rs.hits[i];
+                        rs.cur = s_dst[rs.spp * 256];
+                    } while (reach >= rs.cur);
+                    hits[rs.hoff + rs.sh_nums * SIZE] = hit_pack(slot, cnt);
                     ++rs.sh_nums;
-                    done = rs.spp == SPP;
+                    done = rs.spp == (uint32_t)SPP;
                 }
-                rs.src += delta;
+                rs.src = reach;
             }
             rs.t += delta_t;
             active = !done && rs.t < rs.tmax;
@@ -958,39 +1003,77 @@ hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev&
     }
 }
 
-template <int SPP>
-static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
-                                   const PcgJumpEntry* jump, unsigned long long* queue, int num_cus,
-                                   hipStream_t stream) {
-    const size_t lds = (size_t)(tree.max_depth + 1) * 256 * sizeof(uint32_t) + sizeof(FrameDesc) * kMaxBatch;
-    static int blocks_per_cu = 0;  // per SPP instantiation
+template <int SPP, int REFILL, int WPS>
+static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
+                                    const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
+                                    int chunk_override, hipEvent_t* ev, hipStream_t stream) {
+    const size_t lds = (size_t)(tree.max_depth + 1 + SPP + 1) * 256 * sizeof(uint32_t) + sizeof(FrameDesc) * kMaxBatch;
+    static int blocks_per_cu = 0;  // per instantiation
     if (blocks_per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_persist<SPP>, 256, lds) != hipSuccess || nb < 1) nb = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_persist<SPP, REFILL, WPS>, 256, lds) != hipSuccess || nb < 1)
+            nb = 2;
         blocks_per_cu = nb > 8 ? 8 : nb;
     }
     const int tiles = ((fb.width + 7) / 8) * ((fb.height + 7) / 8) * fb.n;
     int grid = num_cus * blocks_per_cu;
     if (grid > (tiles + 3) / 4) grid = (tiles + 3) / 4;  // never more waves than 8x8 tiles
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(render_persist<SPP>, dim3(grid), dim3(256), lds, stream, tree, opt, fb, jump, queue);
-    if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
+    // dequeue granularity: big enough to keep the single counter far below its ~90 dequeues/us,
+    // small enough that every wave draws several times (a wave that draws twice while its
+    // neighbour draws three times is a 33 % imbalance)
+    const int64_t rays_per_wave = (int64_t)tiles * 64 / ((int64_t)grid * 4);
+    const uint32_t chunk = chunk_override > 0 ? (uint32_t)chunk_override
+                                              : (rays_per_wave >= 2048 ? 256u : rays_per_wave >= 512 ? 128u : 64u);
     const int64_t size = (int64_t)fb.width * fb.height;
+    hipLaunchKernelGGL(sample_kernel<SPP>, dim3((unsigned)((size + 255) / 256), fb.n), dim3(256), 0, stream, fb, jump);
+    if (ev) (void)hipEventRecord(ev[0], stream);
+    hipLaunchKernelGGL((render_persist<SPP, REFILL, WPS>), dim3(grid), dim3(256), lds, stream, tree, opt, fb, queue, hits, chunk);
+    if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
+    if (ev) (void)hipEventRecord(ev[1], stream);
     hipLaunchKernelGGL(shade_kernel<SPP>, dim3((unsigned)((size + 255) / 256), fb.n), dim3(256), 0, stream, tree, opt, fb);
+    if (ev) (void)hipEventRecord(ev[2], stream);
     return hipGetLastError();
 }
 
+template <int SPP>
+static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
+                                   const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
+                                   int refill, hipEvent_t* ev, hipStream_t stream) {
+    const int chunk_override = (refill / 1000) * 64;  // tuning: refill = 1000 * tiles_per_dequeue + threshold
+    refill %= 1000;
+    if (SPP == 6) {  // tuning instantiations only for the benchmark configuration
+#define RTO_B(R, O) return launch_batch_impl<SPP, R, O>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, ev, stream)
+        switch (refill) {
+            case 4: RTO_B(4, 8);
+            case 8: RTO_B(8, 8);
+            case 12: RTO_B(12, 8);
+            case 16: RTO_B(16, 8);
+            case 32: RTO_B(32, 8);
+            case 48: RTO_B(48, 8);
+            case 116: RTO_B(16, 6);
+            case 124: RTO_B(24, 6);
+            case 132: RTO_B(32, 6);
+            case 148: RTO_B(48, 6);
+            default: break;
+        }
+#undef RTO_B
+    }
+    return launch_batch_impl<SPP, 24, 8>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, ev, stream);
+}
+
 hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
-                               const PcgJumpEntry* jump, unsigned long long* queue, int num_cus, hipStream_t stream) {
+                               const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
+                               int refill, hipEvent_t* ev, hipStream_t stream) {
     switch (spp) {
-        case 1: return launch_batch_spp<1>(tree, opt, fb, jump, queue, num_cus, stream);
-        case 2: return launch_batch_spp<2>(tree, opt, fb, jump, queue, num_cus, stream);
-        case 3: return launch_batch_spp<3>(tree, opt, fb, jump, queue, num_cus, stream);
-        case 4: return launch_batch_spp<4>(tree, opt, fb, jump, queue, num_cus, stream);
-        case 6: return launch_batch_spp<6>(tree, opt, fb, jump, queue, num_cus, stream);
-        case 8: return launch_batch_spp<8>(tree, opt, fb, jump, queue, num_cus, stream);
-        case 16: return launch_batch_spp<16>(tree, opt, fb, jump, queue, num_cus, stream);
-        case 32: return launch_batch_spp<32>(tree, opt, fb, jump, queue, num_cus, stream);
+        case 1: return launch_batch_spp<1>(tree, opt, fb, jump, queue, hits, num_cus, refill, ev, stream);
+        case 2: return launch_batch_spp<2>(tree, opt, fb, jump, queue, hits, num_cus, refill, ev, stream);
+        case 3: return launch_batch_spp<3>(tree, opt, fb, jump, queue, hits, num_cus, refill, ev, stream);
+        case 4: return launch_batch_spp<4>(tree, opt, fb, jump, queue, hits, num_cus, refill, ev, stream);
+        case 6: return launch_batch_spp<6>(tree, opt, fb, jump, queue, hits, num_cus, refill, ev, stream);
+        case 8: return launch_batch_spp<8>(tree, opt, fb, jump, queue, hits, num_cus, refill, ev, stream);
+        case 16: return launch_batch_spp<16>(tree, opt, fb, jump, queue, hits, num_cus, refill, ev, stream);
+        case 32: return launch_batch_spp<32>(tree, opt, fb, jump, queue, hits, num_cus, refill, ev, stream);
         default: return hipErrorInvalidValue;
     }
 }

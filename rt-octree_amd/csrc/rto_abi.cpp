@@ -3,6 +3,7 @@
 // (render_kernels.hip, filter_kernels.hip).  There is no CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -17,6 +18,8 @@
 #include "rto_launch.h"
 
 namespace {
+
+constexpr int kKtRing = 256;
 
 thread_local std::string g_err;
 
@@ -72,8 +75,13 @@ struct rto_ctx {
     int sel = 0;     // slot the single-frame entry points and accessors refer to
     int num_cus = 256;
     unsigned long long* queue = nullptr;  // persistent-kernel ray queue {next, waves_done}
+    uint32_t* tile_order = nullptr;       // centre-out order of the 8x8 ray tiles (persistent kernel)
     uint32_t* hits = nullptr;             // [frames][hits_spp][H*W] traversal -> shading hand-off
     int hits_spp = 0;
+    // per-kernel event timing of the batched path (off by default)
+    bool kt_on = false;
+    std::vector<hipEvent_t> kt_ev;  // kKtRing triples
+    int kt_count = 0;               // launches recorded since the last read
     float* aux = nullptr;
     float* noisy = nullptr;
     float* image = nullptr;
@@ -85,6 +93,8 @@ struct rto_ctx {
     int kernel = RTO_KERNEL_AUTO;
     int strip_rows = 1;
     int variant = 0;
+    int refill = 24;
+    bool tile_order_on = true;
     bool stats_on = false;
     unsigned long long* stats = nullptr;  // device, 6 counters
     // Timer (render_context.hpp:122-213)
@@ -458,6 +468,30 @@ int rto_ctx_create_batch(int width, int height, int frames, int device, rto_ctx*
     (void)hipMemset(c->aux, 0, px * RTO_AUX_CHANNELS * sizeof(float));
     (void)hipMemset(c->noisy, 0, px * 4 * sizeof(float));
     (void)hipMemset(c->image, 0, px * 4 * sizeof(float));
+    {
+        // queue order of the 8x8 ray tiles: rings around the image centre, innermost first, each ring
+        // walked by angle -- the frame's long rays (the object) start early, its queue ends on cheap
+        // border tiles, and consecutive tiles stay neighbours
+        const int tx8 = (width + 7) / 8, ty8 = (height + 7) / 8;
+        std::vector<std::pair<double, uint32_t>> keyed;
+        keyed.reserve((size_t)tx8 * ty8);
+        const double cx = 0.5 * (tx8 - 1), cy = 0.5 * (ty8 - 1);
+        for (int ty = 0; ty < ty8; ++ty)
+            for (int tx = 0; tx < tx8; ++tx) {
+                const double dx = tx - cx, dy = ty - cy;
+                const double ring = std::floor(std::fmax(std::fabs(dx), std::fabs(dy)) + 0.5);
+                const double ang = std::atan2(dy, dx) + 3.14159265358979323846;  // [0, 2pi]
+                keyed.emplace_back(ring * 16.0 + ang, ((uint32_t)ty << 16) | (uint32_t)tx);
+            }
+        std::stable_sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        std::vector<uint32_t> order(keyed.size());
+        for (size_t i = 0; i < keyed.size(); ++i) order[i] = keyed[i].second;
+        if (hipMalloc((void**)&c->tile_order, order.size() * 4) != hipSuccess ||
+            hipMemcpy(c->tile_order, order.data(), order.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            rto_ctx_free(c);
+            return set_err(RTO_E_HIP, "hipMalloc(tile_order) failed");
+        }
+    }
     pcg_seed(c->rng, 20230418ULL, 1);  // render_context.hpp:16
     for (int i = 0; i < 3; ++i) {
         if (hipEventCreate(&c->t_start[i]) != hipSuccess || hipEventCreate(&c->t_stop[i]) != hipSuccess) {
@@ -479,6 +513,8 @@ void rto_ctx_free(rto_ctx* c) {
     if (c->jump) (void)hipFree(c->jump);
     if (c->queue) (void)hipFree(c->queue);
     if (c->hits) (void)hipFree(c->hits);
+    if (c->tile_order) (void)hipFree(c->tile_order);
+    for (hipEvent_t e : c->kt_ev) (void)hipEventDestroy(e);
     if (c->stats) (void)hipFree(c->stats);
     for (int i = 0; i < 3; ++i) {
         if (c->t_start[i]) (void)hipEventDestroy(c->t_start[i]);
@@ -531,12 +567,47 @@ int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value) {
     const std::string k(key);
     if (k == "variant") {
         c->variant = value;
+    } else if (k == "tile_order") {
+        c->tile_order_on = value != 0;
+    } else if (k == "refill") {
+        c->refill = value;
     } else if (k == "strip_rows") {
         if (value < 1) return set_err(RTO_E_INVALID, "strip_rows must be >= 1");
         c->strip_rows = value;
     } else {
         return set_err(RTO_E_INVALID, "unknown tuning key '" + k + "'");
     }
+    return RTO_OK;
+}
+
+int rto_ctx_kernel_timing(rto_ctx* c, int enable) {
+    if (!c) return set_err(RTO_E_INVALID, "rto_ctx_kernel_timing: null context");
+    DeviceGuard guard(c->device);
+    if (enable && c->kt_ev.empty()) {
+        c->kt_ev.resize((size_t)kKtRing * 3);
+        for (auto& e : c->kt_ev) HIP_TRY(hipEventCreate(&e));
+    }
+    c->kt_on = enable != 0;
+    c->kt_count = 0;
+    return RTO_OK;
+}
+
+int rto_ctx_kernel_timing_read(rto_ctx* c, float* traverse_ms, float* shade_ms, int* launches) {
+    if (!c) return set_err(RTO_E_INVALID, "rto_ctx_kernel_timing_read: null context");
+    DeviceGuard guard(c->device);
+    double t = 0, s = 0;
+    for (int i = 0; i < c->kt_count; ++i) {
+        float a = 0, b = 0;
+        HIP_TRY(hipEventSynchronize(c->kt_ev[(size_t)i * 3 + 2]));
+        HIP_TRY(hipEventElapsedTime(&a, c->kt_ev[(size_t)i * 3], c->kt_ev[(size_t)i * 3 + 1]));
+        HIP_TRY(hipEventElapsedTime(&b, c->kt_ev[(size_t)i * 3 + 1], c->kt_ev[(size_t)i * 3 + 2]));
+        t += a;
+        s += b;
+    }
+    if (traverse_ms) *traverse_ms = c->kt_count ? (float)(t / c->kt_count) : 0.f;
+    if (shade_ms) *shade_ms = c->kt_count ? (float)(s / c->kt_count) : 0.f;
+    if (launches) *launches = c->kt_count;
+    c->kt_count = 0;
     return RTO_OK;
 }
 
@@ -653,6 +724,7 @@ int rto_launch_renderer_batch(const rto_tree* tree, const rto_camera* cams, cons
     fb.n = n;
     fb.width = ctx->width;
     fb.height = ctx->height;
+    fb.tile_order = ctx->tile_order_on ? ctx->tile_order : nullptr;
     const size_t px = frame_px(ctx);
     for (int f = 0; f < n; ++f) {
         if (cams[f].width != ctx->width || cams[f].height != ctx->height)
@@ -682,7 +754,9 @@ int rto_launch_renderer_batch(const rto_tree* tree, const rto_camera* cams, cons
     std::memcpy(od.render_bbox, o->render_bbox, sizeof(od.render_bbox));
     od.basis_minmax[0] = o->basis_minmax[0];
     od.basis_minmax[1] = o->basis_minmax[1];
-    hipError_t e = rto::launch_render_batch(o->spp, tree->dev, od, fb, ctx->jump, ctx->queue, ctx->num_cus, stream);
+    hipEvent_t* ev = nullptr;
+    if (ctx->kt_on && ctx->kt_count < kKtRing) ev = &ctx->kt_ev[(size_t)ctx->kt_count++ * 3];
+    hipError_t e = rto::launch_render_batch(o->spp, tree->dev, od, fb, ctx->jump, ctx->queue, ctx->hits, ctx->num_cus, ctx->refill, ev, stream);
     if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("batched render launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
 }

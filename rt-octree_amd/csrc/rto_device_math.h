@@ -134,6 +134,31 @@ RTO_DEV float det_expf(float x) {
     return (float)(p * sc);
 }
 
+// fp32-only deterministic exp for the filter taps; mirrors oracle/rto_oracle.c orc_fexp
+RTO_DEV float fexp_f32(float x) {
+    if (x != x) return x;
+    if (x > 88.72283935546875f) return __builtin_inff();
+    if (x < -87.33654022216797f) return 0.0f;
+    const float t = x * 1.44269502162933349609375f;
+    const float kf = (t + 12582912.0f) - 12582912.0f;
+    float r = x - kf * 0.693145751953125f;
+    r = r - kf * 1.42860676533018704e-06f;
+    float p = 1.0f / 5040.0f;
+    p = p * r + 1.0f / 720.0f;
+    p = p * r + 1.0f / 120.0f;
+    p = p * r + 1.0f / 24.0f;
+    p = p * r + 1.0f / 6.0f;
+    p = p * r + 0.5f;
+    p = p * r + 1.0f;
+    p = p * r + 1.0f;
+    int ki = (int)kf;
+    if (ki > 127) {  // 2^128 has no fp32 encoding
+        ki = 127;
+        p = p * 2.0f;
+    }
+    return p * __uint_as_float((uint32_t)(ki + 127) << 23);
+}
+
 RTO_DEV float f_min(float a, float b) { return a < b ? a : b; }
 RTO_DEV float f_max(float a, float b) { return a > b ? a : b; }
 

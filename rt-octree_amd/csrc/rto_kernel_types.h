@@ -62,6 +62,7 @@ struct FrameDesc {
 constexpr uint32_t kNoHit = 0xffffffffu;
 struct FrameBatch {
     int n, width, height, pad;
+    const uint32_t* tile_order;  // [tiles8_x*tiles8_y] (ty << 16 | tx) in queue order, or nullptr
     FrameDesc f[kMaxBatch];
 };
 

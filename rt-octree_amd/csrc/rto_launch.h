@@ -18,9 +18,11 @@ hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev&
                          const Pcg32& rng, const PcgJumpEntry* jump, const FrameOut& fo, int strip_rows,
                          int variant, hipStream_t stream);
 
-// persistent batched renderer (N == 2 trees): fb.n frames in one launch; `queue` = 2 zeroed u64
+// persistent batched renderer (N == 2 trees): fb.n frames in one launch (traversal kernel, then the
+// shading kernel); `queue` = 2 zeroed u64; ev = nullptr or 3 events recorded before / between / after
 hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
-                               const PcgJumpEntry* jump, unsigned long long* queue, int num_cus, hipStream_t stream);
+                               const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
+                               int refill, hipEvent_t* ev, hipStream_t stream);
 
 hipError_t launch_rgba8(const float* rgba, uint8_t* out, int64_t n_pixels, hipStream_t stream);
 

@@ -312,6 +312,15 @@ class RenderContext:
         """performance knobs ("variant", "strip_rows"); results never change"""
         check(lib().rto_ctx_set_tuning(self._h, key.encode("ascii"), int(value)))
 
+    def kernel_timing(self, on=True):
+        """HIP-event timing of the traversal / shading kernels of launch_renderer_batch"""
+        check(lib().rto_ctx_kernel_timing(self._h, int(bool(on))))
+
+    def kernel_timing_read(self):
+        t, s, n = C.c_float(0), C.c_float(0), C.c_int(0)
+        check(lib().rto_ctx_kernel_timing_read(self._h, C.byref(t), C.byref(s), C.byref(n)))
+        return {"traverse_ms": t.value, "shade_ms": s.value, "launches": n.value}
+
     def enable_stats(self, on=True):
         """Work counters for the roofline's algorithmic byte count (never in a timed run)."""
         check(lib().rto_ctx_enable_stats(self._h, int(bool(on))))

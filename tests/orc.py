@@ -78,6 +78,8 @@ def lib():
         L.orc_det_logf.argtypes = [C.c_float]
         L.orc_det_expf.restype = C.c_float
         L.orc_det_expf.argtypes = [C.c_float]
+        L.orc_fexp.restype = C.c_float
+        L.orc_fexp.argtypes = [C.c_float]
         L.orc_half2float.restype = C.c_float
         L.orc_half2float.argtypes = [C.c_uint16]
         L.orc_query.restype = C.c_int64

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--frames", type=int, default=48)
     ap.add_argument("--batches", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--refills", type=int, nargs="+", default=[24])
     ap.add_argument("--tree", default="")
     args = ap.parse_args()
     import torch
@@ -67,7 +68,10 @@ def main():
         print("round %d: one frame per launch (render_fast): %.3f ms/frame" % (rnd, timed(single)), flush=True)
         if ref is None:
             ref = ctx.download_aux()  # last frame
-        for B in args.batches:
+        for B, RF in [(b, r) for b in args.batches for r in args.refills]:
+            ctx.set_tuning("refill", abs(RF))
+            ctx.set_tuning("tile_order", 0 if RF < 0 else 1)  # negative refill = row-major tile order
+
             def batched():
                 for i in range(0, len(cams), B):
                     grp = cams[i:i + B]
@@ -78,7 +82,7 @@ def main():
             ctx.select_frame(last)
             same = np.array_equal(ctx.download_aux().view(np.uint32), ref.view(np.uint32))
             ctx.select_frame(0)
-            print("round %d: batch %d (render_persist): %.3f ms/frame  same_bits=%s" % (rnd, B, ms, same), flush=True)
+            print("round %d: batch %d refill %d (render_persist): %.3f ms/frame  same_bits=%s" % (rnd, B, RF, ms, same), flush=True)
 
 
 if __name__ == "__main__":

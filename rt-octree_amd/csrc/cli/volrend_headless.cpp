@@ -1,0 +1,289 @@
+// volrend_headless -- offscreen PlenOctree rendering with batched regular tracking + GuidanceNet
+// denoising on MI355X.  Same command line, inputs and outputs as the reference's
+// renderer/main_headless.cpp (flags :201-224 + src/opts.cpp:9-29; tree.npz, poses json / txt dir /
+// npy, opt.json, ts_*.ts; r_<i>.png or buf_<name>.bin; the 5-line timing report), on top of the
+// C ABI in include/rto.h.
+//
+// Deviations, all documented in INTEGRATION.md:
+//   * `--ts_module` is only required when the options say denoise = true (the reference constructs
+//     the Denoiser unconditionally and aborts without it, main_headless.cpp:455-456);
+//   * TanksAndTemple pose files are read in sorted order (the reference uses directory order);
+//   * extra flags `--shard i/N` (render poses i, i+N, ...: frame sharding across GPUs, one process
+//     per GPU) and `--warmup K` (default 100 like the reference).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "denoiser_torch.h"
+#include "imwrite.h"
+#include "poses.h"
+#include "rto.h"
+
+namespace fs = std::filesystem;
+
+namespace {
+
+struct Args {
+    std::map<std::string, std::string> kv;
+    std::vector<std::string> positional;
+    bool has(const std::string& k) const { return kv.count(k) != 0; }
+    std::string get(const std::string& k, const std::string& d) const {
+        auto it = kv.find(k);
+        return it == kv.end() ? d : it->second;
+    }
+};
+
+// long options taking a value, with their short aliases (opts.cpp:9-29, main_headless.cpp:201-224)
+const std::map<std::string, std::string> kShort = {{"w", "width"},      {"h", "height"},     {"s", "step_size"},
+                                                   {"e", "stop_thresh"}, {"a", "sigma_thresh"}, {"o", "write_images"},
+                                                   {"i", "intrin"},      {"r", "reverse_yz"}};
+const char* kFlags[] = {"reverse_yz", "write_buffer", "help"};
+
+bool is_flag(const std::string& k) {
+    for (const char* f : kFlags)
+        if (k == f) return true;
+    return false;
+}
+
+Args parse(int argc, char** argv) {
+    Args a;
+    for (int i = 1; i < argc; ++i) {
+        std::string s = argv[i];
+        if (s.rfind("--", 0) == 0) {
+            std::string k = s.substr(2), v;
+            const size_t eq = k.find('=');
+            if (eq != std::string::npos) {
+                v = k.substr(eq + 1);
+                k = k.substr(0, eq);
+            } else if (!is_flag(k) && i + 1 < argc) {
+                v = argv[++i];
+            } else {
+                v = "true";
+            }
+            a.kv[k] = v;
+        } else if (s.size() >= 2 && s[0] == '-' && !(s[1] >= '0' && s[1] <= '9') && s[1] != '.') {
+            const std::string sk = s.substr(1, 1);
+            auto it = kShort.find(sk);
+            if (it == kShort.end()) {
+                std::fprintf(stderr, "WARNING: unknown option %s ignored\n", s.c_str());  // allow_unrecognised_options
+                continue;
+            }
+            std::string v;
+            if (s.size() > 2)
+                v = s.substr(2);
+            else if (!is_flag(it->second) && i + 1 < argc)
+                v = argv[++i];
+            else
+                v = "true";
+            a.kv[it->second] = v;
+        } else {
+            a.positional.push_back(s);
+        }
+    }
+    return a;
+}
+
+void usage() {
+    std::puts(
+        "Headless PlenOctree volume rendering, MI355X build\n"
+        "Usage: volrend_headless npz_file poses [options]\n"
+        "  --gpu N            HIP device id (default: current)\n"
+        "  -w,--width W  -h,--height H   image size (800x800)\n"
+        "  --fx F --fy F      focal lengths (-1 = 1111.11 / fx)\n"
+        "  --bg B             background brightness 0-1 (1.0)\n"
+        "  -s,--step_size -e,--stop_thresh -a,--sigma_thresh   render options when no --options file\n"
+        "  --options opt.json render options (spp, denoise, ...)\n"
+        "  --dataset blender|tt|llff (blender)\n"
+        "  --ts_module ts.ts  TorchScript GuidanceNet (needed when denoise = true)\n"
+        "  -o,--write_images DIR   write r_<i>.png (or buf_<name>.bin with --write_buffer)\n"
+        "  --write_buffer  --max_imgs N  --scale S  -i intrin  -r,--reverse_yz\n"
+        "  --shard i/N        render poses i, i+N, ... only     --warmup K (100)\n");
+}
+
+#define CHECK_RTO(expr)                                                          \
+    do {                                                                         \
+        if ((expr) != RTO_OK) {                                                  \
+            std::fprintf(stderr, "ERROR: %s: %s\n", #expr, rto_last_error());    \
+            return 1;                                                            \
+        }                                                                        \
+    } while (0)
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    const Args args = parse(argc, argv);
+    if (args.has("help") || args.positional.size() < 2) {
+        usage();
+        return args.has("help") ? 0 : 1;
+    }
+    const std::string tree_path = args.positional[0], poses_path = args.positional[1];
+    const int device = std::max(0, std::atoi(args.get("gpu", "-1").c_str()));
+
+    rto::PoseSet ps;
+    ps.width = std::atoi(args.get("width", "800").c_str());
+    ps.height = std::atoi(args.get("height", "800").c_str());
+    ps.fx = (float)std::atof(args.get("fx", "-1.0").c_str());
+    if (ps.fx < 0) ps.fx = 1111.11f;  // main_headless.cpp:241-243
+    ps.fy = (float)std::atof(args.get("fy", "-1.0").c_str());
+    if (ps.fy < 0) ps.fy = ps.fx;
+    const std::string dataset = args.get("dataset", "blender");
+    try {
+        rto::load_poses(dataset, poses_path, args.has("reverse_yz"), ps);
+        if (args.has("intrin") && !args.get("intrin", "").empty()) {  // -i overrides fx/fy
+            std::ifstream f(args.get("intrin", ""));
+            float _;
+            if (f) {
+                f >> ps.fx >> _ >> _ >> _;
+                f >> _ >> ps.fy;
+            }
+        }
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "ERROR: %s\n", e.what());
+        return 1;
+    }
+    if (ps.trans.empty()) {
+        std::fputs("WARNING: No camera poses specified, quitting\n", stderr);
+        return 1;
+    }
+
+    rto_tree* tree = nullptr;
+    CHECK_RTO(rto_tree_load_npz(tree_path.c_str(), device, &tree));
+    if (dataset == "llff") CHECK_RTO(rto_tree_set_ndc(tree, (float)ps.width, (float)ps.height, ps.fx));  // :400-405
+
+    int width = ps.width, height = ps.height;
+    float fx = ps.fx, fy = ps.fy;
+    {
+        const float scale = (float)std::atof(args.get("scale", "1").c_str());  // :407-417
+        if (scale != 1.f) {
+            const int ow = width, oh = height;
+            width = (int)(width * scale);
+            height = (int)(height * scale);
+            fx *= (float)width / ow;
+            fy *= (float)height / oh;
+        }
+    }
+    {
+        const int max_imgs = std::atoi(args.get("max_imgs", "0").c_str());  // :419-426
+        if (max_imgs > 0 && ps.trans.size() > (size_t)max_imgs) {
+            ps.trans.resize(max_imgs);
+            ps.basenames.resize(max_imgs);
+        }
+    }
+    int shard_i = 0, shard_n = 1;
+    if (args.has("shard")) {
+        if (std::sscanf(args.get("shard", "0/1").c_str(), "%d/%d", &shard_i, &shard_n) != 2 || shard_n < 1 ||
+            shard_i < 0 || shard_i >= shard_n) {
+            std::fputs("ERROR: --shard expects i/N with 0 <= i < N\n", stderr);
+            return 1;
+        }
+    }
+
+    const std::string out_dir = args.get("write_images", "");
+    if (!out_dir.empty()) fs::create_directories(out_dir);
+
+    rto_ctx* ctx = nullptr;
+    CHECK_RTO(rto_ctx_create(width, height, device, &ctx));
+
+    rto_options options;
+    rto_options_default(&options);
+    const std::string options_path = args.get("options", "");
+    if (!options_path.empty()) {
+        CHECK_RTO(rto_options_from_json_file(options_path.c_str(), &options));
+    } else {  // render_options_from_args opts.cpp:44-66
+        options.background_brightness = (float)std::atof(args.get("bg", "1.0").c_str());
+        options.step_size = (float)std::atof(args.get("step_size", "1e-4").c_str());
+        options.stop_thresh = (float)std::atof(args.get("stop_thresh", "1e-2").c_str());
+        options.sigma_thresh = (float)std::atof(args.get("sigma_thresh", "1e-2").c_str());
+    }
+
+    std::unique_ptr<rto::TorchDenoiser> denoiser;
+    if (options.denoise) {
+        try {
+            denoiser = std::make_unique<rto::TorchDenoiser>(args.get("ts_module", ""), device);
+        } catch (const std::exception& e) {
+            std::fprintf(stderr, "ERROR: %s\n", e.what());
+            return 1;
+        }
+    }
+
+    rto_camera cam;
+    cam.width = width;
+    cam.height = height;
+    cam.fx = fx;
+    cam.fy = fy;
+    void* stream = nullptr;  // the default stream: libtorch's current stream in this process
+
+    auto denoise = [&]() -> int {  // Denoiser::denoise denoiser.cpp:31-61
+        const float *w = nullptr, *g = nullptr;
+        int L = 0;
+        rto_timer_start(ctx, RTO_T_TORCH);
+        denoiser->forward(rto_ctx_aux(ctx), height, width, &w, &g, &L);
+        rto_timer_stop(ctx, RTO_T_TORCH);
+        rto_timer_start(ctx, RTO_T_FILTER);
+        const int rc = rto_ctx_filtering(ctx, stream, w, g, L);
+        rto_timer_stop(ctx, RTO_T_FILTER);
+        return rc;
+    };
+
+    // Warm up (main_headless.cpp:469-479): pose 0, every iteration advances the RNG
+    rto_timer_reset(ctx, stream);
+    const int warmup = std::atoi(args.get("warmup", "100").c_str());
+    std::memcpy(cam.transform, ps.trans[0].data(), sizeof(cam.transform));
+    for (int i = 0; i < warmup; ++i) {
+        CHECK_RTO(rto_launch_renderer(tree, &cam, &options, ctx, stream));
+        if (options.denoise) CHECK_RTO(denoise());
+        rto_ctx_rng_advance(ctx, 1LL << 32);
+    }
+    rto_timer_reset(ctx, stream);
+
+    std::vector<uint8_t> rgba8((size_t)width * height * 4);
+    std::vector<float> aux;
+    const bool write_buffer = args.has("write_buffer");
+    if (write_buffer) aux.resize((size_t)width * height * RTO_AUX_CHANNELS);
+
+    for (size_t i = 0; i < ps.trans.size(); ++i) {  // :485-543
+        if ((int)(i % shard_n) == shard_i) {
+            std::memcpy(cam.transform, ps.trans[i].data(), sizeof(cam.transform));
+            rto_timer_start(ctx, RTO_T_RENDER);
+            CHECK_RTO(rto_launch_renderer(tree, &cam, &options, ctx, stream));
+            rto_timer_stop(ctx, RTO_T_RENDER);
+            if (options.denoise) CHECK_RTO(denoise());
+            CHECK_RTO(rto_timer_record(ctx, options.denoise));
+        }
+        rto_ctx_rng_advance(ctx, 1LL << 32);  // skipped poses advance too: images do not depend on N
+        if ((int)(i % shard_n) != shard_i || out_dir.empty()) continue;
+        if (write_buffer) {
+            CHECK_RTO(rto_ctx_download_aux(ctx, stream, aux.data()));
+            std::ofstream f(out_dir + "/buf_" + ps.basenames[i] + ".bin", std::ios::binary);
+            f.write(reinterpret_cast<const char*>(aux.data()), (std::streamsize)(aux.size() * sizeof(float)));
+        } else {
+            CHECK_RTO(rto_ctx_download_rgba8(ctx, stream, 0, rgba8.data()));
+            if (!rto::write_png_rgba8(out_dir + "/" + ps.basenames[i] + ".png", rgba8.data(), width, height)) {
+                std::fprintf(stderr, "ERROR: cannot write %s/%s.png\n", out_dir.c_str(), ps.basenames[i].c_str());
+                return 1;
+            }
+        }
+    }
+
+    float ms[3], fps;  // Timer::report render_context.hpp:190-206
+    int frames;
+    rto_timer_report(ctx, ms, &fps, &frames);
+    std::printf("render: %.10f ms per frame\n", ms[0]);
+    std::printf("torch:  %.10f ms per frame\n", ms[1]);
+    std::printf("filter: %.10f ms per frame\n", ms[2]);
+    std::printf("all:    %.10f ms per frame\n", ms[0] + ms[1] + ms[2]);
+    std::printf("FPS:    %.10f\n", fps);
+
+    denoiser.reset();
+    rto_ctx_free(ctx);
+    rto_tree_free(tree);
+    return 0;
+}

@@ -14,6 +14,11 @@
 // Per level, per pixel p (support S = level+1, window (2S+1)^2, row-major tap order):
 //   m = max_q g(q);  k_q = exp(g(q) - m);  out += (sum_q k_q rgb(q)) * (w(p) / sum_q k_q)
 // Out-of-image taps: rgb = 0, g = -FLT_MAX (:140-143).
+//
+// Roofline: VALU-bound, not HBM-bound -- (2S+1)^2 taps of ~33 fp32 instructions each (the exp is
+// 25 of them) against 48 B of traffic per pixel.  The tap loops are kept rolled per window row so
+// the kernel stays at <= 128 VGPRs (4 waves/SIMD); fully unrolled it needs 256 VGPRs and runs one
+// wave per SIMD.
 #include <hip/hip_runtime.h>
 
 #include "rto_launch.h"
@@ -24,12 +29,52 @@ namespace rto {
 
 constexpr int kFiltW = 32, kFiltH = 8;  // output tile per 256-thread workgroup
 
+template <int S, int TW>
+RTO_DEV void filter_level(const float* __restrict__ g, const float4* __restrict__ rgb, int centre, float w_pix,
+                          float& o0, float& o1, float& o2, bool first) {
+    float max_val = -3.402823466e+38f;
+#pragma unroll 1
+    for (int dy = -S; dy <= S; ++dy) {
+        const float* row = g + centre + dy * TW;
+#pragma unroll
+        for (int dx = -S; dx <= S; ++dx) max_val = fmaxf(max_val, row[dx]);
+    }
+    float r = 0.f, gg = 0.f, b = 0.f, kernel_sum = 0;
+#pragma unroll 1
+    for (int dy = -S; dy <= S; ++dy) {
+        const int e0 = centre + dy * TW;
+#pragma unroll
+        for (int dx = -S; dx <= S; ++dx) {
+            const float k = fexp_f32_le88(g[e0 + dx] - max_val);
+            kernel_sum += k;
+            const float4 t = rgb[e0 + dx];
+            r += t.x * k;
+            gg += t.y * k;
+            b += t.z * k;
+        }
+    }
+    const float inv = 1.0f / kernel_sum;
+    const float w = w_pix * inv;
+    r *= w;
+    gg *= w;
+    b *= w;
+    if (first) {
+        o0 = r;
+        o1 = gg;
+        o2 = b;
+    } else {
+        o0 += r;
+        o1 += gg;
+        o2 += b;
+    }
+}
+
 template <int L>
-__global__ void __launch_bounds__(256) filter_fused(const float* __restrict__ weight,    // [L][H][W]
-                                                     const float* __restrict__ guidance,  // [L][H][W]
-                                                     const float4* __restrict__ img_in,   // [H][W]
-                                                     float4* __restrict__ img_out,        // [H][W]
-                                                     int H, int W) {
+__global__ void __launch_bounds__(256, 4) filter_fused(const float* __restrict__ weight,    // [n][L][H][W]
+                                                        const float* __restrict__ guidance,  // [n][L][H][W]
+                                                        const float4* __restrict__ img_in,   // [n][H][W]
+                                                        float4* __restrict__ img_out,        // [n][H][W]
+                                                        int H, int W) {
     constexpr int TW = kFiltW + 2 * L, TH = kFiltH + 2 * L;
     __shared__ float4 s_rgb[TH * TW];
     __shared__ float s_g[L][TH * TW];
@@ -58,42 +103,15 @@ __global__ void __launch_bounds__(256) filter_fused(const float* __restrict__ we
     const int px = blockIdx.x * kFiltW + lx, py = blockIdx.y * kFiltH + ly;
     if (px >= W || py >= H) return;
     const int64_t pidx = (int64_t)py * W + px;
+    const int centre = (ly + L) * TW + lx + L;
 
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-        const int S = l + 1;
-        const float* g = s_g[l];
-        const int cx = lx + L, cy = ly + L;
-        float max_val = -3.402823466e+38f;
-        for (int dy = -S; dy <= S; ++dy)
-            for (int dx = -S; dx <= S; ++dx) max_val = fmaxf(max_val, g[(cy + dy) * TW + cx + dx]);
-        float r = 0.f, gg = 0.f, b = 0.f, kernel_sum = 0;
-        for (int dy = -S; dy <= S; ++dy)
-            for (int dx = -S; dx <= S; ++dx) {
-                const int e = (cy + dy) * TW + cx + dx;
-                const float k = fexp_f32(g[e] - max_val);
-                kernel_sum += k;
-                const float4 t = s_rgb[e];
-                r += t.x * k;
-                gg += t.y * k;
-                b += t.z * k;
-            }
-        const float inv = 1.0f / kernel_sum;
-        const float w = weight[l * HW + pidx] * inv;
-        r *= w;
-        gg *= w;
-        b *= w;
-        if (l == 0) {
-            o0 = r;
-            o1 = gg;
-            o2 = b;
-        } else {
-            o0 += r;
-            o1 += gg;
-            o2 += b;
-        }
-    }
+    filter_level<1, TW>(s_g[0], s_rgb, centre, weight[pidx], o0, o1, o2, true);
+    if constexpr (L >= 2) filter_level<2, TW>(s_g[1], s_rgb, centre, weight[HW + pidx], o0, o1, o2, false);
+    if constexpr (L >= 3) filter_level<3, TW>(s_g[2], s_rgb, centre, weight[2 * HW + pidx], o0, o1, o2, false);
+    if constexpr (L >= 4) filter_level<4, TW>(s_g[3], s_rgb, centre, weight[3 * HW + pidx], o0, o1, o2, false);
+    if constexpr (L >= 5) filter_level<5, TW>(s_g[4], s_rgb, centre, weight[4 * HW + pidx], o0, o1, o2, false);
+    if constexpr (L >= 6) filter_level<6, TW>(s_g[5], s_rgb, centre, weight[5 * HW + pidx], o0, o1, o2, false);
     img_out[pidx] = make_float4(o0, o1, o2, 1.0f);
 }
 

@@ -204,8 +204,11 @@ def write_transforms_json(path, poses, camera_angle_x=CAMERA_ANGLE_X):
 
 def blender_focal(width, camera_angle_x=CAMERA_ANGLE_X):
     """fx = fy = 0.5f * width / tanf(0.5f * camera_angle_x) (main_headless.cpp:258), in fp32."""
+    import ctypes
+    tanf = ctypes.CDLL("libm.so.6").tanf  # the C tanf the reference (and volrend_headless) calls
+    tanf.restype, tanf.argtypes = ctypes.c_float, [ctypes.c_float]
     a = np.float32(camera_angle_x)
-    return float(np.float32(0.5) * np.float32(width) / np.tan(np.float32(0.5) * a, dtype=np.float32))
+    return float(np.float32(0.5) * np.float32(width) / np.float32(tanf(float(np.float32(0.5) * a))))
 
 
 def write_tt_dataset(root, poses, fx=1160.0, fy=1160.0, cx=960.0, cy=540.0):

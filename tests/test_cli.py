@@ -1,0 +1,123 @@
+"""volrend_headless (C++ host over the C ABI): the reference CLI contract of
+renderer/main_headless.cpp -- tree.npz + transforms_test.json + opt.json (+ ts_*.ts) in,
+r_<i>.png / buf_r_<i>.bin + the 5-line timing report out."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import rt_octree_amd as R
+from rt_octree_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BIN = os.path.join(os.path.dirname(HERE), "rt-octree_amd", "bin", "volrend_headless")
+
+
+def _run(args, **kw):
+    return subprocess.run([BIN] + args, capture_output=True, text=True, timeout=600, **kw)
+
+
+def test_cli_help_and_usage_errors(tmp_path):
+    assert os.path.exists(BIN), "volrend_headless was not built (make -C rt-octree_amd/csrc)"
+    r = _run(["--help"])
+    assert r.returncode == 0 and "--ts_module" in r.stdout and "--dataset" in r.stdout
+    assert _run([]).returncode == 1  # needs npz_file and poses
+    p = synth.write_transforms_json(str(tmp_path / "t.json"), synth.orbit_poses(2))
+    r = _run([str(tmp_path / "missing.npz"), p])
+    assert r.returncode == 1 and "does not exist" in (r.stdout + r.stderr)
+    r = _run([str(tmp_path / "missing.npz"), str(tmp_path / "nope.json")])
+    assert r.returncode == 1 and "cannot open poses file" in r.stderr
+    r = _run([str(tmp_path / "x.npz"), p, "--dataset", "bogus"])
+    assert r.returncode == 1 and "unknown dataset type" in r.stderr
+
+
+def _scene(tmp_path, n=3):
+    tree = synth.make_tree(depth_limit=6, basis_dim=9, seed=7)
+    tp = tree.save_npz(str(tmp_path / "tree.npz"))
+    poses = synth.orbit_poses(n)
+    pp = synth.write_transforms_json(str(tmp_path / "transforms_test.json"), poses)
+    return tree, tp, poses, pp
+
+
+@pytest.mark.gpu
+def test_cli_blender_png_matches_oracle(tmp_path):
+    """no denoise: the PNG bytes decode to exactly the oracle's RGBA8 for every pose (RNG advanced
+    warmup + i times, main_headless.cpp:469-506)."""
+    import orc
+    from PIL import Image
+    tree, tp, poses, pp = _scene(tmp_path)
+    op = synth.write_opt_json(str(tmp_path / "opt.json"), denoise=False, spp=6)
+    out = str(tmp_path / "out")
+    r = _run([tp, pp, "--options", op, "--dataset", "blender", "-w", "96", "-h", "64", "-o", out, "--warmup", "5"])
+    assert r.returncode == 0, r.stderr
+    assert re.search(r"render: [0-9.]+ ms per frame\ntorch:  [0-9.]+ ms per frame\nfilter: [0-9.]+ ms per frame\nall:    [0-9.]+ ms per frame\nFPS:    [0-9.]+", r.stdout)
+    ht = orc.HostTree(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+    fx = synth.blender_focal(96)
+    for i in range(3):
+        got = np.array(Image.open(os.path.join(out, "r_%d.png" % i)))
+        cam = orc.camera(96, 64, fx, fx, poses[i][:3, :4].T.reshape(-1))
+        _, rgba, _ = orc.render_frame(ht, cam, orc.default_options(spp=6), orc.rng(frame=5 + i))
+        assert got.shape == (64, 96, 4) and np.array_equal(got, orc.rgba8(rgba)), i
+
+
+@pytest.mark.gpu
+def test_cli_write_buffer_and_shard(tmp_path):
+    """--write_buffer dumps aux [8,H,W] fp32 (dataset.py:161-163 layout); --shard i/N renders a subset
+    with unchanged per-frame RNG, so shards reproduce the unsharded frames."""
+    import orc
+    tree, tp, poses, pp = _scene(tmp_path, n=4)
+    op = synth.write_opt_json(str(tmp_path / "opt.json"), denoise=False, spp=2)
+    full, s1 = str(tmp_path / "full"), str(tmp_path / "s1")
+    base = [tp, pp, "--options", op, "-w", "48", "-h", "40", "--warmup", "2", "--write_buffer"]
+    assert _run(base + ["-o", full]).returncode == 0
+    assert _run(base + ["-o", s1, "--shard", "1/2"]).returncode == 0
+    assert sorted(os.listdir(s1)) == ["buf_r_1.bin", "buf_r_3.bin"]
+    ht = orc.HostTree(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+    fx = synth.blender_focal(48)
+    for i in range(4):
+        buf = np.fromfile(os.path.join(full, "buf_r_%d.bin" % i), np.float32).reshape(8, 40, 48)
+        cam = orc.camera(48, 40, fx, fx, poses[i][:3, :4].T.reshape(-1))
+        aux, _, _ = orc.render_frame(ht, cam, orc.default_options(spp=2), orc.rng(frame=2 + i))
+        assert np.array_equal(buf.view(np.uint32), aux.view(np.uint32)), i
+        if i % 2 == 1:
+            assert open(os.path.join(s1, "buf_r_%d.bin" % i), "rb").read() == buf.tobytes()
+
+
+@pytest.mark.gpu
+def test_cli_denoise_with_torchscript_module(tmp_path):
+    """full C2-style pipeline through libtorch: ts module exported like compact_and_compile, filter on
+    the HIP kernel; the PNG equals the Python host's result for the same inputs."""
+    import torch
+    from PIL import Image
+    from rt_octree_amd import denoiser
+    tree, tp, poses, pp = _scene(tmp_path, n=2)
+    torch.manual_seed(0)
+    full = denoiser.GuidanceNet(8, 32, 5, 2, 4)
+    ts = denoiser.compact_and_compile(full, device="cuda:0", example_hw=(64, 80))
+    tsp = str(tmp_path / "ts_latest.ts")
+    ts.save(tsp)
+    op = synth.write_opt_json(str(tmp_path / "opt.json"))  # spp 6, denoise true: the reference's opt.json
+    out = str(tmp_path / "out")
+    r = _run([tp, pp, "--options", op, "--ts_module", tsp, "-w", "80", "-h", "64", "-o", out, "--warmup", "1"])
+    assert r.returncode == 0, r.stderr
+    # the same through the Python host
+    dt = R.N3Tree(tp)
+    ctx = R.RenderContext(80, 64)
+    fx = synth.blender_focal(80)
+    cam = R.Camera(80, 64, fx, fx)
+    dn = denoiser.Denoiser(tsp)
+    opt = R.RenderOptions.from_json(op)
+    for i in range(2):
+        cam.set_c2w(poses[i])
+        ctx.rng_seed()
+        ctx.rng_advance((1 + i) << 32)
+        R.launch_renderer(dt, cam, opt, ctx)
+        dn.denoise(cam, ctx)
+        want = ctx.download_rgba8()
+        got = np.array(Image.open(os.path.join(out, "r_%d.png" % i)))
+        assert np.array_equal(got, want), i
+    # denoise = true without --ts_module: the reference's error text
+    r = _run([tp, pp, "--options", op, "-w", "80", "-h", "64"])
+    assert r.returncode == 1 and "No torchscript module is given to denoiser." in r.stderr

@@ -215,6 +215,12 @@ int rto_timer_record(rto_ctx* c, int denoise);
 /* Timer::report: mean ms per bucket and FPS = 1000/(render+torch+filter) */
 int rto_timer_report(const rto_ctx* c, float ms_out[3], float* fps_out, int* frames_out);
 
+/* ---- profiling aid ---- */
+/* Counter calibration (MI355X_MICROARCH.md "HBM"): launches `repeats` kernels in which every lane
+ * loads one dword from its own never-repeated 128-byte line of a zero-filled n_lines*128-byte buffer
+ * (the render path's access shape).  Known lines per launch = n_lines; compare with FETCH_SIZE. */
+int rto_probe_gather(uint64_t n_lines, int repeats);
+
 #ifdef __cplusplus
 }
 #endif

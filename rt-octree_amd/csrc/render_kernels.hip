@@ -339,6 +339,27 @@ __global__ void build_nodew_kernel(const int32_t* __restrict__ child, const uint
     }
 }
 
+// Top-of-tree shortcut (TreeDev::topgrid): one thread per cell of the 2^G-per-axis grid walks its
+// root path over node levels 0..G-1 and records where it ends: {slot | level << 27, nodew[slot]}.
+__global__ void build_topgrid_kernel(const uint32_t* __restrict__ nodew, int G, uint2* __restrict__ grid) {
+    const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+    if (key >= (1u << (3 * G))) return;
+    const uint32_t mask = (1u << G) - 1u;
+    const uint32_t cx = key >> (2 * G), cy = (key >> G) & mask, cz = key & mask;
+    uint32_t node = 0, slot = 0, w = 0;
+    int lvl = 0;
+    for (;;) {
+        const int sh = G - 1 - lvl;
+        const uint32_t ci = (((cx >> sh) & 1u) << 2) | (((cy >> sh) & 1u) << 1) | ((cz >> sh) & 1u);
+        slot = node * 8u + ci;
+        w = nodew[slot];
+        if (nodew_is_leaf(w) || lvl == G - 1) break;
+        node += w;
+        ++lvl;
+    }
+    grid[key] = make_uint2(slot | ((uint32_t)lvl << 27), w);
+}
+
 // ------------------------------------------------------------------ fast kernel (N == 2)
 
 constexpr int kTileW = 32, kTileH = 8;  // workgroup tile; each wave owns an 8x8 sub-tile
@@ -620,9 +641,11 @@ struct RayState {
     float delta_scale, t, tmax, src, cur;      // cur = next threshold to cross (dst[spp])
     uint32_t spp, sh_nums;
     uint32_t pix, piy, piz;
-    int prev_lvl;
+    int prev_lvl;   // FLAT: level of the node about to be visited
     uint32_t hoff;  // index of this pixel's first hit entry in the hand-off buffer
+    uint32_t node;  // FLAT: node about to be visited; kGridNext = the top grid is visited next
 };
+constexpr uint32_t kGridNext = 0xffffffffu;
 
 // queue index -> (frame, x, y); 64 rays per 8x8 tile, tiles in `tile_order` (ty << 16 | tx per
 // queue position: centre-out, so a frame's queue ends on its cheap border tiles) or row-major when
@@ -677,7 +700,11 @@ __global__ void __launch_bounds__(256) sample_kernel(const FrameBatch fb, const 
 }
 
 // REFILL = idle lanes that trigger a retire + refill round
-template <int SPP, int REFILL, int WPS>
+// FLAT: one node visit (one load) per lane per loop iteration -- a lane either descends one level or,
+// at a leaf, takes its march step and picks the restart node of the next one -- instead of a nested
+// "descend until leaf" loop whose trip count is the maximum over the wave (measured: 1.4 loads per
+// lane-step on average, but ~4 per wave-step for the slowest lane).
+template <int SPP, int REFILL, int WPS, bool FLAT>
 __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, const OptDev opt, const FrameBatch fb,
                                                        unsigned long long* __restrict__ queue,
                                                        uint32_t* __restrict__ hits, const uint32_t chunk) {
@@ -686,8 +713,9 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     extern __shared__ uint32_t s_mem[];
     const int tid = threadIdx.x;
     uint32_t* stack = s_mem + tid;
-    float* s_dst = reinterpret_cast<float*>(s_mem + (size_t)(tree.max_depth + 1) * 256) + tid;
-    FrameDesc* s_frames = reinterpret_cast<FrameDesc*>(s_mem + (size_t)(tree.max_depth + 1 + SPP + 1) * 256);
+    const int stack_levels = tree.max_depth + 1 - tree.top_levels;  // levels top_levels.. only
+    float* s_dst = reinterpret_cast<float*>(s_mem + (size_t)stack_levels * 256) + tid;
+    FrameDesc* s_frames = reinterpret_cast<FrameDesc*>(s_mem + (size_t)(stack_levels + SPP + 1) * 256);
 #pragma unroll
     for (int f = 0; f < kMaxBatch; ++f)  // static indices: the kernarg struct is never address-taken
         if (tid == f) s_frames[f] = fb.f[f];
@@ -702,11 +730,22 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     // Loop-invariant scalars pinned in SGPRs: under the 8-waves/SIMD register budget hipcc
     // otherwise re-loads them from the kernarg segment inside the descent loop (an s_load +
     // lgkmcnt(0) round trip per level).
-    const uint32_t* __restrict__ nodew = tree.nodew;
+    typedef const __attribute__((address_space(1))) uint32_t* gptr_t;  // keep global_load (not flat_load)
+    const uint32_t* nodew_p = tree.nodew;
+    const uint2* topgrid_p = tree.topgrid;
     const uint32_t* __restrict__ tile_order = fb.tile_order;
     float step_size = opt.step_size, sigma_thresh = opt.sigma_thresh;
-    asm volatile("" : "+s"(nodew), "+s"(step_size), "+s"(sigma_thresh));
+    asm volatile("" : "+s"(nodew_p), "+s"(topgrid_p), "+s"(step_size), "+s"(sigma_thresh));
+    const gptr_t nodew = (gptr_t)nodew_p;
+    typedef unsigned int __attribute__((ext_vector_type(2))) u32x2;
+    typedef const __attribute__((address_space(1))) u32x2* gptr2_t;
+    const gptr2_t topgrid = (gptr2_t)topgrid_p;
+    const int G = tree.top_levels;  // grid bits per axis; the LDS stack holds node levels G.. (entry 0 = level G)
+    if (G == 0) stack[0] = 0u;      // no top grid: level 0 is the root
 
+#ifdef RTO_DBG_COUNTERS
+    unsigned dbg_wave_steps = 0, dbg_lane_steps = 0, dbg_lane_loads = 0, dbg_lane_leafs = 0;
+#endif
     RayState rs;
     bool active = false;    // marching
     bool pending = false;   // finished, hit list not yet terminated
@@ -781,6 +820,16 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                             rs.pix = rs.piy = rs.piz = 0;
                             rs.prev_lvl = 0;
                             active = rs.t < rs.tmax;
+                            if (FLAT) {  // locate the first position: fixed-point coordinates + first node
+                                float p0[3] = {rs.cen[0] + rs.t * rs.dir[0], rs.cen[1] + rs.t * rs.dir[1],
+                                               rs.cen[2] + rs.t * rs.dir[2]};
+#pragma unroll
+                                for (int i = 0; i < 3; ++i) p0[i] = f_max(f_min(p0[i], 1.f - 1e-6f), 0.f);
+                                rs.pix = (uint32_t)(p0[0] * 16777216.f);
+                                rs.piy = (uint32_t)(p0[1] * 16777216.f);
+                                rs.piz = (uint32_t)(p0[2] * 16777216.f);
+                                rs.node = G > 0 ? kGridNext : 0u;
+                            }
                         }
                     }
                 }
@@ -791,6 +840,98 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
             }
         }
 
+#ifdef RTO_DBG_COUNTERS
+        ++dbg_wave_steps;
+        dbg_lane_steps += (unsigned)__popcll(__ballot(active));
+#endif
+        if (FLAT) {
+            // ---- one node visit for every active lane
+            if (active) {
+                const bool grid = rs.node == kGridNext;
+                const uint32_t gs = 24u - (uint32_t)G;
+                const uint32_t key = (((rs.pix >> gs) << G | (rs.piy >> gs)) << G) | (rs.piz >> gs);
+                const uint32_t sh = 23u - (uint32_t)rs.prev_lvl;
+                const uint32_t ci = (__builtin_amdgcn_ubfe(rs.pix, sh, 1u) << 2) |
+                                    (__builtin_amdgcn_ubfe(rs.piy, sh, 1u) << 1) | __builtin_amdgcn_ubfe(rs.piz, sh, 1u);
+                uint32_t slot = (rs.node << 3) | ci;
+                uint32_t w;
+                if (grid) {  // the iteration's one load: 8 bytes of the top grid ...
+                    const u32x2 e = topgrid[key];
+                    slot = e.x & 0x07ffffffu;
+                    rs.prev_lvl = (int)(e.x >> 27);
+                    rs.node = slot >> 3;
+                    w = e.y;
+                } else {  // ... or 4 bytes of the traversal image
+                    w = nodew[slot];
+                }
+#ifdef RTO_DBG_COUNTERS
+                ++dbg_lane_loads;
+#endif
+                if ((int32_t)w >= -(1 << 30)) {  // internal: one level down
+                    rs.node += w;
+                    ++rs.prev_lvl;
+                    stack[(rs.prev_lvl - G) * 256] = rs.node;
+                } else {  // leaf: the march step (rt_core.cuh:241-270)
+                    const int lvl = rs.prev_lvl;
+                    float pos[3] = {rs.cen[0] + rs.t * rs.dir[0], rs.cen[1] + rs.t * rs.dir[1],
+                                    rs.cen[2] + rs.t * rs.dir[2]};
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) pos[i] = f_max(f_min(pos[i], 1.f - 1e-6f), 0.f);
+                    const float cube_sz = __uint_as_float((uint32_t)(128 + lvl) << 23);
+                    const float inv_cube = __uint_as_float((uint32_t)(126 - lvl) << 23);
+                    const float a0 = -__builtin_amdgcn_fractf(pos[0] * cube_sz) * rs.invdir[0] + rs.addv[0];
+                    const float a1 = -__builtin_amdgcn_fractf(pos[1] * cube_sz) * rs.invdir[1] + rs.addv[1];
+                    const float a2 = -__builtin_amdgcn_fractf(pos[2] * cube_sz) * rs.invdir[2] + rs.addv[2];
+                    const float tm = __builtin_fminf(1e4f, __builtin_fminf(__builtin_fminf(a0, a1), a2));
+                    const float delta_t = tm * inv_cube + step_size;
+                    const float sigma = half_bits_to_float((uint16_t)w);
+                    bool done = false;
+                    if (sigma > sigma_thresh) {
+                        const float delta = delta_t * rs.delta_scale * sigma;
+                        const float reach = rs.src + delta;
+                        if (reach >= rs.cur) {
+                            uint32_t cnt = 0;
+                            do {
+                                ++cnt;
+                                ++rs.spp;
+                                rs.cur = s_dst[rs.spp * 256];
+                            } while (reach >= rs.cur);
+                            hits[rs.hoff + rs.sh_nums * SIZE] = hit_pack(slot, cnt);
+                            ++rs.sh_nums;
+                            done = rs.spp == (uint32_t)SPP;
+                        }
+                        rs.src = reach;
+                    }
+                    rs.t += delta_t;
+                    active = !done && rs.t < rs.tmax;
+#ifdef RTO_DBG_COUNTERS
+                    ++dbg_lane_leafs;
+#endif
+                    if (active) {  // next position -> restart node (deepest ancestor shared with this step)
+                        float np[3] = {rs.cen[0] + rs.t * rs.dir[0], rs.cen[1] + rs.t * rs.dir[1],
+                                       rs.cen[2] + rs.t * rs.dir[2]};
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) np[i] = f_max(f_min(np[i], 1.f - 1e-6f), 0.f);
+                        const uint32_t ix = (uint32_t)(np[0] * 16777216.f);
+                        const uint32_t iy = (uint32_t)(np[1] * 16777216.f);
+                        const uint32_t iz = (uint32_t)(np[2] * 16777216.f);
+                        const uint32_t diff = (ix ^ rs.pix) | (iy ^ rs.piy) | (iz ^ rs.piz);
+                        int m = __clz((int)diff) - 8;
+                        m = m < lvl ? m : lvl;
+                        rs.pix = ix;
+                        rs.piy = iy;
+                        rs.piz = iz;
+                        if (m < G) {
+                            rs.node = kGridNext;
+                        } else {
+                            rs.node = stack[(m - G) * 256];
+                            rs.prev_lvl = m;
+                        }
+                    }
+                }
+            }
+            continue;
+        }
         // ---- one march step for every active lane (rt_core.cuh:241-270)
         if (active) {
             float pos[3] = {rs.cen[0] + rs.t * rs.dir[0], rs.cen[1] + rs.t * rs.dir[1], rs.cen[2] + rs.t * rs.dir[2]};
@@ -803,18 +944,40 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
             const uint32_t diff = (ix ^ rs.pix) | (iy ^ rs.piy) | (iz ^ rs.piz);
             int lvl = __clz((int)diff) - 8;
             lvl = lvl < rs.prev_lvl ? lvl : rs.prev_lvl;
-            uint32_t node = lvl ? stack[lvl * 256] : 0u;
-            uint32_t w, slot;
-            for (;;) {
+            uint32_t node, w, slot;
+            if (lvl < G) {
+                // restart above the shortcut levels: ONE 8-byte lookup replaces the walk over node levels
+                // 0..G-1 and already carries the word of the slot where that walk ends
+                const uint32_t gs = 24u - (uint32_t)G;
+                const uint32_t key = (((ix >> gs) << G | (iy >> gs)) << G) | (iz >> gs);
+                const u32x2 e = topgrid[key];
+                slot = e.x & 0x07ffffffu;
+                lvl = (int)(e.x >> 27);
+                node = slot >> 3;
+                w = e.y;
+            } else {
+                node = stack[(lvl - G) * 256];
                 const uint32_t sh = 23u - (uint32_t)lvl;
                 const uint32_t ci = (__builtin_amdgcn_ubfe(ix, sh, 1u) << 2) | (__builtin_amdgcn_ubfe(iy, sh, 1u) << 1) |
                                     __builtin_amdgcn_ubfe(iz, sh, 1u);
                 slot = (node << 3) | ci;
                 w = nodew[slot];
-                if ((int32_t)w < -(1 << 30)) break;  // leaf tag 0b10: below every encodable offset
+            }
+#ifdef RTO_DBG_COUNTERS
+            ++dbg_lane_loads;
+#endif
+            while ((int32_t)w >= -(1 << 30)) {  // internal (leaf tag 0b10 lies below every encodable offset)
                 node += w;
                 ++lvl;
-                stack[lvl * 256] = node;
+                stack[(lvl - G) * 256] = node;  // lvl >= G: the grid resolves every level below
+                const uint32_t sh = 23u - (uint32_t)lvl;
+                const uint32_t ci = (__builtin_amdgcn_ubfe(ix, sh, 1u) << 2) | (__builtin_amdgcn_ubfe(iy, sh, 1u) << 1) |
+                                    __builtin_amdgcn_ubfe(iz, sh, 1u);
+                slot = (node << 3) | ci;
+                w = nodew[slot];
+#ifdef RTO_DBG_COUNTERS
+                ++dbg_lane_loads;
+#endif
             }
             rs.pix = ix;
             rs.piy = iy;
@@ -851,6 +1014,17 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
             active = !done && rs.t < rs.tmax;
         }
     }
+#ifdef RTO_DBG_COUNTERS
+    {
+        // wave-level descent iterations = max over lanes is not directly visible; report lane loads
+        atomicAdd(queue + 4, (unsigned long long)dbg_lane_loads);
+        atomicAdd(queue + 5, (unsigned long long)dbg_lane_leafs);
+        if ((tid & 63) == 0) {
+            atomicAdd(queue + 2, (unsigned long long)dbg_wave_steps);
+            atomicAdd(queue + 3, (unsigned long long)dbg_lane_steps);
+        }
+    }
+#endif
     // the last wave out re-arms the queue for the next launch (stream order makes it visible)
     if ((tid & 63) == 0) {
         const unsigned long long waves = (unsigned long long)gridDim.x * (blockDim.x >> 6);
@@ -947,6 +1121,12 @@ hipError_t launch_build_nodew(const int32_t* child, const uint16_t* data, int64_
     return hipGetLastError();
 }
 
+hipError_t launch_build_topgrid(const uint32_t* nodew, int G, uint2* grid, hipStream_t stream) {
+    const unsigned n = 1u << (3 * G);
+    hipLaunchKernelGGL(build_topgrid_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, nodew, G, grid);
+    return hipGetLastError();
+}
+
 TileMap make_tile_map(int width, int height, int strip_rows) {
     TileMap tm;
     tm.tiles_x = (width + kTileW - 1) / kTileW;
@@ -1003,15 +1183,16 @@ hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev&
     }
 }
 
-template <int SPP, int REFILL, int WPS>
+template <int SPP, int REFILL, int WPS, bool FLAT>
 static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                     const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
                                     int chunk_override, hipEvent_t* ev, hipStream_t stream) {
-    const size_t lds = (size_t)(tree.max_depth + 1 + SPP + 1) * 256 * sizeof(uint32_t) + sizeof(FrameDesc) * kMaxBatch;
+    const size_t lds = (size_t)(tree.max_depth + 1 - tree.top_levels + SPP + 1) * 256 * sizeof(uint32_t) +
+                       sizeof(FrameDesc) * kMaxBatch;
     static int blocks_per_cu = 0;  // per instantiation
     if (blocks_per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_persist<SPP, REFILL, WPS>, 256, lds) != hipSuccess || nb < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_persist<SPP, REFILL, WPS, FLAT>, 256, lds) != hipSuccess || nb < 1)
             nb = 2;
         blocks_per_cu = nb > 8 ? 8 : nb;
     }
@@ -1028,7 +1209,7 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
     const int64_t size = (int64_t)fb.width * fb.height;
     hipLaunchKernelGGL(sample_kernel<SPP>, dim3((unsigned)((size + 255) / 256), fb.n), dim3(256), 0, stream, fb, jump);
     if (ev) (void)hipEventRecord(ev[0], stream);
-    hipLaunchKernelGGL((render_persist<SPP, REFILL, WPS>), dim3(grid), dim3(256), lds, stream, tree, opt, fb, queue, hits, chunk);
+    hipLaunchKernelGGL((render_persist<SPP, REFILL, WPS, FLAT>), dim3(grid), dim3(256), lds, stream, tree, opt, fb, queue, hits, chunk);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
     if (ev) (void)hipEventRecord(ev[1], stream);
     hipLaunchKernelGGL(shade_kernel<SPP>, dim3((unsigned)((size + 255) / 256), fb.n), dim3(256), 0, stream, tree, opt, fb);
@@ -1043,14 +1224,20 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
     const int chunk_override = (refill / 1000) * 64;  // tuning: refill = 1000 * tiles_per_dequeue + threshold
     refill %= 1000;
     if (SPP == 6) {  // tuning instantiations only for the benchmark configuration
-#define RTO_B(R, O) return launch_batch_impl<SPP, R, O>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, ev, stream)
+#define RTO_B(R, O) return launch_batch_impl<SPP, R, O, false>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, ev, stream)
+#define RTO_F(R, O) return launch_batch_impl<SPP, R, O, true>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, ev, stream)
         switch (refill) {
             case 4: RTO_B(4, 8);
             case 8: RTO_B(8, 8);
             case 12: RTO_B(12, 8);
             case 16: RTO_B(16, 8);
+            case 24: RTO_B(24, 8);
             case 32: RTO_B(32, 8);
             case 48: RTO_B(48, 8);
+            case 208: RTO_F(8, 8);
+            case 216: RTO_F(16, 8);
+            case 224: RTO_F(24, 8);
+            case 232: RTO_F(32, 8);
             case 116: RTO_B(16, 6);
             case 124: RTO_B(24, 6);
             case 132: RTO_B(32, 6);
@@ -1058,8 +1245,9 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
             default: break;
         }
 #undef RTO_B
+#undef RTO_F
     }
-    return launch_batch_impl<SPP, 24, 8>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, ev, stream);
+    return launch_batch_impl<SPP, 16, 8, true>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, ev, stream);
 }
 
 hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,

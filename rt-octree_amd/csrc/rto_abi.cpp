@@ -65,6 +65,7 @@ struct rto_tree {
     void* d_data = nullptr;
     void* d_child = nullptr;
     void* d_nodew = nullptr;
+    void* d_topgrid = nullptr;
     bool fast_ok = false;
 };
 
@@ -93,7 +94,7 @@ struct rto_ctx {
     int kernel = RTO_KERNEL_AUTO;
     int strip_rows = 1;
     int variant = 0;
-    int refill = 24;
+    int refill = 0;  // 0 = the default instantiation (flat traversal, refill at 16 idle lanes)
     bool tile_order_on = true;
     bool stats_on = false;
     unsigned long long* stats = nullptr;  // device, 6 counters
@@ -214,7 +215,21 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
         }
     }
 
+    int top_levels = 0;
+    if (t->fast_ok && max_depth >= 3) {
+        // shortcut grid over the top levels: 2^(3G) x 8 B (2 MB at G = 6: L2-resident)
+        top_levels = max_depth - 1 < 6 ? max_depth - 1 : 6;
+        const size_t gbytes = (size_t)8 << (3 * top_levels);
+        if (hipMalloc(&t->d_topgrid, gbytes) != hipSuccess) return fail(RTO_E_HIP, "hipMalloc(topgrid) failed");
+        hipError_t e = rto::launch_build_topgrid((const uint32_t*)t->d_nodew, top_levels, (uint2*)t->d_topgrid, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) return fail(RTO_E_HIP, std::string("build_topgrid failed: ") + hipGetErrorString(e));
+        dev_bytes += gbytes;
+    }
+
     rto::TreeDev& d = t->dev;
+    d.topgrid = (const uint2*)t->d_topgrid;
+    d.top_levels = top_levels;
     d.data = (const uint16_t*)t->d_data;
     d.child = (const int32_t*)t->d_child;
     d.nodew = (const uint32_t*)t->d_nodew;
@@ -426,6 +441,7 @@ void rto_tree_free(rto_tree* t) {
     if (t->d_data) (void)hipFree(t->d_data);
     if (t->d_child) (void)hipFree(t->d_child);
     if (t->d_nodew) (void)hipFree(t->d_nodew);
+    if (t->d_topgrid) (void)hipFree(t->d_topgrid);
     delete t;
 }
 
@@ -460,8 +476,8 @@ int rto_ctx_create_batch(int width, int height, int frames, int device, rto_ctx*
         hipMalloc((void**)&c->noisy, px * 4 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&c->image, px * 4 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&c->rgba8, px * 4) != hipSuccess ||
-        hipMalloc((void**)&c->queue, 2 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(c->queue, 0, 2 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void**)&c->queue, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->queue, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
         rto_ctx_free(c);
         return set_err(RTO_E_HIP, "hipMalloc(ctx buffers) failed");
     }
@@ -561,6 +577,13 @@ int rto_ctx_set_kernel(rto_ctx* c, int kernel) {
     c->kernel = kernel;
     return RTO_OK;
 }
+
+#ifdef RTO_DBG_COUNTERS
+extern "C" int rto_debug_read_queue(rto_ctx* c, uint64_t out[8]) {
+    return hipMemcpy(out, c->queue, 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -4;
+}
+extern "C" int rto_debug_zero_queue(rto_ctx* c) { return hipMemset(c->queue + 2, 0, 48) == hipSuccess ? 0 : -4; }
+#endif
 
 int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value) {
     if (!c || !key) return set_err(RTO_E_INVALID, "rto_ctx_set_tuning: null argument");

@@ -25,6 +25,12 @@ struct TreeDev {
     int format, basis_dim;
     float ndc_width, ndc_height, ndc_focal;  // ndc_width <= 0: off (data_spec.hpp:49)
     int max_depth;                            // levels of child[] visited to reach the deepest leaf
+    // Dense shortcut over the top of the tree (N == 2): G = top_levels bits per axis; entry
+    // [(x*2^G + y)*2^G + z] = {slot | level << 27, nodew[slot]} where the root-path walk of that cell
+    // over node levels 0..G-1 ends (at a leaf, or at the level G-1 slot).  A march step that restarts
+    // above level G costs this one 8-byte, L2-resident load.  nullptr / 0 when absent.
+    const uint2* topgrid;
+    int top_levels;
 };
 
 struct CamDev {

@@ -11,6 +11,9 @@ namespace rto {
 hipError_t launch_build_nodew(const int32_t* child, const uint16_t* data, int64_t n_slots, int data_dim,
                               uint32_t* nodew, int* bad_flag, hipStream_t stream);
 
+// top-of-tree shortcut grid: 2^(3G) entries (TreeDev::topgrid)
+hipError_t launch_build_topgrid(const uint32_t* nodew, int G, uint2* grid, hipStream_t stream);
+
 TileMap make_tile_map(int width, int height, int strip_rows);
 
 // kernel: 1 = generic, 2 = fast.  spp must be one of {1,2,3,4,6,8,16,32} (hipErrorInvalidValue otherwise)

@@ -4,7 +4,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one frame of config C2: batched-regular-tracking render (800x800, SPP 6) + GuidanceNet
-(PyTorch-ROCm) + guided filter, i.e. what one iteration of the reference's timed loop does
+(the compact network as one fused MFMA kernel; --torch-net runs it through PyTorch-ROCm/MIOpen) +
+guided filter, i.e. what one iteration of the reference's timed loop does
 (main_headless.cpp:485-543).  Frames are issued in groups of --batch poses (default 8): one launch
 of the persistent ray-queue traversal kernel + one shading launch, one batched GuidanceNet forward,
 one batched filter launch per group -- a frame alone cannot fill 256 CUs (DESIGN.md "Batching").
@@ -58,6 +59,7 @@ def parse_args():
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores)")
     ap.add_argument("--tree", default="", help="render this tree.npz instead of the synthetic one")
+    ap.add_argument("--torch-net", action="store_true", help="run GuidanceNet through PyTorch-ROCm (MIOpen) instead of the fused HIP kernel")
     return ap.parse_args()
 
 
@@ -123,7 +125,11 @@ def main():
     if denoise:
         torch.manual_seed(0)
         full = denoiser.GuidanceNet(8, 32, 5, 2, 4)
-        net = denoiser.GuidanceNetCompact.from_full(full).half().to(dev).eval()
+        compact = denoiser.GuidanceNetCompact.from_full(full).eval()
+        if args.torch_net:
+            net = compact.half().to(dev)
+        else:
+            net = denoiser.FusedGuidanceNet(compact, device=local_rank)  # same weights, one HIP kernel
     stream = torch.cuda.current_stream(dev)
     aux_v, noisy_v, image_v = ctx.batch_views()
     aux_t = torch.as_tensor(aux_v, device=dev)  # zero-copy [B,8,H,W]
@@ -275,7 +281,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if not denoise else "f32 (traversal, filter) + f16 (GuidanceNet conv)",
+        "dtype": "f32" if not denoise else "f32 (traversal, filter) + f16 x f16 -> f32 (GuidanceNet conv, %s)" % ("MIOpen" if args.torch_net else "fused MFMA kernel"),
         "data": "synthetic",
         "config": {
             "workload": "configs[1]: lego-like synthetic PlenOctree %s (%d nodes, depth %d), %dx%d SPP=%d%s, 1 frame per step issued in groups of %d, frames sharded pose i -> rank i mod N"

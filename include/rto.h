@@ -215,6 +215,21 @@ int rto_timer_record(rto_ctx* c, int denoise);
 /* Timer::report: mean ms per bucket and FPS = 1000/(render+torch+filter) */
 int rto_timer_report(const rto_ctx* c, float ms_out[3], float* fps_out, int* frames_out);
 
+/* ---- GuidanceNet forward as one fused kernel ---- */
+/* The compact network of denoiser/network.py:156-168 (what compact_and_compile exports and
+ * Denoiser::denoise runs, denoiser.cpp:46): relu6(conv3x3(8 -> c1)) -> relu6(conv3x3(c1 -> 2*levels))
+ * -> softmax over the first `levels` channels.  Weights in PyTorch layout, fp32:
+ * w1 [c1][8][3][3], b1 [c1], w2 [2*levels][c1][3][3], b2 [2*levels]; they are rounded to fp16 like the
+ * reference's `.half()` module.  Supported: c1 = 32, levels = 4 (denoiser/configs/blender.txt:21-25);
+ * anything else returns RTO_E_UNSUPPORTED and the caller keeps using the TorchScript module. */
+typedef struct rto_guidance_net rto_guidance_net;
+int rto_guidance_net_create(const float* w1, const float* b1, const float* w2, const float* b2, int c1, int levels,
+                            int device, rto_guidance_net** out);
+/* aux: device [n][8][H][W] fp32; outputs: device [n][levels][H][W] fp32 (weight_map, guidance_map) */
+int rto_guidance_net_forward(const rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W,
+                             float* weight_map, float* guidance_map);
+void rto_guidance_net_free(rto_guidance_net* net);
+
 /* ---- profiling aid ---- */
 /* Counter calibration (MI355X_MICROARCH.md "HBM"): launches `repeats` kernels in which every lane
  * loads one dword from its own never-repeated 128-byte line of a zero-filled n_lines*128-byte buffer

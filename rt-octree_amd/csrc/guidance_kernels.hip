@@ -1,0 +1,190 @@
+// guidance_kernels.hip -- the compact GuidanceNet as ONE fused gfx950 kernel.
+//
+// Reference network (denoiser/network.py:123-168 after compact_and_compile :170-208, run by
+// renderer/src/denoiser/denoiser.cpp:46):  x = aux.half();  x = relu6(conv3x3(x; 8 -> C1));
+// x = relu6(conv3x3(x; C1 -> 2L));  x = x.float();  weight = softmax(x[:L]);  guidance = x[L:].
+// Default C1 = 32, L = 4 (denoiser/configs/blender.txt:21-25): 5.9 GFLOP per 800x800 frame, which
+// PyTorch-ROCm runs as two MIOpen Winograd convolutions plus seven elementwise launches
+// (~0.2 ms/frame, profiles/r1_b_*).  Here one workgroup produces a 32x8 pixel tile end to end:
+//
+//   stage A  aux tile + 2-pixel halo, fp32 planar -> fp16 HWC in LDS (zero outside the image)
+//   stage B  layer 1 on the tile + 1-pixel halo with v_mfma_f32_16x16x32_f16: M = 16 output
+//            channels (weights, A operand, register-resident), N = 16 pixels (B operand: ONE
+//            ds_read_b128 per lane = the 8 input channels of one tap), K = 9 taps x 8 channels
+//            padded to 96; + bias, ReLU6, fp16, HWC in LDS (zero outside the image = the second
+//            convolution's "same" padding)
+//   stage C  layer 2 the same way: K = 9 taps x 32 channels = 9 MFMAs per 16 pixels, output
+//            channels padded 8 -> 16; + bias, ReLU6, fp16 rounding (the reference keeps fp16
+//            activations), then softmax over the L weight channels in fp32 and the stores
+//
+// Accumulation is fp32 inside the MFMA like cuDNN/MIOpen fp16 convolutions; rounding points
+// (fp16 input, fp16 activations after each ReLU6) are the reference's.  Results agree with the fp32
+// PyTorch network to fp16 accuracy (tests/test_guidance_fused.py), not bit for bit: libtorch 1.11 /
+// cuDNN results are not pinned by the reference either.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include "rto_launch.h"
+
+namespace rto {
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+constexpr int kGW = 32, kGH = 8;  // output tile
+constexpr int kCIn = 8;           // aux channels (render_context.hpp:23)
+
+__device__ __forceinline__ float relu6(float x) { return fminf(fmaxf(x, 0.f), 6.f); }
+
+// C1 = mid channels (multiple of 16, <= 64), L = kernel levels (2L <= 16)
+template <int C1, int L>
+__global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ aux,    // [n][8][H][W]
+                                                       const _Float16* __restrict__ w1,  // [C1][96]   k = tap*8 + ci
+                                                       const float* __restrict__ b1,     // [C1]
+                                                       const _Float16* __restrict__ w2,  // [16][9*C1] k = tap*C1 + ci
+                                                       const float* __restrict__ b2,     // [16]
+                                                       float* __restrict__ weight_out,   // [n][L][H][W]
+                                                       float* __restrict__ guidance_out, // [n][L][H][W]
+                                                       int H, int W) {
+    constexpr int IW = kGW + 4, IH = kGH + 4;  // input tile with halo 2
+    constexpr int AW = kGW + 2, AH = kGH + 2;  // layer-1 activation tile with halo 1
+    constexpr int NT1 = C1 / 16;               // output-channel tiles of layer 1
+    constexpr int KS2 = 9 * C1 / 32;           // k-steps of layer 2
+    __shared__ __attribute__((aligned(16))) _Float16 s_in[IH * IW * kCIn];
+    __shared__ __attribute__((aligned(16))) _Float16 s_act[AH * AW * C1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = blockIdx.x * kGW, y0 = blockIdx.y * kGH;
+    const int64_t HW = (int64_t)H * W;
+    aux += (int64_t)blockIdx.z * kCIn * HW;
+    weight_out += (int64_t)blockIdx.z * L * HW;
+    guidance_out += (int64_t)blockIdx.z * L * HW;
+
+    // ---- stage A: input tile, planar fp32 -> HWC fp16
+    for (int e = tid; e < IH * IW * kCIn; e += 256) {
+        const int c = e / (IH * IW), r = e - c * (IH * IW);
+        const int ty = r / IW, tx = r - ty * IW;
+        const int gx = x0 - 2 + tx, gy = y0 - 2 + ty;
+        float v = 0.f;
+        if (gx >= 0 && gx < W && gy >= 0 && gy < H) v = aux[c * HW + (int64_t)gy * W + gx];
+        s_in[(ty * IW + tx) * kCIn + c] = (_Float16)v;
+    }
+    __syncthreads();
+
+    const int col = lane & 15, kg = lane >> 4;  // MFMA lane roles: pixel (B/C column), k-group / row block
+
+    // ---- stage B: layer 1 on the AH x AW region
+    {
+        half8 wa[NT1][3];
+#pragma unroll
+        for (int t = 0; t < NT1; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)
+                wa[t][ks] = *reinterpret_cast<const half8*>(w1 + (size_t)(t * 16 + col) * 96 + ks * 32 + kg * 8);
+        float bias[NT1][4];
+#pragma unroll
+        for (int t = 0; t < NT1; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bias[t][i] = b1[t * 16 + kg * 4 + i];
+
+        constexpr int NG1 = (AH * AW + 15) / 16;
+        for (int g = wave; g < NG1; g += 4) {
+            const int p = g * 16 + col;
+            const bool valid = p < AH * AW;
+            const int ry = valid ? p / AW : 0, rx = valid ? p - (p / AW) * AW : 0;
+            float4v acc[NT1];
+#pragma unroll
+            for (int t = 0; t < NT1; ++t) acc[t] = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const int tap = ks * 4 + kg;
+                half8 bfrag = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+                if (tap < 9) {
+                    const int ky = tap / 3, kx = tap - ky * 3;
+                    bfrag = *reinterpret_cast<const half8*>(s_in + ((ry + ky) * IW + rx + kx) * kCIn);
+                }
+#pragma unroll
+                for (int t = 0; t < NT1; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][ks], bfrag, acc[t], 0, 0, 0);
+            }
+            if (valid) {
+                const int gx = x0 - 1 + rx, gy = y0 - 1 + ry;
+                const bool inside = gx >= 0 && gx < W && gy >= 0 && gy < H;
+#pragma unroll
+                for (int t = 0; t < NT1; ++t) {
+                    half4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = inside ? (_Float16)relu6(acc[t][i] + bias[t][i]) : (_Float16)0.f;
+                    *reinterpret_cast<half4*>(s_act + (size_t)p * C1 + t * 16 + kg * 4) = o;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- stage C: layer 2 on the kGH x kGW tile, softmax, stores
+    {
+        half8 wb[KS2];
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks)
+            wb[ks] = *reinterpret_cast<const half8*>(w2 + (size_t)col * (9 * C1) + ks * 32 + kg * 8);
+        float bias[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias[i] = b2[kg * 4 + i];
+
+        constexpr int NG2 = kGH * kGW / 16;
+        for (int g = wave; g < NG2; g += 4) {
+            const int p = g * 16 + col;
+            const int oy = p / kGW, ox = p - oy * kGW;
+            float4v acc = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {
+                const int k0 = ks * 32 + kg * 8;  // k = tap*C1 + ci
+                const int tap = k0 / C1, ci = k0 - tap * C1;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const half8 bfrag = *reinterpret_cast<const half8*>(s_act + (size_t)((oy + ky) * AW + ox + kx) * C1 + ci);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ks], bfrag, acc, 0, 0, 0);
+            }
+            const int gx = x0 + ox, gy = y0 + oy;
+            if (gx < W && gy < H && kg * 4 < 2 * L) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = (float)(_Float16)relu6(acc[i] + bias[i]);  // fp16 activations, then .float()
+                const int64_t pix = (int64_t)gy * W + gx;
+                if (L == 4) {
+                    if (kg == 0) {  // channels 0..3: softmax -> weight_map (network.py:113-114)
+                        const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                        float e[4], s = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            e[i] = __expf(v[i] - m);
+                            s += e[i];
+                        }
+                        const float inv = 1.f / s;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) weight_out[i * HW + pix] = e[i] * inv;
+                    } else {  // channels 4..7: guidance_map (:116)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) guidance_out[i * HW + pix] = v[i];
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_guidance_net(const float* aux, const void* w1, const float* b1, const void* w2, const float* b2, int c1,
+                               int levels, int n, int H, int W, float* weight_out, float* guidance_out,
+                               hipStream_t stream) {
+    if (c1 != 32 || levels != 4) return hipErrorInvalidValue;  // the reference configuration (blender.txt:21-25)
+    const dim3 grid((W + kGW - 1) / kGW, (H + kGH - 1) / kGH, n), block(256);
+    hipLaunchKernelGGL((guidance_fused<32, 4>), grid, block, 0, stream, aux, (const _Float16*)w1, b1, (const _Float16*)w2, b2,
+                       weight_out, guidance_out, H, W);
+    return hipGetLastError();
+}
+
+}  // namespace rto

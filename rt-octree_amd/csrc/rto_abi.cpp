@@ -292,6 +292,9 @@ int options_from_value(const rto::json::Value& j, rto_options* o) {
 
 }  // namespace
 
+// error hook for the other translation units of the library (not part of the public ABI)
+extern "C" int rto_set_error_(int code, const char* msg) { return set_err(code, msg ? msg : ""); }
+
 extern "C" {
 
 const char* rto_version(void) { return "rt-octree_amd 0.1 (gfx950)"; }

@@ -1,0 +1,91 @@
+// rto_guidance_abi.cpp -- C ABI of the fused GuidanceNet forward (include/rto.h, guidance_kernels.hip).
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "rto.h"
+#include "rto_launch.h"
+
+extern "C" const char* rto_last_error(void);
+
+struct rto_guidance_net {
+    int device = 0, c1 = 0, levels = 0;
+    void* w1 = nullptr;   // fp16 [c1][96]
+    void* w2 = nullptr;   // fp16 [16][9*c1]
+    float* b1 = nullptr;  // [c1]
+    float* b2 = nullptr;  // [16]
+};
+
+namespace {
+// rto_abi.cpp owns the thread-local error string; this translation unit reports through it
+extern "C" int rto_set_error_(int code, const char* msg);
+int fail(int code, const std::string& m) { return rto_set_error_(code, m.c_str()); }
+}  // namespace
+
+extern "C" {
+
+int rto_guidance_net_create(const float* w1, const float* b1, const float* w2, const float* b2, int c1, int levels,
+                            int device, rto_guidance_net** out) {
+    if (!w1 || !b1 || !w2 || !b2 || !out) return fail(RTO_E_INVALID, "rto_guidance_net_create: null argument");
+    if (c1 != 32 || levels != 4)
+        return fail(RTO_E_UNSUPPORTED, "fused GuidanceNet supports mid_channels = 32, kernel_levels = 4 (configs/blender.txt)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RTO_E_HIP, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(RTO_E_INVALID, "device index out of range");
+    const int cout = 2 * levels;
+    // pack: k = tap*Cin + ci, tap = ky*3 + kx; layer 1 rows padded to 96 (12 taps), layer 2 to 16 rows
+    std::vector<_Float16> p1((size_t)c1 * 96, (_Float16)0.f), p2((size_t)16 * 9 * c1, (_Float16)0.f);
+    for (int co = 0; co < c1; ++co)
+        for (int ci = 0; ci < 8; ++ci)
+            for (int t = 0; t < 9; ++t) p1[(size_t)co * 96 + t * 8 + ci] = (_Float16)w1[((size_t)co * 8 + ci) * 9 + t];
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < c1; ++ci)
+            for (int t = 0; t < 9; ++t)
+                p2[(size_t)co * 9 * c1 + (size_t)t * c1 + ci] = (_Float16)w2[((size_t)co * c1 + ci) * 9 + t];
+    std::vector<float> pb2(16, 0.f);
+    for (int co = 0; co < cout; ++co) pb2[co] = b2[co];
+
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(device);
+    auto n = new rto_guidance_net();
+    n->device = device;
+    n->c1 = c1;
+    n->levels = levels;
+    bool ok = hipMalloc(&n->w1, p1.size() * 2) == hipSuccess && hipMalloc(&n->w2, p2.size() * 2) == hipSuccess &&
+              hipMalloc((void**)&n->b1, c1 * sizeof(float)) == hipSuccess &&
+              hipMalloc((void**)&n->b2, 16 * sizeof(float)) == hipSuccess;
+    ok = ok && hipMemcpy(n->w1, p1.data(), p1.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(n->w2, p2.data(), p2.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(n->b1, b1, c1 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(n->b2, pb2.data(), 16 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    (void)hipSetDevice(prev);
+    if (!ok) {
+        rto_guidance_net_free(n);
+        return fail(RTO_E_HIP, "uploading the GuidanceNet weights failed");
+    }
+    *out = n;
+    return RTO_OK;
+}
+
+int rto_guidance_net_forward(const rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W,
+                             float* weight_map, float* guidance_map) {
+    if (!net || !aux || !weight_map || !guidance_map || n < 1 || H < 1 || W < 1)
+        return fail(RTO_E_INVALID, "rto_guidance_net_forward: bad argument");
+    const hipError_t e = rto::launch_guidance_net(aux, net->w1, net->b1, net->w2, net->b2, net->c1, net->levels, n, H, W,
+                                                  weight_map, guidance_map, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(RTO_E_HIP, std::string("GuidanceNet launch failed: ") + hipGetErrorString(e));
+    return RTO_OK;
+}
+
+void rto_guidance_net_free(rto_guidance_net* net) {
+    if (!net) return;
+    if (net->w1) (void)hipFree(net->w1);
+    if (net->w2) (void)hipFree(net->w2);
+    if (net->b1) (void)hipFree(net->b1);
+    if (net->b2) (void)hipFree(net->b2);
+    delete net;
+}
+
+}  // extern "C"

@@ -34,4 +34,9 @@ hipError_t launch_rgba8(const float* rgba, uint8_t* out, int64_t n_pixels, hipSt
 hipError_t launch_filter(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
                          float* img_out, hipStream_t stream);
 
+// fused compact GuidanceNet (guidance_kernels.hip): w1 fp16 [c1][96], w2 fp16 [16][9*c1], b2 [16]
+hipError_t launch_guidance_net(const float* aux, const void* w1, const float* b1, const void* w2, const float* b2, int c1,
+                               int levels, int n, int H, int W, float* weight_out, float* guidance_out,
+                               hipStream_t stream);
+
 }  // namespace rto

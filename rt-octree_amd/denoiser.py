@@ -145,6 +145,53 @@ def compact_and_compile(model, device=None, example_hw=(800, 800)):
         return torch.jit.trace(compact, (aux,), check_trace=False)
 
 
+class FusedGuidanceNet:
+    """The compact GuidanceNet as ONE hand-written gfx950 kernel (csrc/guidance_kernels.hip, MFMA fp16
+    with fp32 accumulation) instead of two MIOpen convolutions plus seven elementwise launches.
+    Built from a GuidanceNetCompact, or from a TorchScript export of compact_and_compile (its
+    parameters are named layers.<i>.conv.weight / .bias); callable like the module:
+    aux [n,8,H,W] float32 cuda -> (weight_map, guidance_map) [n,L,H,W] float32."""
+
+    def __init__(self, module, device=0):
+        import ctypes as C
+        from ._lib import check, lib
+        sd = {k: v.detach().float().cpu().contiguous() for k, v in module.state_dict().items()}
+        keys = ("layers.0.conv.weight", "layers.0.conv.bias", "layers.1.conv.weight", "layers.1.conv.bias")
+        if not all(k in sd for k in keys) or any(k.startswith("layers.2.") for k in sd):
+            raise ValueError("FusedGuidanceNet needs a two-layer compact GuidanceNet (layers.{0,1}.conv.*)")
+        w1, b1, w2, b2 = (sd[k] for k in keys)
+        if tuple(w1.shape[1:]) != (8, 3, 3) or tuple(w2.shape[2:]) != (3, 3) or w2.shape[1] != w1.shape[0]:
+            raise ValueError("unexpected GuidanceNet weight shapes")
+        self.c1, self.levels = int(w1.shape[0]), int(w2.shape[0]) // 2
+        self.device = torch.device("cuda", device)
+        h = C.c_void_p(0)
+        check(lib().rto_guidance_net_create(w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), self.c1,
+                                            self.levels, device, C.byref(h)))
+        self._h = h
+        self._out = {}
+
+    def __call__(self, aux, stream=None):
+        from ._lib import check, lib
+        n, c, H, W = aux.shape
+        assert c == 8 and aux.dtype == torch.float32 and aux.is_contiguous()
+        key = (n, H, W)
+        if key not in self._out:
+            self._out[key] = (torch.empty((n, self.levels, H, W), device=self.device),
+                              torch.empty((n, self.levels, H, W), device=self.device))
+        wm, gm = self._out[key]
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        check(lib().rto_guidance_net_forward(self._h, V._stream_ptr(s), aux.data_ptr(), n, H, W, wm.data_ptr(), gm.data_ptr()))
+        return wm, gm
+
+    def __del__(self):
+        try:
+            from ._lib import lib
+            if getattr(self, "_h", None):
+                lib().rto_guidance_net_free(self._h)
+        except Exception:
+            pass
+
+
 class Denoiser:
     """volrend::Denoiser (denoiser.hpp:11-21, denoiser.cpp:31-61).
 

@@ -1,0 +1,76 @@
+"""Fused GuidanceNet kernel (MFMA fp16, fp32 accumulate) vs the fp32 PyTorch compact network.
+Tolerance: fp16 rounding of inputs / weights / activations -- |guidance| <= 3e-2 absolute (values in
+[0, 6]), softmax weights <= 1e-2; and the denoised image through the HIP filter stays > 50 dB PSNR
+from the one obtained with the PyTorch network (SURVEY.md 8c tolerance for the fp16 network)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import rt_octree_amd as R  # noqa: E402
+from rt_octree_amd import denoiser  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _nets(seed=0):
+    torch.manual_seed(seed)
+    full = denoiser.GuidanceNet(8, 32, 5, 2, 4)
+    compact = denoiser.GuidanceNetCompact.from_full(full).eval()
+    return compact, denoiser.FusedGuidanceNet(compact)
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 96), (2, 37, 53), (1, 8, 32), (3, 5, 7)])
+def test_fused_matches_fp32_network(shape):
+    n, H, W = shape
+    compact, fused = _nets()
+    torch.manual_seed(1)
+    aux = torch.rand(n, 8, H, W)
+    aux[:, 4:] = aux[:, :4] ** 2
+    with torch.no_grad():
+        w_ref, g_ref = compact(aux)
+    w, g = fused(aux.cuda().contiguous())
+    torch.cuda.synchronize()
+    assert float((g.cpu() - g_ref).abs().max()) < 3e-2
+    assert float((w.cpu() - w_ref).abs().max()) < 1e-2
+    assert np.allclose(w.cpu().sum(1).numpy(), 1.0, atol=1e-5)
+
+
+def test_fused_exact_on_integer_data():
+    """layout check (MFMA fragment maps, tap order, halo): small-integer weights and inputs make every
+    product and sum exact in fp16/fp32, so the fused kernel must equal the fp32 network exactly,
+    asymmetric kernels included."""
+    compact, _ = _nets()
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for layer in compact.layers:
+            layer.conv.weight.copy_(torch.randint(-2, 3, layer.conv.weight.shape, generator=g).float() / 8)
+            layer.conv.bias.copy_(torch.randint(-4, 5, layer.conv.bias.shape, generator=g).float() / 8)
+    fused = denoiser.FusedGuidanceNet(compact)
+    aux = torch.randint(0, 3, (1, 8, 24, 40), generator=g).float() / 4
+    with torch.no_grad():
+        w_ref, g_ref = compact(aux)
+    w, gm = fused(aux.cuda().contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(gm.cpu(), g_ref)
+    assert float((w.cpu() - w_ref).abs().max()) < 2e-6  # softmax: fast exp vs torch exp
+
+
+def test_denoised_image_psnr():
+    compact, fused = _nets()
+    torch.manual_seed(2)
+    H, W = 96, 128
+    aux = torch.rand(1, 8, H, W)
+    noisy = torch.rand(H, W, 4)
+    noisy[..., 3] = 1
+    dev = torch.device("cuda:0")
+    with torch.no_grad():
+        w_ref, g_ref = compact(aux)
+    w, g = fused(aux.to(dev).contiguous())
+    outs = []
+    for wm, gm in ((w_ref[0].to(dev).contiguous(), g_ref[0].to(dev).contiguous()), (w[0], g[0])):
+        out = torch.empty((H, W, 4), device=dev)
+        R.filtering(None, wm, gm, noisy.to(dev), out)
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+    mse = np.mean((outs[0][..., :3].astype(np.float64) - outs[1][..., :3]) ** 2)
+    assert -10 * np.log10(mse) > 50.0

@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=24)
-    ap.add_argument("--batch", type=int, default=8, help="frames per launch group (1..8)")
+    ap.add_argument("--batch", type=int, default=16, help="frames per launch group (1..16)")
     ap.add_argument("--size", type=int, default=800)
     ap.add_argument("--spp", type=int, default=6)
     ap.add_argument("--basis", type=int, default=16, help="SH basis per channel (16 = the NeRF-synthetic PlenOctrees)")
@@ -97,7 +97,7 @@ def main():
 
     # ---------------- inputs (untimed) ----------------
     W = H = args.size
-    B = max(1, min(8, args.batch))
+    B = max(1, min(16, args.batch))
     tree_host = None
     if args.tree:
         path = args.tree

@@ -43,11 +43,27 @@ RTO_DEV void filter_level(const float* __restrict__ g, const float4* __restrict_
 #pragma unroll 1
     for (int dy = -S; dy <= S; ++dy) {
         const int e0 = centre + dy * TW;
+        // the exps of two neighbouring taps share packed fp32 instructions; the sums stay in tap order
 #pragma unroll
-        for (int dx = -S; dx <= S; ++dx) {
-            const float k = fexp_f32_le88(g[e0 + dx] - max_val);
+        for (int dx = -S; dx < S; dx += 2) {
+            float2v x2;
+            x2.x = g[e0 + dx] - max_val;
+            x2.y = g[e0 + dx + 1] - max_val;
+            const float2v k2 = fexp_f32_le88_x2(x2);
+            const float4 t0 = rgb[e0 + dx], t1 = rgb[e0 + dx + 1];
+            kernel_sum += k2.x;
+            r += t0.x * k2.x;
+            gg += t0.y * k2.x;
+            b += t0.z * k2.x;
+            kernel_sum += k2.y;
+            r += t1.x * k2.y;
+            gg += t1.y * k2.y;
+            b += t1.z * k2.y;
+        }
+        {  // the window is 2S+1 wide: one tap left
+            const float k = fexp_f32_le88(g[e0 + S] - max_val);
             kernel_sum += k;
-            const float4 t = rgb[e0 + dx];
+            const float4 t = rgb[e0 + S];
             r += t.x * k;
             gg += t.y * k;
             b += t.z * k;

@@ -179,6 +179,35 @@ RTO_DEV float fexp_f32_le88(float x) {
     return x < -87.33654022216797f ? 0.0f : res;
 }
 
+// Two arguments at once: the same operations on a 2-vector, which gfx950 executes as packed fp32
+// instructions (v_pk_mul_f32 / v_pk_add_f32: two IEEE results per lane per instruction, each
+// rounded exactly like the scalar form).
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef int int2v __attribute__((ext_vector_type(2)));
+RTO_DEV float2v fexp_f32_le88_x2(float2v x) {
+    const float2v t = x * 1.44269502162933349609375f;
+    const float2v kf = (t + 12582912.0f) - 12582912.0f;
+    float2v r = x - kf * 0.693145751953125f;
+    r = r - kf * 1.42860676533018704e-06f;
+    float2v p = {1.0f / 5040.0f, 1.0f / 5040.0f};
+    p = p * r + 1.0f / 720.0f;
+    p = p * r + 1.0f / 120.0f;
+    p = p * r + 1.0f / 24.0f;
+    p = p * r + 1.0f / 6.0f;
+    p = p * r + 0.5f;
+    p = p * r + 1.0f;
+    p = p * r + 1.0f;
+    const int2v ki = __builtin_convertvector(kf, int2v);
+    const int2v sb = (ki + 127) << 23;
+    float2v sc;
+    sc.x = __int_as_float(sb.x);
+    sc.y = __int_as_float(sb.y);
+    float2v res = p * sc;
+    res.x = x.x < -87.33654022216797f ? 0.0f : res.x;
+    res.y = x.y < -87.33654022216797f ? 0.0f : res.y;
+    return res;
+}
+
 RTO_DEV float f_min(float a, float b) { return a < b ? a : b; }
 RTO_DEV float f_max(float a, float b) { return a > b ? a : b; }
 

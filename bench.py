@@ -50,7 +50,10 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--batch", type=int, default=16, help="frames per launch group (1..16)")
-    ap.add_argument("--size", type=int, default=800)
+    ap.add_argument("--size", type=int, default=800, help="square image size (config C2/C5)")
+    ap.add_argument("--width", type=int, default=0, help="with --height: non-square frames (config C4: 1920x1080)")
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--psnr-frames", type=int, default=64, help="SPP-32 frames accumulated into the PSNR reference (0 = skip PSNR)")
     ap.add_argument("--spp", type=int, default=6)
     ap.add_argument("--basis", type=int, default=16, help="SH basis per channel (16 = the NeRF-synthetic PlenOctrees)")
     ap.add_argument("--depth", type=int, default=10)
@@ -97,6 +100,8 @@ def main():
 
     # ---------------- inputs (untimed) ----------------
     W = H = args.size
+    if args.width > 0 and args.height > 0:
+        W, H = args.width, args.height
     B = max(1, min(16, args.batch))
     tree_host = None
     if args.tree:
@@ -269,6 +274,35 @@ def main():
                "render_s_per_frame": t_render / args.cpu_frames, "net_s_per_frame": t_net / args.cpu_frames,
                "filter_s_per_frame": t_filter / args.cpu_frames, "steps_per_frame": cpu_steps / args.cpu_frames}
 
+    # ---------------- PSNR (untimed, pose 0): SPP-6 raw / denoised vs a high-SPP reference ----------------
+    psnr = None
+    if args.psnr_frames > 0:
+        def _psnr(a, b):  # denoiser/metrics.py:61-62 on rgb in [0,1]
+            mse = float(np.mean((a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64)) ** 2))
+            return float("inf") if mse == 0 else -10.0 * np.log10(mse)
+        ctx.select_frame(0)
+        ctx.set_kernel(R.KERNEL_FAST)
+        acc = np.zeros((H, W, 4), np.float64)
+        ref_opt = R.RenderOptions(spp=32, denoise=False)
+        for k in range(args.psnr_frames):  # independent RNG jumps far away from the timed frames
+            ctx.rng_seed()
+            ctx.rng_advance((100000 + k) << 32)
+            R.launch_renderer(tree, cams[0], ref_opt, ctx, stream)
+            acc += ctx.download_image()
+        ref_img = (acc / args.psnr_frames).astype(np.float32)
+        ctx.rng_seed()
+        R.launch_renderer_batch(tree, [cams[0]], opt, ctx, stream, rng_jumps=[WARM_FRAMES_REF])
+        raw = ctx.download_image(noisy=denoise)
+        psnr = {"reference": "%d x SPP32 = %d spp, pose 0" % (args.psnr_frames, 32 * args.psnr_frames),
+                "raw_spp%d_db" % args.spp: _psnr(raw, ref_img)}
+        if denoise:
+            with torch.no_grad():
+                wm, gm = net(aux_t[:1])
+            R.filtering(stream, wm, gm, ctx.noisy_ptr, ctx.image_ptr)
+            psnr["denoised_db"] = _psnr(ctx.download_image(), ref_img)
+            psnr["note"] = "GuidanceNet has seeded RANDOM weights (no trained ts_*.ts exists offline): the denoised figure shows the pipeline runs, not denoiser quality"
+        psnr["hip_vs_cpu_oracle"] = "bit-exact (tests/test_render_parity.py), PSNR = inf"
+
     total_frames = args.steps * world
     out = {
         "metric": "FPS @ 800x800 (Lego SPP=6) + PSNR vs ref; 1/2/4/8 GPU scaling",
@@ -301,6 +335,7 @@ def main():
             "shade_kernel_avg_launch_ms": kt["shade_ms"],
             "units_per_frame": {k: v / args.steps for k, v in units.items()},
         },
+        "psnr": psnr,
         "cpu_baseline": cpu,
     }
     print(json.dumps(out))

@@ -45,7 +45,7 @@ struct Args {
 const std::map<std::string, std::string> kShort = {{"w", "width"},      {"h", "height"},     {"s", "step_size"},
                                                    {"e", "stop_thresh"}, {"a", "sigma_thresh"}, {"o", "write_images"},
                                                    {"i", "intrin"},      {"r", "reverse_yz"}};
-const char* kFlags[] = {"reverse_yz", "write_buffer", "help"};
+const char* kFlags[] = {"reverse_yz", "write_buffer", "help", "print_poses"};
 
 bool is_flag(const std::string& k) {
     for (const char* f : kFlags)
@@ -105,7 +105,8 @@ void usage() {
         "  --ts_module ts.ts  TorchScript GuidanceNet (needed when denoise = true)\n"
         "  -o,--write_images DIR   write r_<i>.png (or buf_<name>.bin with --write_buffer)\n"
         "  --write_buffer  --max_imgs N  --scale S  -i intrin  -r,--reverse_yz\n"
-        "  --shard i/N        render poses i, i+N, ... only     --warmup K (100)\n");
+        "  --shard i/N        render poses i, i+N, ... only     --warmup K (100)\n"
+        "  --print_poses      parse the poses, print them (column-major 4x3) and exit\n");
 }
 
 #define CHECK_RTO(expr)                                                          \
@@ -152,6 +153,15 @@ int main(int argc, char** argv) {
     if (ps.trans.empty()) {
         std::fputs("WARNING: No camera poses specified, quitting\n", stderr);
         return 1;
+    }
+    if (args.has("print_poses")) {  // host-only check of the pose loaders: no tree, no device
+        std::printf("POSES %zu %d %d %.9g %.9g\n", ps.trans.size(), ps.width, ps.height, ps.fx, ps.fy);
+        for (size_t i = 0; i < ps.trans.size(); ++i) {
+            std::printf("%s", ps.basenames[i].c_str());
+            for (float v : ps.trans[i]) std::printf(" %.9g", v);
+            std::printf("\n");
+        }
+        return 0;
     }
 
     rto_tree* tree = nullptr;

@@ -121,3 +121,88 @@ def test_cli_denoise_with_torchscript_module(tmp_path):
     # denoise = true without --ts_module: the reference's error text
     r = _run([tp, pp, "--options", op, "-w", "80", "-h", "64"])
     assert r.returncode == 1 and "No torchscript module is given to denoiser." in r.stderr
+
+
+def _parse_poses(out):
+    lines = [l for l in out.splitlines() if l and not l.startswith("INFO")]
+    head = lines[0].split()
+    assert head[0] == "POSES"
+    n, w, h, fx, fy = int(head[1]), int(head[2]), int(head[3]), float(head[4]), float(head[5])
+    names, mats = [], []
+    for l in lines[1:1 + n]:
+        parts = l.split()
+        names.append(parts[0])
+        mats.append(np.array([float(x) for x in parts[1:13]], np.float32).reshape(4, 3))  # rows = glm columns
+    return n, w, h, fx, fy, names, np.stack(mats)
+
+
+def test_cli_pose_loader_blender(tmp_path):
+    poses = synth.orbit_poses(5)
+    pp = synth.write_transforms_json(str(tmp_path / "transforms_test.json"), poses)
+    r = _run(["unused.npz", pp, "--print_poses", "-w", "400", "-h", "400"])
+    assert r.returncode == 0, r.stderr
+    n, w, h, fx, fy, names, m = _parse_poses(r.stdout)
+    assert (n, w, h) == (5, 400, 400) and names == ["r_%d" % i for i in range(5)]  # main_headless.cpp:271
+    assert abs(fx - synth.blender_focal(400)) < 1e-4 and fx == fy
+    for i in range(5):
+        assert np.allclose(m[i], poses[i][:3, :4].T.astype(np.float32), atol=1e-6)  # column-major 4x3
+    assert "Use NeRF camera convention" in r.stdout
+
+
+def test_cli_pose_loader_tt(tmp_path):
+    """TanksAndTemple: 1920x1080, ../intrinsics.txt, OpenCV -> NeRF flip (main_headless.cpp:273-297,372-384)"""
+    poses = synth.orbit_poses(3)
+    pose_dir = synth.write_tt_dataset(str(tmp_path / "tt"), poses, fx=1166.5, fy=1163.25)
+    r = _run(["unused.npz", pose_dir, "--dataset", "tt", "--print_poses"])
+    assert r.returncode == 0, r.stderr
+    n, w, h, fx, fy, names, m = _parse_poses(r.stdout)
+    assert (n, w, h) == (3, 1920, 1080) and abs(fx - 1166.5) < 1e-3 and abs(fy - 1163.25) < 1e-3
+    assert names == ["000000", "000001", "000002"]
+    for i in range(3):  # files hold c2w * diag(1,-1,-1,1); the loader flips back
+        assert np.allclose(m[i], poses[i][:3, :4].T.astype(np.float32), atol=1e-5)
+    assert "Use OpenCV camera convention" in r.stdout
+
+
+def test_cli_pose_loader_llff(tmp_path):
+    """LLFF poses_bounds.npy: factor 4, axis swap, bounds scaling, recentring (main_headless.cpp:298-390)
+    against an independent numpy statement."""
+    rs = np.random.RandomState(4)
+    n = 6
+    pb = np.zeros((n, 17))
+    c2w = synth.orbit_poses(n, radius=3.0, elev_deg=(10.0, 5.0))
+    for i in range(n):
+        m = np.zeros((3, 5))
+        m[:, :4] = c2w[i][:3, :4] + rs.randn(3, 4) * 0.01
+        m[:, 4] = (3024.0, 4032.0, 3260.0)  # H, W, focal
+        pb[i, :15] = m.reshape(-1)
+        pb[i, 15:] = (1.2 + 0.1 * i, 9.0 + i)
+    d = tmp_path / "llff"
+    (d / "images_4").mkdir(parents=True)
+    for i in range(n):
+        (d / "images_4" / ("img_%03d.png" % i)).write_bytes(b"")
+    np.save(str(d / "poses_bounds.npy"), pb)
+    r = _run(["unused.npz", str(d / "poses_bounds.npy"), "--dataset", "llff", "--print_poses"])
+    assert r.returncode == 0, r.stderr
+    cnt, w, h, fx, fy, names, m = _parse_poses(r.stdout)
+    assert (cnt, w, h) == (n, 1008, 756) and abs(fx - 815.0) < 1e-3 and names[0] == "img_000"
+    # independent statement
+    bds_min = pb[:, 15].min()
+    mats = []
+    for i in range(n):
+        t = pb[i, :15].reshape(3, 5)[:, :4].astype(np.float32)           # 3x4 row-major
+        t = np.stack([t[:, 1], -t[:, 0], t[:, 2], t[:, 3] * np.float32(1.0 / (bds_min * 0.75))], 1)
+        mats.append(t)
+    mats = np.stack(mats).astype(np.float64)
+    z = mats[:, :, 2].sum(0) / n
+    z /= np.linalg.norm(z)
+    up = mats[:, :, 1].sum(0) / n
+    cen = mats[:, :, 3].sum(0) / n
+    x = np.cross(up, z); x /= np.linalg.norm(x)
+    y = np.cross(z, x); y /= np.linalg.norm(y)
+    avg = np.eye(4); avg[:3, 0], avg[:3, 1], avg[:3, 2], avg[:3, 3] = x, y, z, cen
+    inv = np.linalg.inv(avg)
+    for i in range(n):
+        p4 = np.eye(4); p4[:3, :4] = mats[i]
+        want = (inv @ p4)[:3, :4]
+        assert np.allclose(m[i], want.T, atol=2e-5), i
+    assert "Use LLFF camera convention" in r.stdout

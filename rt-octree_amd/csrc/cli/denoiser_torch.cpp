@@ -27,16 +27,16 @@ TorchDenoiser::TorchDenoiser(const std::string& path, int device) : impl_(new Im
 
 TorchDenoiser::~TorchDenoiser() = default;
 
-void TorchDenoiser::forward(float* aux, int H, int W, const float** weight, const float** guidance, int* levels) {
+void TorchDenoiser::forward(float* aux, int n, int H, int W, const float** weight, const float** guidance, int* levels) {
     torch::NoGradGuard no_grad;
     const auto options = torch::TensorOptions().device(torch::kCUDA, impl_->device).dtype(torch::kFloat32);
-    torch::Tensor aux_t = torch::from_blob(aux, {1, 8, H, W}, options);  // denoiser.cpp:40-43
+    torch::Tensor aux_t = torch::from_blob(aux, {n, 8, H, W}, options);  // denoiser.cpp:40-43 (n = 1 there)
     auto maps = impl_->module.forward({aux_t}).toTuple()->elements();
-    impl_->weight = maps[0].toTensor().squeeze(0).contiguous();    // [L,H,W]
-    impl_->guidance = maps[1].toTensor().squeeze(0).contiguous();  // [L,H,W]
+    impl_->weight = maps[0].toTensor().contiguous();    // [n,L,H,W]
+    impl_->guidance = maps[1].toTensor().contiguous();  // [n,L,H,W]
     *weight = impl_->weight.data_ptr<float>();
     *guidance = impl_->guidance.data_ptr<float>();
-    *levels = (int)impl_->guidance.size(0);
+    *levels = (int)impl_->guidance.size(1);
 }
 
 }  // namespace rto

@@ -15,9 +15,9 @@ public:
     TorchDenoiser(const std::string& ts_module_path, int device);
     ~TorchDenoiser();
 
-    // aux: device pointer to [1,8,H,W] fp32 (zero-copy from_blob).  On return *weight / *guidance point
-    // at contiguous device tensors [L,H,W] that stay alive until the next call.
-    void forward(float* aux, int H, int W, const float** weight, const float** guidance, int* levels);
+    // aux: device pointer to [n,8,H,W] fp32 (zero-copy from_blob).  On return *weight / *guidance point
+    // at contiguous device tensors [n,L,H,W] that stay alive until the next call.
+    void forward(float* aux, int n, int H, int W, const float** weight, const float** guidance, int* levels);
 
 private:
     struct Impl;

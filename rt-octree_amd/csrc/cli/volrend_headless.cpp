@@ -8,6 +8,8 @@
 //   * `--ts_module` is only required when the options say denoise = true (the reference constructs
 //     the Denoiser unconditionally and aborts without it, main_headless.cpp:455-456);
 //   * TanksAndTemple pose files are read in sorted order (the reference uses directory order);
+//   * `--batch B` (1..16, default 1) renders B poses per launch of the persistent ray-queue kernel and
+//     denoises them as one batch; images are identical to B = 1, the report is still per frame;
 //   * extra flags `--shard i/N` (render poses i, i+N, ...: frame sharding across GPUs, one process
 //     per GPU) and `--warmup K` (default 100 like the reference).
 #include <cmath>
@@ -106,6 +108,7 @@ void usage() {
         "  -o,--write_images DIR   write r_<i>.png (or buf_<name>.bin with --write_buffer)\n"
         "  --write_buffer  --max_imgs N  --scale S  -i intrin  -r,--reverse_yz\n"
         "  --shard i/N        render poses i, i+N, ... only     --warmup K (100)\n"
+        "  --batch B          poses per launch (1..16, default 1 = the reference's frame loop)\n"
         "  --print_poses      parse the poses, print them (column-major 4x3) and exit\n");
 }
 
@@ -199,8 +202,9 @@ int main(int argc, char** argv) {
     const std::string out_dir = args.get("write_images", "");
     if (!out_dir.empty()) fs::create_directories(out_dir);
 
+    const int batch = std::max(1, std::min(16, std::atoi(args.get("batch", "1").c_str())));
     rto_ctx* ctx = nullptr;
-    CHECK_RTO(rto_ctx_create(width, height, device, &ctx));
+    CHECK_RTO(rto_ctx_create_batch(width, height, batch, device, &ctx));
 
     rto_options options;
     rto_options_default(&options);
@@ -235,7 +239,7 @@ int main(int argc, char** argv) {
         const float *w = nullptr, *g = nullptr;
         int L = 0;
         rto_timer_start(ctx, RTO_T_TORCH);
-        denoiser->forward(rto_ctx_aux(ctx), height, width, &w, &g, &L);
+        denoiser->forward(rto_ctx_aux(ctx), 1, height, width, &w, &g, &L);
         rto_timer_stop(ctx, RTO_T_TORCH);
         rto_timer_start(ctx, RTO_T_FILTER);
         const int rc = rto_ctx_filtering(ctx, stream, w, g, L);
@@ -258,6 +262,73 @@ int main(int argc, char** argv) {
     std::vector<float> aux;
     const bool write_buffer = args.has("write_buffer");
     if (write_buffer) aux.resize((size_t)width * height * RTO_AUX_CHANNELS);
+
+    if (batch > 1) {
+        // throughput form of the loop below: groups of `batch` poses per launch.  ctx.rng stays at its
+        // post-warm-up state; pose i uses it advanced i times (explicit jump counts), exactly the
+        // state the per-frame loop reaches.
+        std::vector<size_t> mine;
+        for (size_t i = 0; i < ps.trans.size(); ++i)
+            if ((int)(i % shard_n) == shard_i) mine.push_back(i);
+        std::vector<rto_camera> cams(batch, cam);
+        std::vector<int64_t> jumps(batch);
+        size_t rendered = 0;
+        int groups = 0;
+        for (size_t g0 = 0; g0 < mine.size(); g0 += batch, ++groups) {
+            const int n = (int)std::min<size_t>(batch, mine.size() - g0);
+            for (int f = 0; f < n; ++f) {
+                std::memcpy(cams[f].transform, ps.trans[mine[g0 + f]].data(), sizeof(cam.transform));
+                jumps[f] = (int64_t)mine[g0 + f];
+            }
+            rto_ctx_select_frame(ctx, 0);
+            rto_timer_start(ctx, RTO_T_RENDER);
+            CHECK_RTO(rto_launch_renderer_batch(tree, cams.data(), jumps.data(), n, &options, ctx, stream));
+            rto_timer_stop(ctx, RTO_T_RENDER);
+            if (options.denoise) {
+                const float *w = nullptr, *gd = nullptr;
+                int L = 0;
+                rto_timer_start(ctx, RTO_T_TORCH);
+                denoiser->forward(rto_ctx_aux(ctx), n, height, width, &w, &gd, &L);
+                rto_timer_stop(ctx, RTO_T_TORCH);
+                rto_timer_start(ctx, RTO_T_FILTER);
+                CHECK_RTO(rto_filtering_batch(stream, w, gd, L, height, width, n, rto_ctx_noisy(ctx), rto_ctx_image(ctx)));
+                rto_timer_stop(ctx, RTO_T_FILTER);
+            }
+            CHECK_RTO(rto_timer_record(ctx, options.denoise));
+            rendered += (size_t)n;
+            if (out_dir.empty()) continue;
+            for (int f = 0; f < n; ++f) {
+                const size_t i = mine[g0 + f];
+                rto_ctx_select_frame(ctx, f);
+                if (write_buffer) {
+                    CHECK_RTO(rto_ctx_download_aux(ctx, stream, aux.data()));
+                    std::ofstream fo(out_dir + "/buf_" + ps.basenames[i] + ".bin", std::ios::binary);
+                    fo.write(reinterpret_cast<const char*>(aux.data()), (std::streamsize)(aux.size() * sizeof(float)));
+                } else {
+                    CHECK_RTO(rto_ctx_download_rgba8(ctx, stream, 0, rgba8.data()));
+                    if (!rto::write_png_rgba8(out_dir + "/" + ps.basenames[i] + ".png", rgba8.data(), width, height)) {
+                        std::fprintf(stderr, "ERROR: cannot write %s/%s.png\n", out_dir.c_str(), ps.basenames[i].c_str());
+                        return 1;
+                    }
+                }
+            }
+        }
+        float ms[3], fps;
+        int cnt;
+        rto_timer_report(ctx, ms, &fps, &cnt);
+        const float per_frame = rendered ? (float)groups / (float)rendered : 0.f;  // group means -> per frame
+        for (float& m : ms) m *= per_frame;
+        const float all = ms[0] + ms[1] + ms[2];
+        std::printf("render: %.10f ms per frame\n", ms[0]);
+        std::printf("torch:  %.10f ms per frame\n", ms[1]);
+        std::printf("filter: %.10f ms per frame\n", ms[2]);
+        std::printf("all:    %.10f ms per frame\n", all);
+        std::printf("FPS:    %.10f\n", all > 0 ? 1000.f / all : 0.f);
+        denoiser.reset();
+        rto_ctx_free(ctx);
+        rto_tree_free(tree);
+        return 0;
+    }
 
     for (size_t i = 0; i < ps.trans.size(); ++i) {  // :485-543
         if ((int)(i % shard_n) == shard_i) {

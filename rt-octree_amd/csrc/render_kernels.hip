@@ -1151,12 +1151,8 @@ static hipError_t launch_spp(int kernel, const TreeDev& tree, const CamDev& cam,
         if (fo.stats) {
             RTO_LAUNCH_FAST(true, 0);
         } else {
-            switch (variant & 3) {
-                case 0: RTO_LAUNCH_FAST(false, 0); break;
-                case 1: RTO_LAUNCH_FAST(false, 1); break;
-                case 2: RTO_LAUNCH_FAST(false, 2); break;
-                default: RTO_LAUNCH_FAST(false, 3); break;
-            }
+            (void)variant;  // the node-cache / priority-ramp instantiations measured slower and are not built
+            RTO_LAUNCH_FAST(false, 0);
         }
 #undef RTO_LAUNCH_FAST
     } else {
@@ -1226,22 +1222,11 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
     if (SPP == 6) {  // tuning instantiations only for the benchmark configuration
 #define RTO_B(R, O) return launch_batch_impl<SPP, R, O, false>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, ev, stream)
 #define RTO_F(R, O) return launch_batch_impl<SPP, R, O, true>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, ev, stream)
-        switch (refill) {
-            case 4: RTO_B(4, 8);
-            case 8: RTO_B(8, 8);
-            case 12: RTO_B(12, 8);
-            case 16: RTO_B(16, 8);
-            case 24: RTO_B(24, 8);
-            case 32: RTO_B(32, 8);
-            case 48: RTO_B(48, 8);
-            case 208: RTO_F(8, 8);
-            case 216: RTO_F(16, 8);
-            case 224: RTO_F(24, 8);
+        switch (refill) {  // A/B set kept for tools/batch_bench.py
+            case 24: RTO_B(24, 8);   // nested descent loop
+            case 208: RTO_F(8, 8);   // flat, refill at 8 / 32 idle lanes
             case 232: RTO_F(32, 8);
-            case 116: RTO_B(16, 6);
-            case 124: RTO_B(24, 6);
-            case 132: RTO_B(32, 6);
-            case 148: RTO_B(48, 6);
+            case 316: RTO_F(16, 6);  // flat, 6 waves/SIMD
             default: break;
         }
 #undef RTO_B

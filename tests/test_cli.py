@@ -206,3 +206,25 @@ def test_cli_pose_loader_llff(tmp_path):
         want = (inv @ p4)[:3, :4]
         assert np.allclose(m[i], want.T, atol=2e-5), i
     assert "Use LLFF camera convention" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_batch_equals_frame_loop(tmp_path):
+    """--batch 4 (persistent ray-queue kernel + batched libtorch forward + batched filter) writes the
+    same PNG bytes as the reference-style one-frame-per-launch loop."""
+    import torch
+    from rt_octree_amd import denoiser
+    tree, tp, poses, pp = _scene(tmp_path, n=6)
+    torch.manual_seed(0)
+    ts = denoiser.compact_and_compile(denoiser.GuidanceNet(8, 32, 5, 2, 4), device="cuda:0", example_hw=(48, 64))
+    tsp = str(tmp_path / "ts_latest.ts")
+    ts.save(tsp)
+    op = synth.write_opt_json(str(tmp_path / "opt.json"))
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    base = [tp, pp, "--options", op, "--ts_module", tsp, "-w", "64", "-h", "48", "--warmup", "2"]
+    r1 = _run(base + ["-o", a])
+    r4 = _run(base + ["-o", b, "--batch", "4"])
+    assert r1.returncode == 0 and r4.returncode == 0, r1.stderr + r4.stderr
+    assert "FPS:" in r4.stdout
+    for i in range(6):
+        assert open(os.path.join(a, "r_%d.png" % i), "rb").read() == open(os.path.join(b, "r_%d.png" % i), "rb").read(), i

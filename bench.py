@@ -62,6 +62,8 @@ def parse_args():
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores)")
     ap.add_argument("--tree", default="", help="render this tree.npz instead of the synthetic one")
+    ap.add_argument("--quant-direct", action="store_true",
+                    help="with --tree <quantised tree.npz>: render from the codebooks instead of the expanded fp16 tree")
     ap.add_argument("--torch-net", action="store_true", help="run GuidanceNet through PyTorch-ROCm (MIOpen) instead of the fused HIP kernel")
     return ap.parse_args()
 
@@ -122,7 +124,7 @@ def main():
             os.replace(path + ".tmp.npz", path)
             print("[bench] generated %s: %s in %.1fs" % (path, tree_host.stats, time.time() - t0), file=sys.stderr)
     barrier()
-    tree = R.N3Tree(path, device=local_rank)  # the reference's own input path: tree.npz -> device
+    tree = R.N3Tree(path, device=local_rank, quant_direct=args.quant_direct)  # the reference's own input path: tree.npz -> device
     poses = synth.orbit_poses(200)
     fx = synth.blender_focal(W)
     cams = []
@@ -213,13 +215,18 @@ def main():
     ctx.enable_stats(True)
     ctx.get_stats(reset=True)
     opt_nd = R.RenderOptions(spp=args.spp, denoise=False)
+    # the counting kernel shades from dense records: a codebook-direct tree is counted on its
+    # expanded twin (same traversal, same hits)
+    count_tree = R.N3Tree(path, device=local_rank) if args.quant_direct else tree
     for s in range(args.steps):  # same poses, same RNG bases as the timed frames
         i = pose_of(s)
         ctx.rng_seed()
         ctx.rng_advance((WARM_FRAMES_REF + i) << 32)
-        R.launch_renderer(tree, cams[i], opt_nd, ctx, stream)
+        R.launch_renderer(count_tree, cams[i], opt_nd, ctx, stream)
     units = ctx.get_stats(reset=True)
     ctx.enable_stats(False)
+    if count_tree is not tree:
+        count_tree.free()
     px = W * H
     alg_bytes_frame = (4 * units["levels"] + 2 * units["steps"] + 2 * (tree.data_dim - 1) * units["hit_leaves"]
                        + 48 * px * args.steps) / args.steps

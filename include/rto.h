@@ -117,6 +117,13 @@ int rto_options_from_json(const char* text, rto_options* o);
 /* N3Tree::open (n3tree.cpp:111-154) + load_cuda (n3tree.cu:9-41).  Reads `tree.npz` (dense fp16
  * `data`, or the quantised set quant_colors/quant_map/sigma[/data_retained]) and uploads it. */
 int rto_tree_load_npz(const char* path, int device, rto_tree** out);
+/* flags: RTO_TREE_QUANT_DIRECT keeps a quantised tree (quant_colors / quant_map / sigma
+ * [/ data_retained]) as stored and renders straight from the codebooks instead of expanding it to
+ * the dense fp16 layout: same pixels, a fraction of the footprint.  N == 2,
+ * SH4/9/16/25 only; such a tree renders through the batched kernels (also for single frames).
+ * Ignored for dense files. */
+#define RTO_TREE_QUANT_DIRECT 1
+int rto_tree_load_npz_ex(const char* path, int device, int flags, rto_tree** out);
 /* Same upload from host arrays: child int32 [capacity*N^3], data fp16 bits
  * [capacity*N^3*data_dim], data_format like "SH9"/"SH16"/"RGBA" (DataFormat::parse,
  * n3tree.cpp:55-78). */

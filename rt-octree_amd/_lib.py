@@ -55,6 +55,7 @@ SYMBOLS = {
     "rto_options_from_json_file": (C.c_int, [C.c_char_p, C.POINTER(COptions)]),
     "rto_options_from_json": (C.c_int, [C.c_char_p, C.POINTER(COptions)]),
     "rto_tree_load_npz": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
+    "rto_tree_load_npz_ex": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
     "rto_tree_from_arrays": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_char_p,
                                        C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
                                        C.POINTER(_P)]),
@@ -116,6 +117,25 @@ def build_library(force=False, verbose=False):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process: the PyTorch-ROCm wheel bundles its own libamdhip64.so (soname
+    libamdhip64.so.7, the name librto.so needs too).  Whichever copy is mapped first serves both, but
+    torch cannot find a GPU if it comes second behind /opt/rocm's -- so map torch's copy before
+    librto.so.  Without torch installed this is a no-op and /opt/rocm's runtime is used."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    for d in spec.submodule_search_locations:
+        cand = os.path.join(d, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def lib():
     """The loaded library with prototypes set.  Raises if librto.so is absent or lacks a symbol."""
     global _lib
@@ -124,6 +144,7 @@ def lib():
             raise RuntimeError(
                 "librto.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback for the render path)" % LIB_PATH)
+        _preload_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the symbol is missing

@@ -47,7 +47,7 @@ struct Args {
 const std::map<std::string, std::string> kShort = {{"w", "width"},      {"h", "height"},     {"s", "step_size"},
                                                    {"e", "stop_thresh"}, {"a", "sigma_thresh"}, {"o", "write_images"},
                                                    {"i", "intrin"},      {"r", "reverse_yz"}};
-const char* kFlags[] = {"reverse_yz", "write_buffer", "help", "print_poses"};
+const char* kFlags[] = {"reverse_yz", "write_buffer", "help", "print_poses", "quant_direct"};
 
 bool is_flag(const std::string& k) {
     for (const char* f : kFlags)
@@ -109,6 +109,7 @@ void usage() {
         "  --write_buffer  --max_imgs N  --scale S  -i intrin  -r,--reverse_yz\n"
         "  --shard i/N        render poses i, i+N, ... only     --warmup K (100)\n"
         "  --batch B          poses per launch (1..16, default 1 = the reference's frame loop)\n"
+        "  --quant_direct     render a quantised tree.npz from its codebooks (no expansion to dense fp16)\n"
         "  --print_poses      parse the poses, print them (column-major 4x3) and exit\n");
 }
 
@@ -168,7 +169,7 @@ int main(int argc, char** argv) {
     }
 
     rto_tree* tree = nullptr;
-    CHECK_RTO(rto_tree_load_npz(tree_path.c_str(), device, &tree));
+    CHECK_RTO(rto_tree_load_npz_ex(tree_path.c_str(), device, args.has("quant_direct") ? RTO_TREE_QUANT_DIRECT : 0, &tree));
     if (dataset == "llff") CHECK_RTO(rto_tree_set_ndc(tree, (float)ps.width, (float)ps.height, ps.fx));  // :400-405
 
     int width = ps.width, height = ps.height;

@@ -107,7 +107,7 @@ void unpack_llff(const NpyArray& pb, HostTree& t) {
 
 }  // namespace
 
-bool HostTree::open(const std::string& path) {
+bool HostTree::open(const std::string& path, bool keep_quantized) {
     if (path.size() <= 4 || path.substr(path.size() - 4) != ".npz")  // n3tree.cpp:119 (assert)
         throw std::runtime_error("tree file must end in .npz: " + path);
     if (!std::ifstream(path)) {
@@ -180,6 +180,23 @@ bool HostTree::open(const std::string& path) {
         if (sg.num_vals() < n_child || qm.num_vals() < (size_t)(n_basis - n_retain) * n_child)
             throw std::runtime_error("tree.npz: quantised arrays are too small for the tree");
         if (data_dim < 3 * n_basis + 1) throw std::runtime_error("tree.npz: data_dim too small for the quantised bases");
+        if (keep_quantized) {  // render straight from the codebooks: nothing is expanded
+            quantized = true;
+            this->n_basis = n_basis;
+            this->n_retain = n_retain;
+            q_map = qm.as<uint16_t>();
+            q_colors = qc.as<uint16_t>();
+            q_sigma = sg.as<uint16_t>();
+            if (n_retain) {
+                const NpyArray& rt = z.at("data_retained");
+                if (rt.word_size != 2 || rt.num_vals() < (size_t)n_retain * n_child * 3)
+                    throw std::runtime_error("tree.npz: data_retained must be fp16 [n_retain,capacity,N,N,N,3]");
+                q_retained = rt.as<uint16_t>();
+            }
+            if (qc.num_vals() < (size_t)(n_basis - n_retain) * 65536 * 3)
+                throw std::runtime_error("tree.npz: quant_colors must be [n_quantised,65536,3]");
+            data = nullptr;
+        } else {
         decoded.assign(n_child * (size_t)data_dim, 0);
         const uint16_t* sigma = sg.as<uint16_t>();
         const uint16_t* qmap = qm.as<uint16_t>();
@@ -216,6 +233,7 @@ bool HostTree::open(const std::string& path) {
             }
         }
         data = decoded.data();
+        }
     } else {
         const NpyArray& d = z.at("data");
         capacity = (int64_t)d.shape[0];

@@ -32,13 +32,21 @@ struct HostTree {
     float ndc_width = 0, ndc_height = 0, ndc_focal = 0;
     float ndc_avg_up[3] = {0, 0, 0}, ndc_avg_back[3] = {0, 0, 0}, ndc_avg_cen[3] = {0, 0, 0};
 
+    // quantised set kept as stored (open(path, /*keep_quantized=*/true)): `data` stays nullptr
+    bool quantized = false;
+    int n_basis = 0, n_retain = 0;
+    const uint16_t* q_map = nullptr;       // u16  [n_basis - n_retain][capacity*N^3]
+    const uint16_t* q_colors = nullptr;    // fp16 [n_basis - n_retain][65536][3]
+    const uint16_t* q_sigma = nullptr;     // fp16 [capacity*N^3]
+    const uint16_t* q_retained = nullptr;  // fp16 [n_retain][capacity*N^3][3]
+
     // keep-alives
     std::shared_ptr<NpzFile> npz;
     std::vector<uint16_t> decoded;  // quantised trees are expanded here
 
     // throws std::runtime_error (bad dtype / schema), returns false when the file does not exist
     // (the reference prints a message and leaves the tree empty, n3tree.cpp:123-126)
-    bool open(const std::string& path);
+    bool open(const std::string& path, bool keep_quantized = false);
 };
 
 // deepest leaf level (number of child[] loads to reach it), validating every offset on the way;

@@ -1035,59 +1035,233 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     }
 }
 
+// One hit leaf of a quantised tree, shaded straight from the codebooks (TreeDev::qrec / qcolors): the
+// coefficients are the very fp16 values N3Tree::load_npz would have expanded (n3tree.cpp:310-339),
+// summed in shade_leaf's order, so the pixel is bit-identical to rendering the decoded tree.
+template <int B>
+RTO_DEV void shade_leaf_quant(const TreeDev& tree, uint32_t slot, const float* basis_fn, float cnt, float* out) {
+    const int nr = tree.q_retain;
+    const uint16_t* __restrict__ rec = tree.qrec + (uint64_t)slot * (uint32_t)tree.q_rec;
+    float v[B][3];
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+        if (k < nr) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[k][c] = half_bits_to_float(rec[k * 3 + c]);
+        } else {
+            const uint32_t id = rec[2 * nr + k];  // 3 * nr + (k - nr)
+            const uint2 e = tree.qcolors[(uint32_t)(k - nr) * 65536u + id];
+            v[k][0] = half_bits_to_float((uint16_t)(e.x & 0xffffu));
+            v[k][1] = half_bits_to_float((uint16_t)(e.x >> 16));
+            v[k][2] = half_bits_to_float((uint16_t)(e.y & 0xffffu));
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float tmp = basis_fn[0] * v[0][c];
+        if constexpr (B >= 25) {
+            tmp += basis_fn[16] * v[16][c] + basis_fn[17] * v[17][c] + basis_fn[18] * v[18][c] +
+                   basis_fn[19] * v[19][c] + basis_fn[20] * v[20][c] + basis_fn[21] * v[21][c] +
+                   basis_fn[22] * v[22][c] + basis_fn[23] * v[23][c] + basis_fn[24] * v[24][c];
+        }
+        if constexpr (B >= 16) {
+            tmp += basis_fn[9] * v[9][c] + basis_fn[10] * v[10][c] + basis_fn[11] * v[11][c] +
+                   basis_fn[12] * v[12][c] + basis_fn[13] * v[13][c] + basis_fn[14] * v[14][c] +
+                   basis_fn[15] * v[15][c];
+        }
+        if constexpr (B >= 9) {
+            tmp += basis_fn[4] * v[4][c] + basis_fn[5] * v[5][c] + basis_fn[6] * v[6][c] + basis_fn[7] * v[7][c] +
+                   basis_fn[8] * v[8][c];
+        }
+        if constexpr (B >= 4) {
+            tmp += basis_fn[1] * v[1][c] + basis_fn[2] * v[2][c] + basis_fn[3] * v[3][c];
+        }
+        out[c] += cnt / (1.f + det_expf(-tmp));
+    }
+    out[3] += cnt;
+}
+
+// quant_map [nq][ns] + data_retained [nr][ns][3]  ->  slot-major records (TreeDev::qrec)
+__global__ void pack_quant_kernel(const uint16_t* __restrict__ qmap, const uint16_t* __restrict__ retained,
+                                  int64_t ns, int nr, int nq, int rec, uint16_t* __restrict__ out) {
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= ns) return;
+    uint16_t* o = out + slot * rec;
+    for (int k = 0; k < nr; ++k)
+        for (int c = 0; c < 3; ++c) o[k * 3 + c] = retained[((int64_t)k * ns + slot) * 3 + c];
+    for (int j = 0; j < nq; ++j) o[3 * nr + j] = qmap[(int64_t)j * ns + slot];
+    if (rec > 3 * nr + nq) o[rec - 1] = 0;
+}
+
+hipError_t launch_pack_quant(const uint16_t* qmap, const uint16_t* retained, int64_t ns, int nr, int nq, int rec,
+                             uint16_t* out, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_quant_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, qmap, retained, ns, nr,
+                       nq, rec, out);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ shading kernel
 // Second half of trace_ray (rt_core.cuh:272-331) + the pixel epilogue (volrend.cu:174-212) for the
-// batched path: one thread per pixel, pixel-linear so the 8 aux planes and the RGBA32F image are
-// written fully coalesced.  hits: [SPP][H*W] packed entries, kNoHit-terminated.
-template <int SPP>
+// batched path.  hits: [SPP][H*W] packed entries per frame, kNoHit-terminated.
+//
+// Only about a quarter of the pixels hit anything and those that do hold 1..SPP leaves, so a
+// thread-per-pixel loop leaves most lanes idle while the gathers of a few run.  Instead each wave
+// owns 64 * P consecutive pixels, compacts their hit entries into an LDS list (wave prefix sum),
+// shades the entries one per lane -- every lane busy, all of an entry's loads independent -- and
+// the pixel lanes then add their entries' contributions up in hit order, which keeps the float sums
+// those of the reference's loop.  The list is processed in windows of kShadeCap entries so LDS use
+// does not depend on SPP.
+constexpr int kShadeCap = 320;
+
+// contribution of one hit leaf: rgb[c] = cnt * sigmoid(<basis, coeffs_c>) (or cnt * rgb for RGBA trees)
+// MODE (host-chosen, so that each instantiation carries one leaf layout's registers only):
+// 0 any dense tree; 28 / 49 / 76 dense SH9 / SH16 / SH25 records; -B quantised SH<B>, not expanded
+template <int MODE>
+RTO_DEV void leaf_contrib(const TreeDev& tree, uint32_t slot, const float* basis_fn, float cnt, float* o) {
+    o[0] = o[1] = o[2] = o[3] = 0.f;  // 0 + x == x: the helpers' "+=" yields the bare term
+    if constexpr (MODE < 0) {
+        shade_leaf_quant<-MODE>(tree, slot, basis_fn, cnt, o);
+    } else if constexpr (MODE == 0) {
+        shade_leaf(tree, tree.data + (uint64_t)slot * tree.data_dim, basis_fn, cnt, o);
+    } else {
+        shade_leaf_packed<MODE>(tree, slot, basis_fn, cnt, o);
+    }
+}
+
+template <int SPP, int P, int MODE>
 __global__ void __launch_bounds__(256) shade_kernel(const TreeDev tree, const OptDev opt, const FrameBatch fb) {
+    __shared__ uint32_t s_h[4][kShadeCap];       // packed hit entry
+    __shared__ uint16_t s_q[4][kShadeCap];       // its pixel, relative to the wave's first pixel
+    __shared__ float s_c[4][3 * kShadeCap];      // its contribution, [channel][entry]
     const int W = fb.width, H = fb.height;
     const int64_t SIZE = (int64_t)W * H;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= SIZE) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t wave_px0 = ((int64_t)blockIdx.x * 4 + wv) * (64 * P);
+    if (wave_px0 >= SIZE) return;  // wave-uniform
     const FrameDesc& fd = fb.f[blockIdx.y];  // block-uniform index: scalar loads from the kernarg
-    float out[4] = {0.f, 0.f, 0.f, 0.f};
-    const uint32_t* hp = fd.hits + idx;
-    uint32_t h = hp[0];
-    if (h != kNoHit) {
-        const int x = idx % W, y = idx / W;
-        CamDev cam;
-        cam.width = W;
-        cam.height = H;
-        cam.fx = fd.fx;
-        cam.fy = fd.fy;
+
+    // ---- each lane: the hit lists of its P pixels (pixel p*64 + lane of the wave: coalesced)
+    uint32_t h[P][SPP];
+    uint32_t n[P];
+    uint32_t mine = 0;
 #pragma unroll
-        for (int i = 0; i < 12; ++i) cam.transform[i] = fd.transform[i];
-        float dir[3], vdir[3], cen[3];
-        ray_setup(x, y, cam, tree, dir, vdir, cen);  // only vdir is needed (rt_core.cuh:278)
-        float basis_fn[RTO_BASIS_MAX_DEV];
-        ray_basis(tree, opt, vdir, basis_fn);
-        for (int i = 0; i < SPP; ++i) {
-            const uint32_t slot = h & 0x07ffffffu;
-            const float cnt = (float)((h >> 27) + 1u);
-            if (tree.format == 1 && tree.data_dim == 28)
-                shade_leaf_packed<28>(tree, slot, basis_fn, cnt, out);
-            else if (tree.format == 1 && tree.data_dim == 49)
-                shade_leaf_packed<49>(tree, slot, basis_fn, cnt, out);
-            else if (tree.format == 1 && tree.data_dim == 76)
-                shade_leaf_packed<76>(tree, slot, basis_fn, cnt, out);
-            else
-                shade_leaf(tree, tree.data + (uint64_t)slot * tree.data_dim, basis_fn, cnt, out);
-            if (i + 1 == SPP) break;
-            h = hp[(int64_t)(i + 1) * SIZE];
-            if (h == kNoHit) break;
+    for (int p = 0; p < P; ++p) {
+        const int64_t idx = wave_px0 + p * 64 + lane;
+        n[p] = 0;
+        if (idx < SIZE) {
+            const uint32_t* hp = fd.hits + idx;
+            bool open = true;
+#pragma unroll
+            for (int i = 0; i < SPP; ++i) {
+                h[p][i] = kNoHit;
+                if (open) {
+                    h[p][i] = hp[(int64_t)i * SIZE];
+                    open = h[p][i] != kNoHit;
+                    n[p] += open ? 1u : 0u;
+                }
+            }
         }
-        constexpr float INV_SPP = 1.0f / SPP;
-        out[0] *= INV_SPP;
-        out[1] *= INV_SPP;
-        out[2] *= INV_SPP;
-        out[3] *= INV_SPP;
+        mine += n[p];
     }
+    // ---- wave exclusive prefix sum -> each pixel's range in the compacted list
+    uint32_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    const uint32_t total = __shfl(inc, 63, 64);
+    uint32_t start[P];
+    {
+        uint32_t sacc = inc - mine;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            start[p] = sacc;
+            sacc += n[p];
+        }
+    }
+    float out[P][4];
+#pragma unroll
+    for (int p = 0; p < P; ++p) out[p][0] = out[p][1] = out[p][2] = out[p][3] = 0.f;
+
+    CamDev cam;
+    cam.width = W;
+    cam.height = H;
+    cam.fx = fd.fx;
+    cam.fy = fd.fy;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) cam.transform[i] = fd.transform[i];
+
+    for (uint32_t w0 = 0; w0 < total; w0 += kShadeCap) {  // wave-uniform
+        // ---- pixel lanes publish the entries that fall into this window
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+#pragma unroll
+            for (int i = 0; i < SPP; ++i) {
+                const uint32_t pos = start[p] + i - w0;  // wraps to a huge value below the window
+                if ((uint32_t)i < n[p] && pos < (uint32_t)kShadeCap) {
+                    s_h[wv][pos] = h[p][i];
+                    s_q[wv][pos] = (uint16_t)(p * 64 + lane);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- one entry per lane
+        const uint32_t cnt_w = min(total - w0, (uint32_t)kShadeCap);
+        for (uint32_t j = lane; j < cnt_w; j += 64) {
+            const uint32_t he = s_h[wv][j];
+            const int64_t idx = wave_px0 + s_q[wv][j];
+            const int x = (int)(idx % W), y = (int)(idx / W);
+            float dir[3], vdir[3], cen[3];
+            ray_setup(x, y, cam, tree, dir, vdir, cen);  // only vdir is needed (rt_core.cuh:278)
+            float basis_fn[RTO_BASIS_MAX_DEV];
+            ray_basis(tree, opt, vdir, basis_fn);
+            float o[4];
+            leaf_contrib<MODE>(tree, he & 0x07ffffffu, basis_fn, (float)((he >> 27) + 1u), o);
+            s_c[wv][j] = o[0];
+            s_c[wv][kShadeCap + j] = o[1];
+            s_c[wv][2 * kShadeCap + j] = o[2];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- pixel lanes add their entries up, in hit order
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+#pragma unroll
+            for (int i = 0; i < SPP; ++i) {
+                const uint32_t pos = start[p] + i - w0;
+                if ((uint32_t)i < n[p] && pos < (uint32_t)kShadeCap) {
+                    out[p][0] += s_c[wv][pos];
+                    out[p][1] += s_c[wv][kShadeCap + pos];
+                    out[p][2] += s_c[wv][2 * kShadeCap + pos];
+                    out[p][3] += (float)((h[p][i] >> 27) + 1u);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
     FrameOut fo;
     fo.aux = fd.aux;
     fo.image = fd.image;
     fo.stats = nullptr;
-    write_pixel(fo, SIZE, idx, opt.background_brightness, out);
+    constexpr float INV_SPP = 1.0f / SPP;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int64_t idx = wave_px0 + p * 64 + lane;
+        if (idx >= SIZE) continue;
+        if (n[p]) {  // (a pixel without hits keeps its exact zeros, as before)
+            out[p][0] *= INV_SPP;
+            out[p][1] *= INV_SPP;
+            out[p][2] *= INV_SPP;
+            out[p][3] *= INV_SPP;
+        }
+        write_pixel(fo, SIZE, (int)idx, opt.background_brightness, out[p]);
+    }
 }
 
 // ------------------------------------------------------------------ u8 conversion
@@ -1208,7 +1382,30 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
     hipLaunchKernelGGL((render_persist<SPP, REFILL, WPS, FLAT>), dim3(grid), dim3(256), lds, stream, tree, opt, fb, queue, hits, chunk);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
     if (ev) (void)hipEventRecord(ev[1], stream);
-    hipLaunchKernelGGL(shade_kernel<SPP>, dim3((unsigned)((size + 255) / 256), fb.n), dim3(256), 0, stream, tree, opt, fb);
+#ifndef RTO_SHADE_P
+#define RTO_SHADE_P 2
+#endif
+    constexpr int SP = SPP <= 8 ? RTO_SHADE_P : 1;  // pixels per lane of the shading kernel (its hit lists live in registers)
+    const dim3 sgrid((unsigned)((size + 256 * SP - 1) / (256 * SP)), fb.n);
+#define RTO_SHADE(M) hipLaunchKernelGGL((shade_kernel<SPP, SP, M>), sgrid, dim3(256), 0, stream, tree, opt, fb)
+    if (tree.qrec) {  // (the host admits SH4/9/16/25 only)
+        if (tree.basis_dim == 4)
+            RTO_SHADE(-4);
+        else if (tree.basis_dim == 9)
+            RTO_SHADE(-9);
+        else if (tree.basis_dim == 16)
+            RTO_SHADE(-16);
+        else
+            RTO_SHADE(-25);
+    } else if (tree.format == 1 && tree.data_dim == 28)
+        RTO_SHADE(28);
+    else if (tree.format == 1 && tree.data_dim == 49)
+        RTO_SHADE(49);
+    else if (tree.format == 1 && tree.data_dim == 76)
+        RTO_SHADE(76);
+    else
+        RTO_SHADE(0);
+#undef RTO_SHADE
     if (ev) (void)hipEventRecord(ev[2], stream);
     return hipGetLastError();
 }

@@ -66,6 +66,10 @@ struct rto_tree {
     void* d_child = nullptr;
     void* d_nodew = nullptr;
     void* d_topgrid = nullptr;
+    void* d_qrec = nullptr;
+    void* d_qcolors = nullptr;
+    void* d_qsigma = nullptr;
+    bool quant = false;  // rendered from the codebooks; only the batched path can shade it
     bool fast_ok = false;
 };
 
@@ -148,9 +152,13 @@ int ensure_jump_table(rto_ctx* c, hipStream_t stream) {
 
 int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, int N, int data_dim,
                 const rto::DataFormat& fmt, const float scale[3], const float offset[3], int device,
-                rto_tree** out) {
-    if (!child || !data || capacity <= 0 || N < 1 || data_dim < 1 || !out)
+                rto_tree** out, const rto::HostTree* quant = nullptr) {
+    if (!child || (!data && !quant) || capacity <= 0 || N < 1 || data_dim < 1 || !out)
         return set_err(RTO_E_INVALID, "rto_tree: null array or non-positive size");
+    if (quant && (N != 2 || fmt.format != RTO_FMT_SH ||
+                  !(fmt.basis_dim == 4 || fmt.basis_dim == 9 || fmt.basis_dim == 16 || fmt.basis_dim == 25) ||
+                  quant->n_basis != fmt.basis_dim))
+        return set_err(RTO_E_UNSUPPORTED, "direct rendering of quantised trees needs N == 2 and SH4/9/16/25 with matching codebooks");
     if (fmt.format == RTO_FMT_SH || fmt.format == RTO_FMT_SG || fmt.format == RTO_FMT_ASG) {
         if (fmt.basis_dim < 1 || data_dim != 3 * fmt.basis_dim + 1)
             return set_err(RTO_E_FORMAT, "rto_tree: data_dim " + std::to_string(data_dim) + " does not match format " +
@@ -184,15 +192,45 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
         rto_tree_free(t);
         return set_err(code, msg);
     };
-    // +16 B: shade_leaf_packed reads whole dwords around a record and may touch up to 4 B past it
-    if (hipMalloc(&t->d_data, data_bytes + 16) != hipSuccess) return fail(RTO_E_HIP, "hipMalloc(tree.data) failed");
+    size_t dev_bytes = child_bytes;
     if (hipMalloc(&t->d_child, child_bytes) != hipSuccess) return fail(RTO_E_HIP, "hipMalloc(tree.child) failed");
-    if (hipMemcpy(t->d_data, data, data_bytes, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset((char*)t->d_data + data_bytes, 0, 16) != hipSuccess ||
-        hipMemcpy(t->d_child, child, child_bytes, hipMemcpyHostToDevice) != hipSuccess)
+    if (hipMemcpy(t->d_child, child, child_bytes, hipMemcpyHostToDevice) != hipSuccess)
         return fail(RTO_E_HIP, "tree upload failed");
-
-    size_t dev_bytes = data_bytes + 16 + child_bytes;
+    int q_rec = 0;
+    if (quant) {
+        const int nq = quant->n_basis - quant->n_retain, nr = quant->n_retain;
+        q_rec = (3 * nr + nq + 1) & ~1;  // u16 per slot record, dword aligned
+        const size_t map_b = (size_t)nq * n_slots * 2, ret_b = (size_t)nr * n_slots * 3 * 2, sig_b = (size_t)n_slots * 2;
+        const size_t rec_b = (size_t)n_slots * q_rec * 2, col_b = (size_t)nq * 65536 * 8;
+        // codebooks: {r,g,b} fp16 -> {r,g,b,0} so that one 8 B load fetches an entry
+        std::vector<uint16_t> cb((size_t)nq * 65536 * 4, 0);
+        for (size_t i = 0; i < (size_t)nq * 65536; ++i)
+            for (int c = 0; c < 3; ++c) cb[i * 4 + c] = quant->q_colors[i * 3 + c];
+        void *tmp_map = nullptr, *tmp_ret = nullptr;
+        auto up = [&](void** dst, const void* src, size_t bytes) {
+            if (bytes == 0) return true;
+            return hipMalloc(dst, bytes) == hipSuccess && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+        };
+        // file layout up, re-laid slot-major on the device, staging freed (peak = 2x the quantised arrays)
+        bool ok = up(&tmp_map, quant->q_map, map_b) && up(&tmp_ret, quant->q_retained, ret_b) &&
+                  up(&t->d_qcolors, cb.data(), col_b) && up(&t->d_qsigma, quant->q_sigma, sig_b) &&
+                  hipMalloc(&t->d_qrec, rec_b) == hipSuccess &&
+                  rto::launch_pack_quant((const uint16_t*)tmp_map, (const uint16_t*)tmp_ret, n_slots, nr, nq, q_rec,
+                                         (uint16_t*)t->d_qrec, nullptr) == hipSuccess &&
+                  hipDeviceSynchronize() == hipSuccess;
+        if (tmp_map) (void)hipFree(tmp_map);
+        if (tmp_ret) (void)hipFree(tmp_ret);
+        if (!ok) return fail(RTO_E_HIP, "quantised tree upload failed");
+        t->quant = true;
+        dev_bytes += rec_b + col_b + sig_b;
+    } else {
+        // +16 B: shade_leaf_packed reads whole dwords around a record and may touch up to 4 B past it
+        if (hipMalloc(&t->d_data, data_bytes + 16) != hipSuccess) return fail(RTO_E_HIP, "hipMalloc(tree.data) failed");
+        if (hipMemcpy(t->d_data, data, data_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemset((char*)t->d_data + data_bytes, 0, 16) != hipSuccess)
+            return fail(RTO_E_HIP, "tree upload failed");
+        dev_bytes += data_bytes + 16;
+    }
     // traversal image for the fast kernel: N == 2, depth within the 24 fixed-point bits, slot index
     // within the 27 bits of a hit-list entry
     if (N == 2 && max_depth <= 24 && n_slots < (int64_t(1) << 27)) {
@@ -200,8 +238,11 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
         if (hipMalloc(&t->d_nodew, (size_t)n_slots * 4) != hipSuccess || hipMalloc((void**)&d_bad, 4) != hipSuccess ||
             hipMemset(d_bad, 0, 4) != hipSuccess)
             return fail(RTO_E_HIP, "hipMalloc(nodew) failed");
-        hipError_t e = rto::launch_build_nodew((const int32_t*)t->d_child, (const uint16_t*)t->d_data, n_slots,
-                                               data_dim, (uint32_t*)t->d_nodew, d_bad, nullptr);
+        // sigma source: the last value of each dense record, or the quantised set's own sigma array
+        hipError_t e = quant ? rto::launch_build_nodew((const int32_t*)t->d_child, (const uint16_t*)t->d_qsigma, n_slots, 1,
+                                                       (uint32_t*)t->d_nodew, d_bad, nullptr)
+                             : rto::launch_build_nodew((const int32_t*)t->d_child, (const uint16_t*)t->d_data, n_slots,
+                                                       data_dim, (uint32_t*)t->d_nodew, d_bad, nullptr);
         int bad = 0;
         if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost);
         (void)hipFree(d_bad);
@@ -228,8 +269,18 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
     }
 
     rto::TreeDev& d = t->dev;
+    if (t->d_qsigma) {  // sigma now lives in the traversal image
+        (void)hipFree(t->d_qsigma);
+        t->d_qsigma = nullptr;
+        dev_bytes -= (size_t)n_slots * 2;
+    }
+    if (quant && !t->fast_ok) return fail(RTO_E_UNSUPPORTED, "direct rendering of quantised trees needs the N == 2 traversal image");
     d.topgrid = (const uint2*)t->d_topgrid;
     d.top_levels = top_levels;
+    d.qrec = (const uint16_t*)t->d_qrec;
+    d.qcolors = (const uint2*)t->d_qcolors;
+    d.q_retain = quant ? quant->n_retain : 0;
+    d.q_rec = q_rec;
     d.data = (const uint16_t*)t->d_data;
     d.child = (const int32_t*)t->d_child;
     d.nodew = (const uint32_t*)t->d_nodew;
@@ -349,16 +400,20 @@ int rto_options_from_json_file(const char* path, rto_options* o) {
     return rto_options_from_json(ss.str().c_str(), o);
 }
 
-int rto_tree_load_npz(const char* path, int device, rto_tree** out) {
+int rto_tree_load_npz(const char* path, int device, rto_tree** out) { return rto_tree_load_npz_ex(path, device, 0, out); }
+
+int rto_tree_load_npz_ex(const char* path, int device, int flags, rto_tree** out) {
     if (!path || !out) return set_err(RTO_E_INVALID, "rto_tree_load_npz: null argument");
     rto::HostTree h;
     try {
-        if (!h.open(path)) return set_err(RTO_E_IO, std::string("file does not exist: ") + path);
+        if (!h.open(path, (flags & RTO_TREE_QUANT_DIRECT) != 0))
+            return set_err(RTO_E_IO, std::string("file does not exist: ") + path);
     } catch (const std::exception& e) {
         return set_err(RTO_E_FORMAT, e.what());
     }
     std::fprintf(stdout, "INFO: Scale %f %f %f\n", h.scale[0], h.scale[1], h.scale[2]);  // n3tree.cpp:264
-    int rc = upload_tree(h.child, h.data, h.capacity, h.N, h.data_dim, h.data_format, h.scale, h.offset, device, out);
+    int rc = upload_tree(h.child, h.data, h.capacity, h.N, h.data_dim, h.data_format, h.scale, h.offset, device, out,
+                         h.quantized ? &h : nullptr);
     if (rc != RTO_OK) return rc;
     if (h.use_ndc) rto_tree_set_ndc(*out, h.ndc_width, h.ndc_height, h.ndc_focal);
     return RTO_OK;
@@ -445,6 +500,8 @@ void rto_tree_free(rto_tree* t) {
     if (t->d_child) (void)hipFree(t->d_child);
     if (t->d_nodew) (void)hipFree(t->d_nodew);
     if (t->d_topgrid) (void)hipFree(t->d_topgrid);
+    for (void* p : {t->d_qrec, t->d_qcolors, t->d_qsigma})
+        if (p) (void)hipFree(p);
     delete t;
 }
 
@@ -659,9 +716,17 @@ int rto_ctx_get_stats(rto_ctx* c, void* stream_, uint64_t out[6], int reset) {
     return RTO_OK;
 }
 
+static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const int64_t* rng_jumps, int n,
+                           const rto_options* o, rto_ctx* ctx, void* stream_, int slot0);
+
 int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_options* o, rto_ctx* ctx,
                         void* stream_) {
     if (!tree || !cam || !o || !ctx) return set_err(RTO_E_INVALID, "rto_launch_renderer: null argument");
+    if (tree->quant) {  // codebook shading lives in the batched kernels: a batch of one into the selected slot
+        if (ctx->kernel == RTO_KERNEL_GENERIC || ctx->stats_on)
+            return set_err(RTO_E_UNSUPPORTED, "a quantised tree loaded with RTO_TREE_QUANT_DIRECT has no generic kernel / work counters");
+        return launch_batch_at(tree, cam, nullptr, 1, o, ctx, stream_, ctx->sel);
+    }
     if (!spp_supported(o->spp))  // volrend.cu:275-277
         return set_err(RTO_E_SPP, "spp == " + std::to_string(o->spp) + " not supported. (supported: 1,2,3,4,6,8,16,32)");
     if (cam->width != ctx->width || cam->height != ctx->height)
@@ -720,8 +785,15 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
 
 int rto_launch_renderer_batch(const rto_tree* tree, const rto_camera* cams, const int64_t* rng_jumps, int n,
                               const rto_options* o, rto_ctx* ctx, void* stream_) {
+    return launch_batch_at(tree, cams, rng_jumps, n, o, ctx, stream_, 0);
+}
+
+// frames 0..n-1 of the batch land in context slots slot0..slot0+n-1
+static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const int64_t* rng_jumps, int n,
+                           const rto_options* o, rto_ctx* ctx, void* stream_, int slot0) {
     if (!tree || !cams || !o || !ctx) return set_err(RTO_E_INVALID, "rto_launch_renderer_batch: null argument");
-    if (n < 1 || n > ctx->frames) return set_err(RTO_E_INVALID, "rto_launch_renderer_batch: n exceeds the context's frame slots");
+    if (n < 1 || slot0 < 0 || slot0 + n > ctx->frames)
+        return set_err(RTO_E_INVALID, "rto_launch_renderer_batch: n exceeds the context's frame slots");
     if (!spp_supported(o->spp))
         return set_err(RTO_E_SPP, "spp == " + std::to_string(o->spp) + " not supported. (supported: 1,2,3,4,6,8,16,32)");
     if (tree->device != ctx->device) return set_err(RTO_E_INVALID, "tree and context live on different devices");
@@ -766,9 +838,10 @@ int rto_launch_renderer_batch(const rto_tree* tree, const rto_camera* cams, cons
         const rto::PcgJumpEntry j = pcg_jump(ctx->rng.inc, (uint64_t)jumps << 32);
         d.rng_state = j.mult * ctx->rng.state + j.plus;
         d.rng_inc = ctx->rng.inc;
-        d.aux = ctx->aux + (size_t)f * RTO_AUX_CHANNELS * px;
-        d.image = (o->denoise ? ctx->noisy : ctx->image) + (size_t)f * 4 * px;
-        d.hits = ctx->hits + (size_t)f * o->spp * px;
+        const size_t slot = (size_t)(slot0 + f);
+        d.aux = ctx->aux + slot * RTO_AUX_CHANNELS * px;
+        d.image = (o->denoise ? ctx->noisy : ctx->image) + slot * 4 * px;
+        d.hits = ctx->hits + slot * o->spp * px;
     }
     hipStream_t stream = (hipStream_t)stream_;
     int rc = ensure_jump_table(ctx, stream);
@@ -782,7 +855,9 @@ int rto_launch_renderer_batch(const rto_tree* tree, const rto_camera* cams, cons
     od.basis_minmax[1] = o->basis_minmax[1];
     hipEvent_t* ev = nullptr;
     if (ctx->kt_on && ctx->kt_count < kKtRing) ev = &ctx->kt_ev[(size_t)ctx->kt_count++ * 3];
-    hipError_t e = rto::launch_render_batch(o->spp, tree->dev, od, fb, ctx->jump, ctx->queue, ctx->hits, ctx->num_cus, ctx->refill, ev, stream);
+    hipError_t e = rto::launch_render_batch(o->spp, tree->dev, od, fb, ctx->jump, ctx->queue,
+                                            ctx->hits + (size_t)slot0 * o->spp * px,  // = fb.f[0].hits: the kernel indexes frames from here
+                                            ctx->num_cus, ctx->refill, ev, stream);
     if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("batched render launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
 }

@@ -31,6 +31,18 @@ struct TreeDev {
     // above level G costs this one 8-byte, L2-resident load.  nullptr / 0 when absent.
     const uint2* topgrid;
     int top_levels;
+    // Quantised tree rendered WITHOUT expansion (the inputs of n3tree.cpp:279-340):
+    // `data` is nullptr; per leaf slot one record of q_rec u16 values, `qrec[slot * q_rec + ...]`:
+    //   [3 * q_retain] fp16 retained coefficients, (basis k, channel c) at k * 3 + c
+    //   [n_basis - q_retain] codebook indices of the quantised basis functions
+    //   (+ one pad value when the count is odd)
+    // and per quantised basis function a 65536-entry codebook of {r, g, b, 0} fp16 (8 B entries).
+    // Same bytes as quant_map + data_retained of the file, slot-major so that one hit leaf touches
+    // one or two cache lines instead of one per basis function.
+    const uint16_t* qrec;
+    const uint2* qcolors;  // [n_basis - q_retain][65536]
+    int q_retain;
+    int q_rec;
 };
 
 struct CamDev {

@@ -27,6 +27,10 @@ hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, 
                                const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
                                int refill, hipEvent_t* ev, hipStream_t stream);
 
+// quant_map [nq][ns] + data_retained [nr][ns][3] -> slot-major records of `rec` u16 (TreeDev::qrec)
+hipError_t launch_pack_quant(const uint16_t* qmap, const uint16_t* retained, int64_t ns, int nr, int nq, int rec,
+                             uint16_t* out, hipStream_t stream);
+
 hipError_t launch_rgba8(const float* rgba, uint8_t* out, int64_t n_pixels, hipStream_t stream);
 
 // denoiser/extension/filtering.cu:108-228,440-470: L levels, support = level + 1

@@ -86,6 +86,54 @@ class SynthTree:
         (np.savez_compressed if compressed else np.savez)(path, **kw)
         return path
 
+    def save_quant_npz(self, path, n_retain=1, compressed=False):
+        """The quantised schema of octree/compression.py (decoded by n3tree.cpp:279-340): basis
+        functions 0..n_retain-1 stay fp16 (`data_retained`), every other basis function gets a
+        65536-entry RGB codebook (`quant_colors`) + a uint16 index per leaf slot (`quant_map`).
+        The quantiser here is a cheap stand-in for the reference's k-means: slots are ordered by
+        luminance of the coefficient triple and cut into 65536 equal-count cells, codebook entry =
+        cell mean.  Returns the decoded dense data (what N3Tree::load_npz would expand to)."""
+        cap, D = self.capacity, self.data_dim
+        nb = (D - 1) // 3
+        assert self.data_format.startswith("SH") and 0 <= n_retain <= nb
+        n_child = cap * 8
+        flat = self.data.reshape(n_child, D)
+        nq = nb - n_retain
+        retained = np.zeros((n_retain, n_child, 3), np.float16)
+        for k in range(n_retain):
+            for c in range(3):
+                retained[k, :, c] = flat[:, c * nb + k]
+        qcolors = np.zeros((nq, 65536, 3), np.float16)
+        qmap = np.zeros((nq, n_child), np.uint16)
+        for j in range(nq):
+            k = j + n_retain
+            tri = np.stack([flat[:, c * nb + k] for c in range(3)], 1).astype(np.float32)
+            order = np.argsort(tri @ np.array([0.299, 0.587, 0.114], np.float32), kind="stable")
+            cell = (np.arange(n_child, dtype=np.int64) * 65536 // n_child).astype(np.int64)
+            ids = np.empty(n_child, np.int64)
+            ids[order] = cell
+            cnt = np.maximum(np.bincount(ids, minlength=65536), 1)
+            for c in range(3):
+                qcolors[j, :, c] = (np.bincount(ids, weights=tri[:, c], minlength=65536) / cnt).astype(np.float16)
+            qmap[j] = ids.astype(np.uint16)
+        sigma = np.ascontiguousarray(flat[:, D - 1]).reshape(cap, 2, 2, 2)
+        kw = dict(data_dim=np.int64(D), data_format=np.array(self.data_format),
+                  invradius3=self.scale.astype(np.float32), offset=self.offset.astype(np.float32),
+                  child=self.child, quant_colors=qcolors, quant_map=qmap.reshape(nq, cap, 2, 2, 2), sigma=sigma)
+        if n_retain:
+            kw["data_retained"] = retained.reshape(n_retain, cap, 2, 2, 2, 3)
+        (np.savez_compressed if compressed else np.savez)(path, **kw)
+        dec = np.zeros((n_child, D), np.float16)
+        for k in range(n_retain):
+            for c in range(3):
+                dec[:, c * nb + k] = retained[k, :, c]
+        for j in range(nq):
+            col = qcolors[j][qmap[j]]
+            for c in range(3):
+                dec[:, c * nb + j + n_retain] = col[:, c]
+        dec[:, D - 1] = flat[:, D - 1]
+        return dec.reshape(self.data.shape)
+
 
 def make_tree(depth_limit=6, basis_dim=9, seed=20230418, shell=1.25, radius=1.5, sdf=scene_sdf,
               max_nodes=None):

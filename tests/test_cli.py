@@ -228,3 +228,23 @@ def test_cli_batch_equals_frame_loop(tmp_path):
     assert "FPS:" in r4.stdout
     for i in range(6):
         assert open(os.path.join(a, "r_%d.png" % i), "rb").read() == open(os.path.join(b, "r_%d.png" % i), "rb").read(), i
+
+
+@pytest.mark.gpu
+def test_cli_quant_direct_equals_expanded(tmp_path):
+    """--quant_direct (codebook shading, no dense expansion) writes the same PNG bytes as the
+    reference's decode-then-render route (n3tree.cpp:279-340), single frames and batches."""
+    tree, _, poses, pp = _scene(tmp_path, n=4)
+    qp = str(tmp_path / "tree_q.npz")
+    tree.save_quant_npz(qp, n_retain=1)
+    op = synth.write_opt_json(str(tmp_path / "opt.json"), denoise=False)
+    a, b, c = (str(tmp_path / x) for x in "abc")
+    base = [qp, pp, "--options", op, "-w", "64", "-h", "48", "--warmup", "2"]
+    ra = _run(base + ["-o", a])
+    rb = _run(base + ["-o", b, "--quant_direct"])
+    rc = _run(base + ["-o", c, "--quant_direct", "--batch", "4"])
+    assert ra.returncode == 0 and rb.returncode == 0 and rc.returncode == 0, ra.stderr + rb.stderr + rc.stderr
+    for i in range(4):
+        ref = open(os.path.join(a, "r_%d.png" % i), "rb").read()
+        assert ref == open(os.path.join(b, "r_%d.png" % i), "rb").read(), i
+        assert ref == open(os.path.join(c, "r_%d.png" % i), "rb").read(), i

@@ -174,27 +174,28 @@ float orc_det_expf(float x) {
 
 /*
  * Deterministic fp32-only expf for the filter's softmax taps (164 per pixel at L = 4): the same
- * structure in float arithmetic -- k = rint(x log2 e) by the 1.5*2^23 trick, two-term Cody-Waite
- * reduction, degree-7 Taylor, exponent-bit scaling.  Max error 1 ulp on [-87.3, 88.7] (measured in
- * tests/test_oracle_kat.py); results below FLT_MIN flush to 0.  The reference's __expf
- * (filtering.cu:191) is ex2.approx(x*log2e), ~2 ulp: this definition is at least as accurate.
+ * structure in float arithmetic, every multiply-add an explicit fmaf -- k = rint(x log2 e) by the
+ * 1.5*2^23 trick, two-term Cody-Waite reduction, degree-7 Taylor (Horner), exponent-bit scaling.
+ * Max error 0.9 ulp on [-87.3, 88.7] (measured in tests/test_oracle_kat.py); results below FLT_MIN
+ * flush to 0.  The reference's __expf (filtering.cu:195) is ex2.approx(x*log2e), ~2 ulp plus the
+ * rounding of x*log2e: this definition is at least as accurate.  fmaf is correctly rounded on both
+ * sides (glibc / v_fma_f32), so the HIP kernel reproduces these bits.
  */
 float orc_fexp(float x) {
     if (x != x) return x;
     if (x > 88.72283935546875f) return INFINITY;
     if (x < -87.33654022216797f) return 0.0f;
-    const float t = x * 1.44269502162933349609375f;
-    const float kf = (t + 12582912.0f) - 12582912.0f;
-    float r = x - kf * 0.693145751953125f;
-    r = r - kf * 1.42860676533018704e-06f;
+    const float kf = fmaf(x, 1.44269502162933349609375f, 12582912.0f) - 12582912.0f;
+    float r = fmaf(kf, -0.693145751953125f, x);
+    r = fmaf(kf, -1.42860676533018704e-06f, r);
     float p = 1.0f / 5040.0f;
-    p = p * r + 1.0f / 720.0f;
-    p = p * r + 1.0f / 120.0f;
-    p = p * r + 1.0f / 24.0f;
-    p = p * r + 1.0f / 6.0f;
-    p = p * r + 0.5f;
-    p = p * r + 1.0f;
-    p = p * r + 1.0f;
+    p = fmaf(p, r, 1.0f / 720.0f);
+    p = fmaf(p, r, 1.0f / 120.0f);
+    p = fmaf(p, r, 1.0f / 24.0f);
+    p = fmaf(p, r, 1.0f / 6.0f);
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
     int ki = (int)kf;
     if (ki > 127) { ki = 127; p = p * 2.0f; } /* 2^128 has no fp32 encoding */
     union { uint32_t u; float f; } sc;
@@ -608,9 +609,12 @@ int orc_filter(int L, int H, int W, const float* weight, const float* guidance, 
                         kernel_sum += k;
                         const float* t = noisy + ((int64_t)qy * W + qx) * 4;
                         float tr = in ? t[0] : 0.f, tg = in ? t[1] : 0.f, tb = in ? t[2] : 0.f;
-                        r += tr * k;
-                        gg += tg * k;
-                        b += tb * k;
+                        /* rgba.x += t_rgb.x * k (:197-199): nvcc contracts this to an FMA (the
+                         * extension is built with nvcc's defaults, network.py:16-18: -fmad=true);
+                         * stated explicitly so CPU and GPU agree */
+                        r = fmaf(tr, k, r);
+                        gg = fmaf(tg, k, gg);
+                        b = fmaf(tb, k, b);
                     }
                 const float inv = 1.0f / kernel_sum;                 /* :201 */
                 const float w = wm[(int64_t)iy * W + ix] * inv;      /* :215 */

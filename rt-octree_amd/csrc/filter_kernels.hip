@@ -15,8 +15,8 @@
 //   m = max_q g(q);  k_q = exp(g(q) - m);  out += (sum_q k_q rgb(q)) * (w(p) / sum_q k_q)
 // Out-of-image taps: rgb = 0, g = -FLT_MAX (:140-143).
 //
-// Roofline: VALU-bound, not HBM-bound -- (2S+1)^2 taps of ~33 fp32 instructions each (the exp is
-// 25 of them) against 48 B of traffic per pixel.  The tap loops are kept rolled per window row so
+// Roofline: VALU-bound, not HBM-bound -- (2S+1)^2 taps of ~13 fp32 instructions each (the packed exp
+// is 9 of them) against 48 B of traffic per pixel.  The tap loops are kept rolled per window row so
 // the kernel stays at <= 128 VGPRs (4 waves/SIMD); fully unrolled it needs 256 VGPRs and runs one
 // wave per SIMD.
 #include <hip/hip_runtime.h>
@@ -52,21 +52,21 @@ RTO_DEV void filter_level(const float* __restrict__ g, const float4* __restrict_
             const float2v k2 = fexp_f32_le88_x2(x2);
             const float4 t0 = rgb[e0 + dx], t1 = rgb[e0 + dx + 1];
             kernel_sum += k2.x;
-            r += t0.x * k2.x;
-            gg += t0.y * k2.x;
-            b += t0.z * k2.x;
+            r = __builtin_fmaf(t0.x, k2.x, r);  // (explicit FMA, as in the oracle: nvcc contracts the
+            gg = __builtin_fmaf(t0.y, k2.x, gg);  // reference's `rgba.x += t_rgb.x * k` the same way)
+            b = __builtin_fmaf(t0.z, k2.x, b);
             kernel_sum += k2.y;
-            r += t1.x * k2.y;
-            gg += t1.y * k2.y;
-            b += t1.z * k2.y;
+            r = __builtin_fmaf(t1.x, k2.y, r);
+            gg = __builtin_fmaf(t1.y, k2.y, gg);
+            b = __builtin_fmaf(t1.z, k2.y, b);
         }
         {  // the window is 2S+1 wide: one tap left
             const float k = fexp_f32_le88(g[e0 + S] - max_val);
             kernel_sum += k;
             const float4 t = rgb[e0 + S];
-            r += t.x * k;
-            gg += t.y * k;
-            b += t.z * k;
+            r = __builtin_fmaf(t.x, k, r);
+            gg = __builtin_fmaf(t.y, k, gg);
+            b = __builtin_fmaf(t.z, k, b);
         }
     }
     const float inv = 1.0f / kernel_sum;

@@ -634,27 +634,41 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
 //   * the end-of-queue drain happens once per batch instead of once per frame.
 // Per-ray arithmetic is exactly render_fast's; results are bit-identical.
 
+// min(max(x, 0), 1 - 1e-6) (n3tree_query.hpp:20-24 clamp) as one v_med3_f32: the same value for every
+// finite x (the sign of a zero result may differ, which no later operation can observe: the
+// fixed-point conversion, fract * invdir and the sums that follow give the same numbers)
+RTO_DEV float clamp_unit(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f - 1e-6f); }
+
 // the per-ray state that survives between march steps (thresholds live in LDS, hits go straight
 // to the hand-off buffer)
 struct RayState {
-    float cen[3], dir[3], invdir[3], addv[3];  // addv[i] = invdir[i] > 0 ? invdir[i] : 0
+    float cen[3], dir[3], invdir[3];
+    float pos[3];  // clamp(cen + t * dir, 0, 1 - 1e-6): the point the next march step starts from
     float delta_scale, t, tmax, src, cur;      // cur = next threshold to cross (dst[spp])
     uint32_t spp, sh_nums;
     uint32_t pix, piy, piz;
-    int prev_lvl;   // FLAT: level of the node about to be visited
+    int prev_lvl;   // level of the node about to be visited
     uint32_t hoff;  // index of this pixel's first hit entry in the hand-off buffer
-    uint32_t node;  // FLAT: node about to be visited; kGridNext = the top grid is visited next
+    uint32_t node;  // node about to be visited; kGridNext = the top grid is visited next
 };
 constexpr uint32_t kGridNext = 0xffffffffu;
 
-// queue index -> (frame, x, y); 64 rays per 8x8 tile, tiles in `tile_order` (ty << 16 | tx per
-// queue position: centre-out, so a frame's queue ends on its cheap border tiles) or row-major when
-// no table is given; returns false for padding
-RTO_DEV bool ray_pixel(uint32_t r, uint32_t rays_per_frame, int tiles8_x, int width, int height,
-                       const uint32_t* __restrict__ tile_order, int& frame, int& x, int& y) {
-    frame = (int)(r / rays_per_frame);
-    const uint32_t q = r - (uint32_t)frame * rays_per_frame;
-    const int tile = (int)(q >> 6), l = (int)(q & 63u);
+// position p of a ray queue -> (frame, x, y).  The queue holds `qtiles` tiles per frame, frame after
+// frame, 64 rays per 8x8 tile: tile_order[qt0 + j] (ty << 16 | tx) or, without a table, row-major
+// tile qt0 + j.  Returns false for padding (tile overhanging the image).
+RTO_DEV bool ray_pixel(uint32_t p, uint32_t qt0, uint32_t qtiles, uint32_t n_frames, bool tile_major, int tiles8_x,
+                       int width, int height, const uint32_t* __restrict__ tile_order, int& frame, int& x, int& y) {
+    int tile;
+    const int l = (int)(p & 63u);
+    const uint32_t pt = p >> 6;  // tile slot within the queue
+    if (tile_major) {  // slot = tile * n_frames + frame
+        const uint32_t t = pt / n_frames;
+        frame = (int)(pt - t * n_frames);
+        tile = (int)(qt0 + t);
+    } else {  // slot = frame * qtiles + tile
+        frame = (int)(pt / qtiles);
+        tile = (int)(qt0 + (pt - (uint32_t)frame * qtiles));
+    }
     int ty, tx;
     if (tile_order) {
         const uint32_t code = tile_order[tile];
@@ -700,15 +714,15 @@ __global__ void __launch_bounds__(256) sample_kernel(const FrameBatch fb, const 
 }
 
 // REFILL = idle lanes that trigger a retire + refill round
-// FLAT: one node visit (one load) per lane per loop iteration -- a lane either descends one level or,
+// Flat traversal: one node visit (one load) per lane per loop iteration -- a lane either descends one level or,
 // at a leaf, takes its march step and picks the restart node of the next one -- instead of a nested
 // "descend until leaf" loop whose trip count is the maximum over the wave (measured: 1.4 loads per
 // lane-step on average, but ~4 per wave-step for the slowest lane).
-template <int SPP, int REFILL, int WPS, bool FLAT>
+template <int SPP, int REFILL, int WPS>
 __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, const OptDev opt, const FrameBatch fb,
                                                        unsigned long long* __restrict__ queue,
                                                        uint32_t* __restrict__ hits, const uint32_t chunk) {
-    // queue[0]: next ray of the batch; queue[1]: waves that have left (the last one re-arms both)
+    // queue[8 + 8k]: next ray of queue k; queue[1]: waves that have left (the last one re-arms all)
     // LDS: [max_depth+1][256] ancestor stack | [SPP+1][256] sorted thresholds | frame table
     extern __shared__ uint32_t s_mem[];
     const int tid = threadIdx.x;
@@ -716,16 +730,24 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     const int stack_levels = tree.max_depth + 1 - tree.top_levels;  // levels top_levels.. only
     float* s_dst = reinterpret_cast<float*>(s_mem + (size_t)stack_levels * 256) + tid;
     FrameDesc* s_frames = reinterpret_cast<FrameDesc*>(s_mem + (size_t)(stack_levels + SPP + 1) * 256);
+    __shared__ int s_qstart[kMaxQueues + 1];
 #pragma unroll
     for (int f = 0; f < kMaxBatch; ++f)  // static indices: the kernarg struct is never address-taken
         if (tid == f) s_frames[f] = fb.f[f];
+#pragma unroll
+    for (int k = 0; k <= kMaxQueues; ++k)
+        if (tid == 64 + k) s_qstart[k] = fb.qstart[k];
     __syncthreads();
 
     const int W = fb.width, H = fb.height;
     const uint32_t SIZE = (uint32_t)W * (uint32_t)H;
     const int tiles8_x = (W + 7) >> 3, tiles8_y = (H + 7) >> 3;
-    const uint32_t rays_per_frame = (uint32_t)(tiles8_x * tiles8_y) * 64u;
-    const uint32_t total = rays_per_frame * (uint32_t)fb.n;
+    (void)tiles8_y;
+    // the queue this wave draws from first: the one of the XCD it runs on (HW_REG_XCC_ID bits 3:0)
+    const uint32_t n_queues = (uint32_t)fb.n_queues;
+    uint32_t cur_q = n_queues > 1 ? ((uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % n_queues) : 0u;
+    uint32_t q_tried = 0;            // queues found empty so far (wave-uniform)
+    uint32_t res_t0 = 0, res_tiles = 1;  // tile range of the queue the reservoir was drawn from
 
     // Loop-invariant scalars pinned in SGPRs: under the 8-waves/SIMD register budget hipcc
     // otherwise re-loads them from the kernarg segment inside the descent loop (an s_load +
@@ -771,15 +793,27 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                 // the global queue kChunk rays (kChunk/64 tiles) at a time: one device-scope atomic per
                 // kChunk rays instead of one per refill (a single counter sustains only ~90 dequeues/us).
                 if (res_next == res_end) {
-                    unsigned long long base = 0;
-                    if ((tid & 63) == 0) base = atomicAdd(queue, (unsigned long long)kChunk);
-                    const uint32_t base32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
-                    if (base32 >= total) {  // the counter never exceeds total + kChunk * waves: fits 32 bits
-                        drained = true;
-                        break;
+                    for (;;) {  // own queue first, then the others in turn (wave-uniform)
+                        const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane(s_qstart[cur_q]);
+                        const uint32_t t1 = (uint32_t)__builtin_amdgcn_readfirstlane(s_qstart[cur_q + 1]);
+                        const uint32_t qtotal = (t1 - t0) * 64u * (uint32_t)fb.n;
+                        unsigned long long base = 0;
+                        if ((tid & 63) == 0) base = atomicAdd(queue + 8 + 8 * cur_q, (unsigned long long)kChunk);
+                        const uint32_t base32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+                        if (base32 < qtotal) {  // a counter never exceeds qtotal + kChunk * waves: fits 32 bits
+                            res_next = base32;
+                            res_end = base32 + kChunk < qtotal ? base32 + kChunk : qtotal;
+                            res_t0 = t0;
+                            res_tiles = t1 - t0;
+                            break;
+                        }
+                        if (++q_tried >= n_queues) {
+                            drained = true;
+                            break;
+                        }
+                        cur_q = cur_q + 1 == n_queues ? 0u : cur_q + 1;
                     }
-                    res_next = base32;
-                    res_end = base32 + kChunk < total ? base32 + kChunk : total;
+                    if (drained) break;
                 }
                 const uint32_t take = (uint32_t)n_need < res_end - res_next ? (uint32_t)n_need : res_end - res_next;
                 const uint32_t first = res_next;
@@ -789,7 +823,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
                     const uint32_t r = first + rank;
                     int frame, x, y;
-                    if (rank < take && ray_pixel(r, rays_per_frame, tiles8_x, W, H, tile_order, frame, x, y)) {
+                    if (rank < take && ray_pixel(r, res_t0, res_tiles, (uint32_t)fb.n, fb.tile_major != 0, tiles8_x, W, H, tile_order, frame, x, y)) {
                         const FrameDesc& fd = s_frames[frame];
                         CamDev cam;
                         cam.width = W;
@@ -812,22 +846,18 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
 #pragma unroll
                             for (int i = 1; i < SPP; ++i) s_dst[i * 256] = __uint_as_float(tp[(uint32_t)i * SIZE]);
                             s_dst[SPP * 256] = 3.402823466e+38f;
-#pragma unroll
-                            for (int i = 0; i < 3; ++i) rs.addv[i] = rs.invdir[i] > 0.f ? rs.invdir[i] : 0.f;
                             rs.spp = 0;
                             rs.src = 0;
                             rs.t = tmin;
                             rs.pix = rs.piy = rs.piz = 0;
                             rs.prev_lvl = 0;
                             active = rs.t < rs.tmax;
-                            if (FLAT) {  // locate the first position: fixed-point coordinates + first node
-                                float p0[3] = {rs.cen[0] + rs.t * rs.dir[0], rs.cen[1] + rs.t * rs.dir[1],
-                                               rs.cen[2] + rs.t * rs.dir[2]};
+                            {  // locate the first position: fixed-point coordinates + first node
 #pragma unroll
-                                for (int i = 0; i < 3; ++i) p0[i] = f_max(f_min(p0[i], 1.f - 1e-6f), 0.f);
-                                rs.pix = (uint32_t)(p0[0] * 16777216.f);
-                                rs.piy = (uint32_t)(p0[1] * 16777216.f);
-                                rs.piz = (uint32_t)(p0[2] * 16777216.f);
+                                for (int i = 0; i < 3; ++i) rs.pos[i] = clamp_unit(rs.cen[i] + rs.t * rs.dir[i]);
+                                rs.pix = (uint32_t)(rs.pos[0] * 16777216.f);
+                                rs.piy = (uint32_t)(rs.pos[1] * 16777216.f);
+                                rs.piz = (uint32_t)(rs.pos[2] * 16777216.f);
                                 rs.node = G > 0 ? kGridNext : 0u;
                             }
                         }
@@ -844,7 +874,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
         ++dbg_wave_steps;
         dbg_lane_steps += (unsigned)__popcll(__ballot(active));
 #endif
-        if (FLAT) {
+        {
             // ---- one node visit for every active lane
             if (active) {
                 const bool grid = rs.node == kGridNext;
@@ -873,15 +903,17 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     stack[(rs.prev_lvl - G) * 256] = rs.node;
                 } else {  // leaf: the march step (rt_core.cuh:241-270)
                     const int lvl = rs.prev_lvl;
-                    float pos[3] = {rs.cen[0] + rs.t * rs.dir[0], rs.cen[1] + rs.t * rs.dir[1],
-                                    rs.cen[2] + rs.t * rs.dir[2]};
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) pos[i] = f_max(f_min(pos[i], 1.f - 1e-6f), 0.f);
+                    // rs.pos is clamp(cen + t * dir) of this very t (computed when the previous step
+                    // picked its restart node)
                     const float cube_sz = __uint_as_float((uint32_t)(128 + lvl) << 23);
                     const float inv_cube = __uint_as_float((uint32_t)(126 - lvl) << 23);
-                    const float a0 = -__builtin_amdgcn_fractf(pos[0] * cube_sz) * rs.invdir[0] + rs.addv[0];
-                    const float a1 = -__builtin_amdgcn_fractf(pos[1] * cube_sz) * rs.invdir[1] + rs.addv[1];
-                    const float a2 = -__builtin_amdgcn_fractf(pos[2] * cube_sz) * rs.invdir[2] + rs.addv[2];
+                    // _dda_unit (rt_core.cuh:38-51) on the leaf-local point frac(pos * cube_sz)
+                    const float b0 = -__builtin_amdgcn_fractf(rs.pos[0] * cube_sz) * rs.invdir[0];
+                    const float b1 = -__builtin_amdgcn_fractf(rs.pos[1] * cube_sz) * rs.invdir[1];
+                    const float b2 = -__builtin_amdgcn_fractf(rs.pos[2] * cube_sz) * rs.invdir[2];
+                    const float a0 = __builtin_fmaxf(b0, b0 + rs.invdir[0]);
+                    const float a1 = __builtin_fmaxf(b1, b1 + rs.invdir[1]);
+                    const float a2 = __builtin_fmaxf(b2, b2 + rs.invdir[2]);
                     const float tm = __builtin_fminf(1e4f, __builtin_fminf(__builtin_fminf(a0, a1), a2));
                     const float delta_t = tm * inv_cube + step_size;
                     const float sigma = half_bits_to_float((uint16_t)w);
@@ -908,13 +940,11 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     ++dbg_lane_leafs;
 #endif
                     if (active) {  // next position -> restart node (deepest ancestor shared with this step)
-                        float np[3] = {rs.cen[0] + rs.t * rs.dir[0], rs.cen[1] + rs.t * rs.dir[1],
-                                       rs.cen[2] + rs.t * rs.dir[2]};
 #pragma unroll
-                        for (int i = 0; i < 3; ++i) np[i] = f_max(f_min(np[i], 1.f - 1e-6f), 0.f);
-                        const uint32_t ix = (uint32_t)(np[0] * 16777216.f);
-                        const uint32_t iy = (uint32_t)(np[1] * 16777216.f);
-                        const uint32_t iz = (uint32_t)(np[2] * 16777216.f);
+                        for (int i = 0; i < 3; ++i) rs.pos[i] = clamp_unit(rs.cen[i] + rs.t * rs.dir[i]);
+                        const uint32_t ix = (uint32_t)(rs.pos[0] * 16777216.f);
+                        const uint32_t iy = (uint32_t)(rs.pos[1] * 16777216.f);
+                        const uint32_t iz = (uint32_t)(rs.pos[2] * 16777216.f);
                         const uint32_t diff = (ix ^ rs.pix) | (iy ^ rs.piy) | (iz ^ rs.piz);
                         int m = __clz((int)diff) - 8;
                         m = m < lvl ? m : lvl;
@@ -930,88 +960,6 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     }
                 }
             }
-            continue;
-        }
-        // ---- one march step for every active lane (rt_core.cuh:241-270)
-        if (active) {
-            float pos[3] = {rs.cen[0] + rs.t * rs.dir[0], rs.cen[1] + rs.t * rs.dir[1], rs.cen[2] + rs.t * rs.dir[2]};
-            pos[0] = f_max(f_min(pos[0], 1.f - 1e-6f), 0.f);
-            pos[1] = f_max(f_min(pos[1], 1.f - 1e-6f), 0.f);
-            pos[2] = f_max(f_min(pos[2], 1.f - 1e-6f), 0.f);
-            const uint32_t ix = (uint32_t)(pos[0] * 16777216.f);
-            const uint32_t iy = (uint32_t)(pos[1] * 16777216.f);
-            const uint32_t iz = (uint32_t)(pos[2] * 16777216.f);
-            const uint32_t diff = (ix ^ rs.pix) | (iy ^ rs.piy) | (iz ^ rs.piz);
-            int lvl = __clz((int)diff) - 8;
-            lvl = lvl < rs.prev_lvl ? lvl : rs.prev_lvl;
-            uint32_t node, w, slot;
-            if (lvl < G) {
-                // restart above the shortcut levels: ONE 8-byte lookup replaces the walk over node levels
-                // 0..G-1 and already carries the word of the slot where that walk ends
-                const uint32_t gs = 24u - (uint32_t)G;
-                const uint32_t key = (((ix >> gs) << G | (iy >> gs)) << G) | (iz >> gs);
-                const u32x2 e = topgrid[key];
-                slot = e.x & 0x07ffffffu;
-                lvl = (int)(e.x >> 27);
-                node = slot >> 3;
-                w = e.y;
-            } else {
-                node = stack[(lvl - G) * 256];
-                const uint32_t sh = 23u - (uint32_t)lvl;
-                const uint32_t ci = (__builtin_amdgcn_ubfe(ix, sh, 1u) << 2) | (__builtin_amdgcn_ubfe(iy, sh, 1u) << 1) |
-                                    __builtin_amdgcn_ubfe(iz, sh, 1u);
-                slot = (node << 3) | ci;
-                w = nodew[slot];
-            }
-#ifdef RTO_DBG_COUNTERS
-            ++dbg_lane_loads;
-#endif
-            while ((int32_t)w >= -(1 << 30)) {  // internal (leaf tag 0b10 lies below every encodable offset)
-                node += w;
-                ++lvl;
-                stack[(lvl - G) * 256] = node;  // lvl >= G: the grid resolves every level below
-                const uint32_t sh = 23u - (uint32_t)lvl;
-                const uint32_t ci = (__builtin_amdgcn_ubfe(ix, sh, 1u) << 2) | (__builtin_amdgcn_ubfe(iy, sh, 1u) << 1) |
-                                    __builtin_amdgcn_ubfe(iz, sh, 1u);
-                slot = (node << 3) | ci;
-                w = nodew[slot];
-#ifdef RTO_DBG_COUNTERS
-                ++dbg_lane_loads;
-#endif
-            }
-            rs.pix = ix;
-            rs.piy = iy;
-            rs.piz = iz;
-            rs.prev_lvl = lvl;
-            const float cube_sz = __uint_as_float((uint32_t)(128 + lvl) << 23);
-            const float inv_cube = __uint_as_float((uint32_t)(126 - lvl) << 23);
-            // _dda_unit (rt_core.cuh:38-51) on the leaf-local point frac(pos * cube_sz):
-            // max(t1, t1 + invdir) is t1 + invdir for invdir > 0 and t1 otherwise, i.e. t1 + addv
-            const float a0 = -__builtin_amdgcn_fractf(pos[0] * cube_sz) * rs.invdir[0] + rs.addv[0];
-            const float a1 = -__builtin_amdgcn_fractf(pos[1] * cube_sz) * rs.invdir[1] + rs.addv[1];
-            const float a2 = -__builtin_amdgcn_fractf(pos[2] * cube_sz) * rs.invdir[2] + rs.addv[2];
-            const float tm = __builtin_fminf(1e4f, __builtin_fminf(__builtin_fminf(a0, a1), a2));
-            const float delta_t = tm * inv_cube + step_size;
-            const float sigma = half_bits_to_float((uint16_t)w);
-            bool done = false;
-            if (sigma > sigma_thresh) {
-                const float delta = delta_t * rs.delta_scale * sigma;
-                const float reach = rs.src + delta;
-                if (reach >= rs.cur) {
-                    uint32_t cnt = 0;
-                    do {
-                        ++cnt;
-                        ++rs.spp;
-                        rs.cur = s_dst[rs.spp * 256];
-                    } while (reach >= rs.cur);
-                    hits[rs.hoff + rs.sh_nums * SIZE] = hit_pack(slot, cnt);
-                    ++rs.sh_nums;
-                    done = rs.spp == (uint32_t)SPP;
-                }
-                rs.src = reach;
-            }
-            rs.t += delta_t;
-            active = !done && rs.t < rs.tmax;
         }
     }
 #ifdef RTO_DBG_COUNTERS
@@ -1029,7 +977,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     if ((tid & 63) == 0) {
         const unsigned long long waves = (unsigned long long)gridDim.x * (blockDim.x >> 6);
         if (atomicAdd(queue + 1, 1ULL) == waves - 1ULL) {
-            queue[0] = 0ULL;
+            for (int k = 0; k < kMaxQueues; ++k) queue[8 + 8 * k] = 0ULL;
             queue[1] = 0ULL;
         }
     }
@@ -1353,7 +1301,7 @@ hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev&
     }
 }
 
-template <int SPP, int REFILL, int WPS, bool FLAT>
+template <int SPP, int REFILL, int WPS>
 static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                     const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
                                     int chunk_override, hipEvent_t* ev, hipStream_t stream) {
@@ -1362,7 +1310,7 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
     static int blocks_per_cu = 0;  // per instantiation
     if (blocks_per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_persist<SPP, REFILL, WPS, FLAT>, 256, lds) != hipSuccess || nb < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_persist<SPP, REFILL, WPS>, 256, lds) != hipSuccess || nb < 1)
             nb = 2;
         blocks_per_cu = nb > 8 ? 8 : nb;
     }
@@ -1379,7 +1327,7 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
     const int64_t size = (int64_t)fb.width * fb.height;
     hipLaunchKernelGGL(sample_kernel<SPP>, dim3((unsigned)((size + 255) / 256), fb.n), dim3(256), 0, stream, fb, jump);
     if (ev) (void)hipEventRecord(ev[0], stream);
-    hipLaunchKernelGGL((render_persist<SPP, REFILL, WPS, FLAT>), dim3(grid), dim3(256), lds, stream, tree, opt, fb, queue, hits, chunk);
+    hipLaunchKernelGGL((render_persist<SPP, REFILL, WPS>), dim3(grid), dim3(256), lds, stream, tree, opt, fb, queue, hits, chunk);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
     if (ev) (void)hipEventRecord(ev[1], stream);
 #ifndef RTO_SHADE_P
@@ -1417,19 +1365,16 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
     const int chunk_override = (refill / 1000) * 64;  // tuning: refill = 1000 * tiles_per_dequeue + threshold
     refill %= 1000;
     if (SPP == 6) {  // tuning instantiations only for the benchmark configuration
-#define RTO_B(R, O) return launch_batch_impl<SPP, R, O, false>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, ev, stream)
-#define RTO_F(R, O) return launch_batch_impl<SPP, R, O, true>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, ev, stream)
+#define RTO_F(R, O) return launch_batch_impl<SPP, R, O>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, ev, stream)
         switch (refill) {  // A/B set kept for tools/batch_bench.py
-            case 24: RTO_B(24, 8);   // nested descent loop
             case 208: RTO_F(8, 8);   // flat, refill at 8 / 32 idle lanes
             case 232: RTO_F(32, 8);
             case 316: RTO_F(16, 6);  // flat, 6 waves/SIMD
             default: break;
         }
-#undef RTO_B
 #undef RTO_F
     }
-    return launch_batch_impl<SPP, 16, 8, true>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, ev, stream);
+    return launch_batch_impl<SPP, 16, 8>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, ev, stream);
 }
 
 hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,

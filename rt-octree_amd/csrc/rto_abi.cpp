@@ -81,6 +81,11 @@ struct rto_ctx {
     int num_cus = 256;
     unsigned long long* queue = nullptr;  // persistent-kernel ray queue {next, waves_done}
     uint32_t* tile_order = nullptr;       // centre-out order of the 8x8 ray tiles (persistent kernel)
+    uint32_t* wedge_order = nullptr;      // the same tiles grouped into 8 angular wedges (one ray queue per XCD)
+    int wedge_start[rto::kMaxQueues + 1] = {0};
+    bool xcd_queues = true;
+    bool tile_major = true;
+    int tile_block = 4;  // tiles per side of the blocks the wedge queues are ordered by
     uint32_t* hits = nullptr;             // [frames][hits_spp][H*W] traversal -> shading hand-off
     int hits_spp = 0;
     // per-kernel event timing of the batched path (off by default)
@@ -509,6 +514,77 @@ int rto_ctx_create(int width, int height, int device, rto_ctx** out) {
     return rto_ctx_create_batch(width, height, 1, device, out);
 }
 
+
+// Queue orders of the 8x8 ray tiles (persistent kernel).
+//  * tile_order: rings around the image centre, innermost first, each ring walked by angle -- the
+//    frame's long rays (the object) start early, the queue ends on cheap border tiles, consecutive
+//    tiles stay neighbours;
+//  * wedge_order: the image cut into 8 angular wedges around the centre (one ray queue per XCD):
+//    every wedge gets its share of the expensive centre and of the cheap border and covers one
+//    contiguous slice of the view frustum, i.e. of the tree -- which is what the XCD's L2 then holds.
+//    Inside a wedge, blocks of tile_block x tile_block tiles go centre-out and the tiles of a block
+//    in Morton order, so the rays in flight at any time cover a compact patch, not a thin arc.
+static int build_tile_tables(rto_ctx* c) {
+    const int tx8 = (c->width + 7) / 8, ty8 = (c->height + 7) / 8;
+    const int B = c->tile_block < 1 ? 1 : c->tile_block;
+    struct Keyed { int wedge; double ring, ang; uint32_t morton; uint32_t code; };
+    std::vector<Keyed> keyed;
+    keyed.reserve((size_t)tx8 * ty8);
+    const double cx = 0.5 * (tx8 - 1), cy = 0.5 * (ty8 - 1);
+    const double pi = 3.14159265358979323846;
+    auto polar = [&](double x, double y, double& ring, double& ang) {
+        const double dx = x - cx, dy = y - cy;
+        ring = std::floor(std::fmax(std::fabs(dx), std::fabs(dy)) + 0.5);
+        ang = std::atan2(dy, dx) + pi;  // [0, 2pi]
+    };
+    auto spread = [](uint32_t v) {  // interleave helper for up to 8 bits
+        uint32_t r = 0;
+        for (int i = 0; i < 8; ++i) r |= ((v >> i) & 1u) << (2 * i);
+        return r;
+    };
+    std::vector<std::pair<double, uint32_t>> plain;
+    plain.reserve((size_t)tx8 * ty8);
+    for (int ty = 0; ty < ty8; ++ty)
+        for (int tx = 0; tx < tx8; ++tx) {
+            const uint32_t code = ((uint32_t)ty << 16) | (uint32_t)tx;
+            double ring, ang;
+            polar(tx, ty, ring, ang);
+            plain.emplace_back(ring * 16.0 + ang, code);
+            // wedge / order key of the block the tile belongs to (block centre, in tile units)
+            const int bx = tx / B, by = ty / B;
+            double bring, bang;
+            polar(bx * B + 0.5 * (B - 1), by * B + 0.5 * (B - 1), bring, bang);
+            int wedge = (int)(bang / (2.0 * pi) * rto::kMaxQueues);
+            if (wedge >= rto::kMaxQueues) wedge = rto::kMaxQueues - 1;
+            keyed.push_back({wedge, bring, bang, spread((uint32_t)(tx % B)) | (spread((uint32_t)(ty % B)) << 1), code});
+        }
+    std::stable_sort(plain.begin(), plain.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    std::vector<uint32_t> order(plain.size());
+    for (size_t i = 0; i < plain.size(); ++i) order[i] = plain[i].second;
+    std::stable_sort(keyed.begin(), keyed.end(), [](const Keyed& a, const Keyed& b) {
+        if (a.wedge != b.wedge) return a.wedge < b.wedge;
+        const double ka = a.ring * 16.0 + a.ang, kb = b.ring * 16.0 + b.ang;
+        if (ka != kb) return ka < kb;
+        return a.morton < b.morton;
+    });
+    std::vector<uint32_t> worder(keyed.size());
+    for (int k = 0; k <= rto::kMaxQueues; ++k) c->wedge_start[k] = 0;
+    for (size_t i = 0; i < keyed.size(); ++i) {
+        worder[i] = keyed[i].code;
+        c->wedge_start[keyed[i].wedge + 1] = (int)i + 1;
+    }
+    for (int k = 1; k <= rto::kMaxQueues; ++k)  // empty wedges (tiny images) inherit the previous end
+        if (c->wedge_start[k] < c->wedge_start[k - 1]) c->wedge_start[k] = c->wedge_start[k - 1];
+    if (!c->tile_order && hipMalloc((void**)&c->tile_order, order.size() * 4) != hipSuccess)
+        return set_err(RTO_E_HIP, "hipMalloc(tile_order) failed");
+    if (!c->wedge_order && hipMalloc((void**)&c->wedge_order, worder.size() * 4) != hipSuccess)
+        return set_err(RTO_E_HIP, "hipMalloc(tile_order) failed");
+    if (hipMemcpy(c->tile_order, order.data(), order.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->wedge_order, worder.data(), worder.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+        return set_err(RTO_E_HIP, "tile table upload failed");
+    return RTO_OK;
+}
+
 int rto_ctx_create_batch(int width, int height, int frames, int device, rto_ctx** out) {
     if (width <= 0 || height <= 0 || !out) return set_err(RTO_E_INVALID, "rto_ctx_create: bad size");
     if (frames < 1 || frames > rto::kMaxBatch)
@@ -536,8 +612,8 @@ int rto_ctx_create_batch(int width, int height, int frames, int device, rto_ctx*
         hipMalloc((void**)&c->noisy, px * 4 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&c->image, px * 4 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&c->rgba8, px * 4) != hipSuccess ||
-        hipMalloc((void**)&c->queue, 8 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(c->queue, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void**)&c->queue, rto::kQueueWords * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->queue, 0, rto::kQueueWords * sizeof(unsigned long long)) != hipSuccess) {
         rto_ctx_free(c);
         return set_err(RTO_E_HIP, "hipMalloc(ctx buffers) failed");
     }
@@ -545,27 +621,10 @@ int rto_ctx_create_batch(int width, int height, int frames, int device, rto_ctx*
     (void)hipMemset(c->noisy, 0, px * 4 * sizeof(float));
     (void)hipMemset(c->image, 0, px * 4 * sizeof(float));
     {
-        // queue order of the 8x8 ray tiles: rings around the image centre, innermost first, each ring
-        // walked by angle -- the frame's long rays (the object) start early, its queue ends on cheap
-        // border tiles, and consecutive tiles stay neighbours
-        const int tx8 = (width + 7) / 8, ty8 = (height + 7) / 8;
-        std::vector<std::pair<double, uint32_t>> keyed;
-        keyed.reserve((size_t)tx8 * ty8);
-        const double cx = 0.5 * (tx8 - 1), cy = 0.5 * (ty8 - 1);
-        for (int ty = 0; ty < ty8; ++ty)
-            for (int tx = 0; tx < tx8; ++tx) {
-                const double dx = tx - cx, dy = ty - cy;
-                const double ring = std::floor(std::fmax(std::fabs(dx), std::fabs(dy)) + 0.5);
-                const double ang = std::atan2(dy, dx) + 3.14159265358979323846;  // [0, 2pi]
-                keyed.emplace_back(ring * 16.0 + ang, ((uint32_t)ty << 16) | (uint32_t)tx);
-            }
-        std::stable_sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
-        std::vector<uint32_t> order(keyed.size());
-        for (size_t i = 0; i < keyed.size(); ++i) order[i] = keyed[i].second;
-        if (hipMalloc((void**)&c->tile_order, order.size() * 4) != hipSuccess ||
-            hipMemcpy(c->tile_order, order.data(), order.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        int rc = build_tile_tables(c);
+        if (rc != RTO_OK) {
             rto_ctx_free(c);
-            return set_err(RTO_E_HIP, "hipMalloc(tile_order) failed");
+            return rc;
         }
     }
     pcg_seed(c->rng, 20230418ULL, 1);  // render_context.hpp:16
@@ -590,6 +649,7 @@ void rto_ctx_free(rto_ctx* c) {
     if (c->queue) (void)hipFree(c->queue);
     if (c->hits) (void)hipFree(c->hits);
     if (c->tile_order) (void)hipFree(c->tile_order);
+    if (c->wedge_order) (void)hipFree(c->wedge_order);
     for (hipEvent_t e : c->kt_ev) (void)hipEventDestroy(e);
     if (c->stats) (void)hipFree(c->stats);
     for (int i = 0; i < 3; ++i) {
@@ -652,6 +712,16 @@ int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value) {
         c->variant = value;
     } else if (k == "tile_order") {
         c->tile_order_on = value != 0;
+    } else if (k == "xcd_queues") {
+        c->xcd_queues = value != 0;
+    } else if (k == "tile_major") {
+        c->tile_major = value != 0;
+    } else if (k == "tile_block") {
+        if (value < 1 || value > 64) return set_err(RTO_E_INVALID, "tile_block must be 1..64");
+        c->tile_block = value;
+        DeviceGuard guard(c->device);
+        if (hipDeviceSynchronize() != hipSuccess) return set_err(RTO_E_HIP, "hipDeviceSynchronize failed");
+        return build_tile_tables(c);
     } else if (k == "refill") {
         c->refill = value;
     } else if (k == "strip_rows") {
@@ -822,7 +892,20 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     fb.n = n;
     fb.width = ctx->width;
     fb.height = ctx->height;
-    fb.tile_order = ctx->tile_order_on ? ctx->tile_order : nullptr;
+    {
+        const int tiles = ((ctx->width + 7) / 8) * ((ctx->height + 7) / 8);
+        fb.tile_major = ctx->tile_major ? 1 : 0;
+        if (ctx->tile_order_on && ctx->xcd_queues) {  // one queue per XCD over an image wedge each
+            fb.tile_order = ctx->wedge_order;
+            fb.n_queues = rto::kMaxQueues;
+            for (int k = 0; k <= rto::kMaxQueues; ++k) fb.qstart[k] = ctx->wedge_start[k];
+        } else {  // one queue over whole frames (centre-out or row-major tiles)
+            fb.tile_order = ctx->tile_order_on ? ctx->tile_order : nullptr;
+            fb.n_queues = 1;
+            fb.qstart[0] = 0;
+            for (int k = 1; k <= rto::kMaxQueues; ++k) fb.qstart[k] = tiles;
+        }
+    }
     const size_t px = frame_px(ctx);
     for (int f = 0; f < n; ++f) {
         if (cams[f].width != ctx->width || cams[f].height != ctx->height)

@@ -134,23 +134,23 @@ RTO_DEV float det_expf(float x) {
     return (float)(p * sc);
 }
 
-// fp32-only deterministic exp for the filter taps; mirrors oracle/rto_oracle.c orc_fexp
+// fp32-only deterministic exp for the filter taps; mirrors oracle/rto_oracle.c orc_fexp (every
+// multiply-add an explicit, correctly rounded fma: v_fma_f32 here, fmaf there)
 RTO_DEV float fexp_f32(float x) {
     if (x != x) return x;
     if (x > 88.72283935546875f) return __builtin_inff();
     if (x < -87.33654022216797f) return 0.0f;
-    const float t = x * 1.44269502162933349609375f;
-    const float kf = (t + 12582912.0f) - 12582912.0f;
-    float r = x - kf * 0.693145751953125f;
-    r = r - kf * 1.42860676533018704e-06f;
+    const float kf = __builtin_fmaf(x, 1.44269502162933349609375f, 12582912.0f) - 12582912.0f;
+    float r = __builtin_fmaf(kf, -0.693145751953125f, x);
+    r = __builtin_fmaf(kf, -1.42860676533018704e-06f, r);
     float p = 1.0f / 5040.0f;
-    p = p * r + 1.0f / 720.0f;
-    p = p * r + 1.0f / 120.0f;
-    p = p * r + 1.0f / 24.0f;
-    p = p * r + 1.0f / 6.0f;
-    p = p * r + 0.5f;
-    p = p * r + 1.0f;
-    p = p * r + 1.0f;
+    p = __builtin_fmaf(p, r, 1.0f / 720.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 120.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 24.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 6.0f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
     int ki = (int)kf;
     if (ki > 127) {  // 2^128 has no fp32 encoding
         ki = 127;
@@ -163,40 +163,39 @@ RTO_DEV float fexp_f32(float x) {
 // g - max <= 0): identical values, NaN included (cvt of NaN is 0, NaN * 2^0 = NaN, and both
 // comparisons below are false for NaN), one select instead of three branches per tap.
 RTO_DEV float fexp_f32_le88(float x) {
-    const float t = x * 1.44269502162933349609375f;
-    const float kf = (t + 12582912.0f) - 12582912.0f;
-    float r = x - kf * 0.693145751953125f;
-    r = r - kf * 1.42860676533018704e-06f;
+    const float kf = __builtin_fmaf(x, 1.44269502162933349609375f, 12582912.0f) - 12582912.0f;
+    float r = __builtin_fmaf(kf, -0.693145751953125f, x);
+    r = __builtin_fmaf(kf, -1.42860676533018704e-06f, r);
     float p = 1.0f / 5040.0f;
-    p = p * r + 1.0f / 720.0f;
-    p = p * r + 1.0f / 120.0f;
-    p = p * r + 1.0f / 24.0f;
-    p = p * r + 1.0f / 6.0f;
-    p = p * r + 0.5f;
-    p = p * r + 1.0f;
-    p = p * r + 1.0f;
+    p = __builtin_fmaf(p, r, 1.0f / 720.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 120.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 24.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 6.0f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
     const float res = p * __uint_as_float((uint32_t)((int)kf + 127) << 23);
     return x < -87.33654022216797f ? 0.0f : res;
 }
 
 // Two arguments at once: the same operations on a 2-vector, which gfx950 executes as packed fp32
-// instructions (v_pk_mul_f32 / v_pk_add_f32: two IEEE results per lane per instruction, each
+// instructions (v_pk_fma_f32 / v_pk_add_f32: two IEEE results per lane per instruction, each
 // rounded exactly like the scalar form).
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef int int2v __attribute__((ext_vector_type(2)));
+RTO_DEV float2v splat2(float v) { return float2v{v, v}; }
 RTO_DEV float2v fexp_f32_le88_x2(float2v x) {
-    const float2v t = x * 1.44269502162933349609375f;
-    const float2v kf = (t + 12582912.0f) - 12582912.0f;
-    float2v r = x - kf * 0.693145751953125f;
-    r = r - kf * 1.42860676533018704e-06f;
-    float2v p = {1.0f / 5040.0f, 1.0f / 5040.0f};
-    p = p * r + 1.0f / 720.0f;
-    p = p * r + 1.0f / 120.0f;
-    p = p * r + 1.0f / 24.0f;
-    p = p * r + 1.0f / 6.0f;
-    p = p * r + 0.5f;
-    p = p * r + 1.0f;
-    p = p * r + 1.0f;
+    const float2v kf = __builtin_elementwise_fma(x, splat2(1.44269502162933349609375f), splat2(12582912.0f)) - 12582912.0f;
+    float2v r = __builtin_elementwise_fma(kf, splat2(-0.693145751953125f), x);
+    r = __builtin_elementwise_fma(kf, splat2(-1.42860676533018704e-06f), r);
+    float2v p = splat2(1.0f / 5040.0f);
+    p = __builtin_elementwise_fma(p, r, splat2(1.0f / 720.0f));
+    p = __builtin_elementwise_fma(p, r, splat2(1.0f / 120.0f));
+    p = __builtin_elementwise_fma(p, r, splat2(1.0f / 24.0f));
+    p = __builtin_elementwise_fma(p, r, splat2(1.0f / 6.0f));
+    p = __builtin_elementwise_fma(p, r, splat2(0.5f));
+    p = __builtin_elementwise_fma(p, r, splat2(1.0f));
+    p = __builtin_elementwise_fma(p, r, splat2(1.0f));
     const int2v ki = __builtin_convertvector(kf, int2v);
     const int2v sb = (ki + 127) << 23;
     float2v sc;

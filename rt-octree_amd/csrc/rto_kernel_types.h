@@ -78,9 +78,19 @@ struct FrameDesc {
     uint32_t* hits;  // [SPP][H*W] packed hit entries, kNoHit-terminated (traversal -> shading)
 };
 constexpr uint32_t kNoHit = 0xffffffffu;
+constexpr int kMaxQueues = 8;  // XCDs of an MI355X
+// ctx queue memory (u64 words): [1] waves that have left, [2..7] debug counters, [8 + 8k] next ray of queue k
+constexpr int kQueueWords = 8 + 8 * kMaxQueues;
 struct FrameBatch {
-    int n, width, height, pad;
+    int n, width, height;
+    int tile_major;  // queue order: 0 = frame after frame, 1 = tile after tile (each tile for all frames in turn)
     const uint32_t* tile_order;  // [tiles8_x*tiles8_y] (ty << 16 | tx) in queue order, or nullptr
+    // Ray queues of the persistent kernel: queue k holds, frame after frame, the tiles
+    // tile_order[qstart[k] .. qstart[k+1]) -- one image wedge.  A wave draws from the queue of the XCD
+    // it runs on (each XCD has its own L2: one wedge = one slice of the tree per L2) and steals from
+    // the others once that is empty.  n_queues = 1: a single queue over whole frames.
+    int n_queues;
+    int qstart[kMaxQueues + 1];
     FrameDesc f[kMaxBatch];
 };
 

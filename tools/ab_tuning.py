@@ -1,0 +1,53 @@
+"""Development A/B of rto_ctx_set_tuning keys on the batched path (same box, same process):
+python tools/ab_tuning.py xcd_queues=0 xcd_queues=1 ...   -> ms per 16-frame launch, traversal kernel."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import rt_octree_amd as R  # noqa: E402
+from rt_octree_amd import synth  # noqa: E402
+
+
+def main():
+    import torch
+    settings = [a for a in sys.argv[1:] if "=" in a] or ["xcd_queues=0", "xcd_queues=1"]
+    tree = synth.make_tree(depth_limit=10, basis_dim=16, shell=2.5)
+    dt = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+    W = H = 800
+    fx = synth.blender_focal(W)
+    cams = []
+    for p in synth.orbit_poses(200)[:96]:
+        c = R.Camera(W, H, fx, fx)
+        c.set_c2w(p)
+        cams.append(c)
+    opt = R.RenderOptions(spp=6, denoise=False)
+    ctx = R.RenderContext(W, H, frames=16)
+    stream = torch.cuda.current_stream()
+    ref = None
+    for rnd in range(3):
+        for sset in settings:
+            for kv in sset.split(","):
+                k, v = kv.split("=")
+                ctx.set_tuning(k, int(v))
+            ctx.kernel_timing(True)
+            for rep in range(2):
+                for i in range(0, len(cams), 16):
+                    ctx.rng_seed()
+                    R.launch_renderer_batch(dt, cams[i:i + 16], opt, ctx, stream, rng_jumps=[100 + i + k for k in range(16)])
+                torch.cuda.synchronize()
+                kt = ctx.kernel_timing_read()
+            ctx.select_frame(15)
+            aux = ctx.download_aux()
+            if ref is None:
+                ref = aux
+            same = np.array_equal(aux.view(np.uint32), ref.view(np.uint32))
+            print("round %d %-28s traverse %.3f ms  shade %.3f ms per launch  same_bits=%s"
+                  % (rnd, sset, kt["traverse_ms"], kt["shade_ms"], same), flush=True)
+
+
+if __name__ == "__main__":
+    main()

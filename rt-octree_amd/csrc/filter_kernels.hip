@@ -39,7 +39,10 @@ RTO_DEV void filter_level(const float* __restrict__ g, const float4* __restrict_
 #pragma unroll
         for (int dx = -S; dx <= S; ++dx) max_val = fmaxf(max_val, row[dx]);
     }
-    float r = 0.f, gg = 0.f, b = 0.f, kernel_sum = 0;
+    // accumulators as two packed pairs: {r, g} and {b, kernel_sum}.  The tile's alpha is staged as
+    // 1, so kernel_sum += k is the lane fma(1, k, kernel_sum) = kernel_sum + k exactly, and each tap
+    // costs two v_pk_fma_f32 instead of three FMAs and an add.
+    float2v rg = {0.f, 0.f}, bs = {0.f, 0.f};
 #pragma unroll 1
     for (int dy = -S; dy <= S; ++dy) {
         const int e0 = centre + dy * TW;
@@ -51,24 +54,22 @@ RTO_DEV void filter_level(const float* __restrict__ g, const float4* __restrict_
             x2.y = g[e0 + dx + 1] - max_val;
             const float2v k2 = fexp_f32_le88_x2(x2);
             const float4 t0 = rgb[e0 + dx], t1 = rgb[e0 + dx + 1];
-            kernel_sum += k2.x;
-            r = __builtin_fmaf(t0.x, k2.x, r);  // (explicit FMA, as in the oracle: nvcc contracts the
-            gg = __builtin_fmaf(t0.y, k2.x, gg);  // reference's `rgba.x += t_rgb.x * k` the same way)
-            b = __builtin_fmaf(t0.z, k2.x, b);
-            kernel_sum += k2.y;
-            r = __builtin_fmaf(t1.x, k2.y, r);
-            gg = __builtin_fmaf(t1.y, k2.y, gg);
-            b = __builtin_fmaf(t1.z, k2.y, b);
+            // (explicit FMA, as in the oracle: nvcc contracts the reference's `rgba.x += t_rgb.x * k`
+            // the same way)
+            rg = __builtin_elementwise_fma(float2v{t0.x, t0.y}, float2v{k2.x, k2.x}, rg);
+            bs = __builtin_elementwise_fma(float2v{t0.z, t0.w}, float2v{k2.x, k2.x}, bs);
+            rg = __builtin_elementwise_fma(float2v{t1.x, t1.y}, float2v{k2.y, k2.y}, rg);
+            bs = __builtin_elementwise_fma(float2v{t1.z, t1.w}, float2v{k2.y, k2.y}, bs);
         }
         {  // the window is 2S+1 wide: one tap left
             const float k = fexp_f32_le88(g[e0 + S] - max_val);
-            kernel_sum += k;
             const float4 t = rgb[e0 + S];
-            r = __builtin_fmaf(t.x, k, r);
-            gg = __builtin_fmaf(t.y, k, gg);
-            b = __builtin_fmaf(t.z, k, b);
+            rg = __builtin_elementwise_fma(float2v{t.x, t.y}, float2v{k, k}, rg);
+            bs = __builtin_elementwise_fma(float2v{t.z, t.w}, float2v{k, k}, bs);
         }
     }
+    float r = rg.x, gg = rg.y, b = bs.x;
+    const float kernel_sum = bs.y;
     const float inv = 1.0f / kernel_sum;
     const float w = w_pix * inv;
     r *= w;
@@ -109,7 +110,9 @@ __global__ void __launch_bounds__(256, 4) filter_fused(const float* __restrict__
         const int gx = x0 + tx, gy = y0 + ty;
         const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
         const int64_t gi = (int64_t)gy * W + gx;
-        s_rgb[e] = in ? img_in[gi] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 t = in ? img_in[gi] : make_float4(0.f, 0.f, 0.f, 0.f);
+        t.w = 1.f;  // not an image value here: the multiplier of k in the kernel_sum lane (filter_level)
+        s_rgb[e] = t;
 #pragma unroll
         for (int l = 0; l < L; ++l) s_g[l][e] = in ? guidance[l * HW + gi] : -3.402823466e+38f;
     }

@@ -7,7 +7,8 @@
 // PyTorch-ROCm runs as two MIOpen Winograd convolutions plus seven elementwise launches
 // (~0.2 ms/frame, profiles/r1_b_*).  Here one workgroup produces a 32x8 pixel tile end to end:
 //
-//   stage A  aux tile + 2-pixel halo, fp32 planar -> fp16 HWC in LDS (zero outside the image)
+//   stage A  aux tile + 2-pixel halo, fp32 planar -> fp16 HWC in LDS (zero outside the image);
+//            one thread per tile pixel, its 8 channel loads in flight together
 //   stage B  layer 1 on the tile + 1-pixel halo with v_mfma_f32_16x16x32_f16: M = 16 output
 //            channels (weights, A operand, register-resident), N = 16 pixels (B operand: ONE
 //            ds_read_b128 per lane = the 8 input channels of one tap), K = 9 taps x 8 channels
@@ -53,8 +54,15 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
     constexpr int AW = kGW + 2, AH = kGH + 2;  // layer-1 activation tile with halo 1
     constexpr int NT1 = C1 / 16;               // output-channel tiles of layer 1
     constexpr int KS2 = 9 * C1 / 32;           // k-steps of layer 2
+    // activation pixel stride in halves: C1 + 8, i.e. 80 B instead of 64 B for C1 = 32 -- with a
+    // 64-byte stride the 16 pixels a ds_read_b128 gathers start on only two distinct bank groups
+    // (8-way conflict); at 80 B every bank is touched exactly twice, the minimum for 256 B
+#ifndef RTO_NET_PAD
+#define RTO_NET_PAD 0
+#endif
+    constexpr int AS = C1 + RTO_NET_PAD;
     __shared__ __attribute__((aligned(16))) _Float16 s_in[IH * IW * kCIn];
-    __shared__ __attribute__((aligned(16))) _Float16 s_act[AH * AW * C1];
+    __shared__ __attribute__((aligned(16))) _Float16 s_act[AH * AW * AS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x0 = blockIdx.x * kGW, y0 = blockIdx.y * kGH;
@@ -63,27 +71,55 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
     weight_out += (int64_t)blockIdx.z * L * HW;
     guidance_out += (int64_t)blockIdx.z * L * HW;
 
-    // ---- stage A: input tile, planar fp32 -> HWC fp16
-    for (int e = tid; e < IH * IW * kCIn; e += 256) {
-        const int c = e / (IH * IW), r = e - c * (IH * IW);
-        const int ty = r / IW, tx = r - ty * IW;
-        const int gx = x0 - 2 + tx, gy = y0 - 2 + ty;
-        float v = 0.f;
-        if (gx >= 0 && gx < W && gy >= 0 && gy < H) v = aux[c * HW + (int64_t)gy * W + gx];
-        s_in[(ty * IW + tx) * kCIn + c] = (_Float16)v;
+    const int col = lane & 15, kg = lane >> 4;  // MFMA lane roles: pixel (B/C column), k-group / row block
+
+    // Weights first: their loads overlap stage A instead of stalling the first MFMAs of each layer.
+    half8 wa[NT1][3];
+#pragma unroll
+    for (int t = 0; t < NT1; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+            wa[t][ks] = *reinterpret_cast<const half8*>(w1 + (size_t)(t * 16 + col) * 96 + ks * 32 + kg * 8);
+    half8 wb[KS2];
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks)
+        wb[ks] = *reinterpret_cast<const half8*>(w2 + (size_t)col * (9 * C1) + ks * 32 + kg * 8);
+
+    // ---- stage A: input tile, planar fp32 -> HWC fp16.  One thread = one tile pixel: its 8 channel
+    // loads are independent (all in flight at once; a per-element loop waited for each load in turn
+    // and was the whole kernel's critical path) and become one 16-byte LDS store.
+    {
+        constexpr int NPIX = IH * IW, NIT = (NPIX + 255) / 256;
+        float v[NIT][kCIn];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + it * 256;
+            const int ty = e / IW, tx = e - ty * IW;
+            const int gx = x0 - 2 + tx, gy = y0 - 2 + ty;
+            const bool in = e < NPIX && gx >= 0 && gx < W && gy >= 0 && gy < H;
+            const int64_t gi = in ? (int64_t)gy * W + gx : 0;
+#pragma unroll
+            for (int c = 0; c < kCIn; ++c) {
+                const float t = aux[c * HW + gi];
+                v[it][c] = in ? t : 0.f;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + it * 256;
+            if (e < NPIX) {
+                half8 h;
+#pragma unroll
+                for (int c = 0; c < kCIn; ++c) h[c] = (_Float16)v[it][c];
+                *reinterpret_cast<half8*>(s_in + (size_t)e * kCIn) = h;
+            }
+        }
     }
     __syncthreads();
 
-    const int col = lane & 15, kg = lane >> 4;  // MFMA lane roles: pixel (B/C column), k-group / row block
 
     // ---- stage B: layer 1 on the AH x AW region
     {
-        half8 wa[NT1][3];
-#pragma unroll
-        for (int t = 0; t < NT1; ++t)
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks)
-                wa[t][ks] = *reinterpret_cast<const half8*>(w1 + (size_t)(t * 16 + col) * 96 + ks * 32 + kg * 8);
         float bias[NT1][4];
 #pragma unroll
         for (int t = 0; t < NT1; ++t)
@@ -117,7 +153,7 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
                     half4 o;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o[i] = inside ? (_Float16)relu6(acc[t][i] + bias[t][i]) : (_Float16)0.f;
-                    *reinterpret_cast<half4*>(s_act + (size_t)p * C1 + t * 16 + kg * 4) = o;
+                    *reinterpret_cast<half4*>(s_act + (size_t)p * AS + t * 16 + kg * 4) = o;
                 }
             }
         }
@@ -126,10 +162,6 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
 
     // ---- stage C: layer 2 on the kGH x kGW tile, softmax, stores
     {
-        half8 wb[KS2];
-#pragma unroll
-        for (int ks = 0; ks < KS2; ++ks)
-            wb[ks] = *reinterpret_cast<const half8*>(w2 + (size_t)col * (9 * C1) + ks * 32 + kg * 8);
         float bias[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) bias[i] = b2[kg * 4 + i];
@@ -144,7 +176,7 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
                 const int k0 = ks * 32 + kg * 8;  // k = tap*C1 + ci
                 const int tap = k0 / C1, ci = k0 - tap * C1;
                 const int ky = tap / 3, kx = tap - ky * 3;
-                const half8 bfrag = *reinterpret_cast<const half8*>(s_act + (size_t)((oy + ky) * AW + ox + kx) * C1 + ci);
+                const half8 bfrag = *reinterpret_cast<const half8*>(s_act + (size_t)((oy + ky) * AW + ox + kx) * AS + ci);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ks], bfrag, acc, 0, 0, 0);
             }
             const int gx = x0 + ox, gy = y0 + oy;

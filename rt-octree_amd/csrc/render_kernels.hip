@@ -678,7 +678,7 @@ RTO_DEV bool ray_pixel(uint32_t p, uint32_t qt0, uint32_t qtiles, uint32_t n_fra
         ty = tile / tiles8_x;
         tx = tile - ty * tiles8_x;
     }
-    x = tx * 8 + (l & 7);
+    x = tx * 8 + (l & 7);  // (Z-order inside the tile was tried: no fewer L1 accesses)
     y = ty * 8 + (l >> 3);
     return x < width && y < height;
 }
@@ -766,7 +766,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     if (G == 0) stack[0] = 0u;      // no top grid: level 0 is the root
 
 #ifdef RTO_DBG_COUNTERS
-    unsigned dbg_wave_steps = 0, dbg_lane_steps = 0, dbg_lane_loads = 0, dbg_lane_leafs = 0;
+    unsigned dbg_wave_steps = 0, dbg_lane_steps = 0, dbg_lane_loads = 0, dbg_lane_leafs = 0, dbg_refills = 0, dbg_refilled = 0;
 #endif
     RayState rs;
     bool active = false;    // marching
@@ -892,7 +892,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     rs.node = slot >> 3;
                     w = e.y;
                 } else {  // ... or 4 bytes of the traversal image
-                    w = nodew[slot];
+                    w = nodew[slot];  // (through the L1: a non-temporal load here costs 50 %)
                 }
 #ifdef RTO_DBG_COUNTERS
                 ++dbg_lane_loads;
@@ -947,6 +947,10 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                         const uint32_t iz = (uint32_t)(rs.pos[2] * 16777216.f);
                         const uint32_t diff = (ix ^ rs.pix) | (iy ^ rs.piy) | (iz ^ rs.piz);
                         int m = __clz((int)diff) - 8;
+#ifdef RTO_DBG_COUNTERS
+                        if (m >= lvl) ++dbg_refilled;      // next leaf is a sibling (same parent node)
+                        if (m == lvl - 1) ++dbg_refills;   // next leaf is a cousin (same grandparent)
+#endif
                         m = m < lvl ? m : lvl;
                         rs.pix = ix;
                         rs.piy = iy;
@@ -970,6 +974,10 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
         if ((tid & 63) == 0) {
             atomicAdd(queue + 2, (unsigned long long)dbg_wave_steps);
             atomicAdd(queue + 3, (unsigned long long)dbg_lane_steps);
+        }
+        {
+            atomicAdd(queue + 6, (unsigned long long)dbg_refills);
+            atomicAdd(queue + 7, (unsigned long long)dbg_refilled);
         }
     }
 #endif

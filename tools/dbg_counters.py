@@ -12,7 +12,7 @@ cams = []
 for p in synth.orbit_poses(200)[:8]:
     c = R.Camera(W, H, fx, fx); c.set_c2w(p); cams.append(c)
 ctx = R.RenderContext(W, H, frames=8)
-for rf in (16, 24, 208, 216, 224, 232):
+for rf in (16,):
     ctx.set_tuning("refill", rf)
     R.launch_renderer_batch(dt, cams, R.RenderOptions(spp=6, denoise=False), ctx, rng_jumps=list(range(100, 108)))
     torch.cuda.synchronize()
@@ -22,6 +22,6 @@ for rf in (16, 24, 208, 216, 224, 232):
     out = (C.c_uint64 * 8)()
     R.lib().rto_debug_read_queue(ctx._h, out)
     ws, ls, ll, lf = out[2], out[3], out[4], out[5]
-    print("refill %3d: wave_iters/frame %.0f  lane_iters/frame %.0f  util %.3f  loads/frame %.0f leafs/frame %.0f" % (
-        rf, ws / 8, ls / 8, ls / (64.0 * ws), ll / 8, lf / 8))
+    print("refill %3d: wave_iters/frame %.0f  lane_iters/frame %.0f  util %.3f  loads/frame %.0f leafs/frame %.0f  cousin steps/frame %.0f  sibling steps/frame %.0f" % (
+        rf, ws / 8, ls / 8, ls / (64.0 * ws), ll / 8, lf / 8, out[6] / 8, out[7] / 8))
     R.lib().rto_debug_zero_queue(ctx._h)

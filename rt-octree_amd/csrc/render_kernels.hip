@@ -885,8 +885,40 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                                     (__builtin_amdgcn_ubfe(rs.piy, sh, 1u) << 1) | __builtin_amdgcn_ubfe(rs.piz, sh, 1u);
                 uint32_t slot = (rs.node << 3) | ci;
                 uint32_t w;
+#ifdef RTO_DBG_GRIDUNIQ
+                {  // how many distinct top-grid cells / nodew lines does one wave-level load touch?
+                    unsigned long long rem = __ballot(grid);
+                    int uniq = 0;
+                    while (rem) {
+                        const int src = __ffsll((long long)rem) - 1;
+                        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, src);
+                        rem &= ~__ballot(grid && key == k0);
+                        ++uniq;
+                    }
+                    unsigned long long remn = __ballot(!grid);
+                    int uniqn = 0;
+                    while (remn) {
+                        const int src = __ffsll((long long)remn) - 1;
+                        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)(slot >> 4), src);
+                        remn &= ~__ballot(!grid && (slot >> 4) == k0);
+                        ++uniqn;
+                    }
+                    if ((tid & 63) == __ffsll((long long)__ballot(true)) - 1) {
+                        if (uniq) {
+                            atomicAdd(queue + 2, 1ULL);
+                            atomicAdd(queue + 3, (unsigned long long)uniq);
+                            atomicAdd(queue + 4, (unsigned long long)__popcll(__ballot(grid)));
+                        }
+                        if (uniqn) {
+                            atomicAdd(queue + 5, 1ULL);
+                            atomicAdd(queue + 6, (unsigned long long)uniqn);
+                            atomicAdd(queue + 7, (unsigned long long)__popcll(__ballot(!grid)));
+                        }
+                    }
+                }
+#endif
                 if (grid) {  // the iteration's one load: 8 bytes of the top grid ...
-                    const u32x2 e = topgrid[key];
+                    const u32x2 e = topgrid[key];  // (through the L1 as well: non-temporal costs 15 %)
                     slot = e.x & 0x07ffffffu;
                     rs.prev_lvl = (int)(e.x >> 27);
                     rs.node = slot >> 3;

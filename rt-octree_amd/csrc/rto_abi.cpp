@@ -698,7 +698,7 @@ int rto_ctx_set_kernel(rto_ctx* c, int kernel) {
     return RTO_OK;
 }
 
-#ifdef RTO_DBG_COUNTERS
+#if defined(RTO_DBG_COUNTERS) || defined(RTO_DBG_GRIDUNIQ)
 extern "C" int rto_debug_read_queue(rto_ctx* c, uint64_t out[8]) {
     return hipMemcpy(out, c->queue, 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -4;
 }

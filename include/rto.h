@@ -204,6 +204,22 @@ int rto_filtering(void* stream, const float* weight_map, const float* guidance_m
 /* n images per launch: weight_map / guidance_map [n][L][H][W], img_in / img_out [n][H][W][4] */
 int rto_filtering_batch(void* stream, const float* weight_map, const float* guidance_map, int L, int H,
                         int W, int n, const float* img_in, float* img_out);
+/* Training side -- Filtering::forward with requires_grad and Filtering::backward
+ * (filtering.cu:596-707; grad_weight_accumulate :230-248, grad_guidance_accumulate :250-301), what
+ * `_denoiser.filtering_autograd` (bindings.cpp) runs under autograd.  All device pointers, fp32:
+ *   forward : as rto_filtering_batch, also writing rgb_filtered [n][L][H][W][4] (alpha 0), max_map and
+ *             inv_kernel_sum [n][L][H][W] (the reference keeps one [B,H,W,*] tensor per level);
+ *   backward: grad_output, img_in [n][H][W][4] + the forward's inputs and saves ->
+ *             grad_weight, grad_guidance [n][L][H][W] (fully overwritten).
+ * The guidance gradient is gathered per pixel in a fixed order (no atomics): results are run-to-run
+ * identical, which the reference's atomicAdd scatter is not. */
+int rto_filtering_train_forward(void* stream, const float* weight_map, const float* guidance_map, int L, int H,
+                                int W, int n, const float* img_in, float* img_out, float* rgb_filtered,
+                                float* max_map, float* inv_kernel_sum);
+int rto_filtering_backward(void* stream, const float* grad_output, const float* img_in, const float* weight_map,
+                           const float* guidance_map, const float* rgb_filtered, const float* max_map,
+                           const float* inv_kernel_sum, int L, int H, int W, int n, float* grad_weight,
+                           float* grad_guidance);
 /* convenience: filtering from ctx noisy -> ctx image */
 int rto_ctx_filtering(rto_ctx* c, void* stream, const float* weight_map, const float* guidance_map, int L);
 

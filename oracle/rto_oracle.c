@@ -577,8 +577,8 @@ int orc_render_frame(const orc_tree* tree, const orc_camera* cam, const orc_opti
 /* denoiser/extension/filtering.cu:108-228 (applying<_,16,32,SUPPORT>), driven level by level as
  * host::forward :440-470 does (support = level+1; level 0 overwrites with alpha=1, later levels
  * accumulate rgb).  Out-of-image taps: rgba=0, guidance=-FLT_MAX (:140-143). */
-int orc_filter(int L, int H, int W, const float* weight, const float* guidance, const float* noisy,
-               float* out, int num_threads) {
+static int filter_core(int L, int H, int W, const float* weight, const float* guidance, const float* noisy,
+                       float* out, float* rgb_filtered, float* max_map, float* inv_kernel_sum, int num_threads) {
     if (L < 1 || L > 6) return -4; /* kernel_apply :338-367 supports SUPPORT 1..6 */
 #ifdef _OPENMP
     if (num_threads <= 0) num_threads = omp_get_max_threads();
@@ -616,12 +616,90 @@ int orc_filter(int L, int H, int W, const float* weight, const float* guidance, 
                         gg = fmaf(tg, k, gg);
                         b = fmaf(tb, k, b);
                     }
-                const float inv = 1.0f / kernel_sum;                 /* :201 */
-                const float w = wm[(int64_t)iy * W + ix] * inv;      /* :215 */
+                const float inv = 1.0f / kernel_sum;                 /* :204 */
+                if (rgb_filtered) {                                  /* saved for backward :205-216 */
+                    const int64_t si = ((int64_t)level * H + iy) * W + ix;
+                    max_map[si] = max_val;
+                    inv_kernel_sum[si] = inv;
+                    rgb_filtered[si * 4 + 0] = r * inv;
+                    rgb_filtered[si * 4 + 1] = gg * inv;
+                    rgb_filtered[si * 4 + 2] = b * inv;
+                    rgb_filtered[si * 4 + 3] = 0.f; /* torch::zeros, never written (:622) */
+                }
+                const float w = wm[(int64_t)iy * W + ix] * inv;      /* :218 */
                 r *= w; gg *= w; b *= w;
                 float* o = out + ((int64_t)iy * W + ix) * 4;
                 if (S == 1) { o[0] = r; o[1] = gg; o[2] = b; o[3] = 1.0f; } /* :47-60 */
                 else { o[0] += r; o[1] += gg; o[2] += b; }                  /* :62-74 */
+            }
+        }
+    }
+    return 0;
+}
+
+int orc_filter(int L, int H, int W, const float* weight, const float* guidance, const float* noisy,
+               float* out, int num_threads) {
+    return filter_core(L, H, W, weight, guidance, noisy, out, NULL, NULL, NULL, num_threads);
+}
+
+/* Filtering::forward with requires_grad (filtering.cu:596-665): the same pass, also saving per level
+ * rgb_filtered [L][H][W][4], max_map [L][H][W], inv_kernel_sum [L][H][W] (the reference keeps one
+ * tensor per level, [B,H,W,4] / [B,H,W]; here one image, levels outermost). */
+int orc_filter_train_forward(int L, int H, int W, const float* weight, const float* guidance, const float* noisy,
+                             float* out, float* rgb_filtered, float* max_map, float* inv_kernel_sum, int num_threads) {
+    if (!rgb_filtered || !max_map || !inv_kernel_sum) return -1;
+    return filter_core(L, H, W, weight, guidance, noisy, out, rgb_filtered, max_map, inv_kernel_sum, num_threads);
+}
+
+/* Filtering::backward (filtering.cu:667-707) = per level grad_weight_accumulate (:230-248) and
+ * grad_guidance_accumulate (:250-301):
+ *   grad_weight[l][p]   = sum_c grad_out[p][c] * rgb_filtered_l[p][c]
+ *   grad_guidance[l][q] = sum over the pixels p whose (2S+1)^2 window holds q of
+ *                         w_l[p] * (exp(g_l[q] - max_l[p]) * inv_l[p]) * sum_c grad_out[p][c] * (img_in[q][c] - rgb_filtered_l[p][c])
+ * The reference scatters the second sum with one thread per (p, tap) and atomicAdd, i.e. in an order
+ * the hardware picks; this restatement gathers per q with p in row-major window order, which fixes the
+ * result.  Products-into-sums are explicit fmaf (nvcc's default contraction, as in the forward). */
+int orc_filter_backward(int L, int H, int W, const float* grad_out, const float* img_in, const float* weight,
+                        const float* guidance, const float* rgb_filtered, const float* max_map,
+                        const float* inv_kernel_sum, float* grad_weight, float* grad_guidance, int num_threads) {
+    if (L < 1 || L > 6) return -4;
+#ifdef _OPENMP
+    if (num_threads <= 0) num_threads = omp_get_max_threads();
+#else
+    num_threads = 1;
+#endif
+    for (int level = 0; level < L; ++level) {
+        const int S = level + 1;
+        const int64_t lo = (int64_t)level * H * W;
+#pragma omp parallel for schedule(static) num_threads(num_threads)
+        for (int qy = 0; qy < H; ++qy) {
+            for (int qx = 0; qx < W; ++qx) {
+                const int64_t q = (int64_t)qy * W + qx;
+                { /* grad_weight :244-247 */
+                    const float* go = grad_out + q * 4;
+                    const float* f = rgb_filtered + (lo + q) * 4;
+                    float t = go[0] * f[0];
+                    t = fmaf(go[1], f[1], t);
+                    t = fmaf(go[2], f[2], t);
+                    grad_weight[lo + q] = t;
+                }
+                const float gq = guidance[lo + q];
+                const float* in = img_in + q * 4;
+                float acc = 0.f;
+                for (int py = qy - S; py <= qy + S; ++py)
+                    for (int px = qx - S; px <= qx + S; ++px) {
+                        if (py < 0 || py >= H || px < 0 || px >= W) continue; /* threads exist for image pixels only */
+                        const int64_t pi = (int64_t)py * W + px;
+                        const float* go = grad_out + pi * 4;
+                        const float* f = rgb_filtered + (lo + pi) * 4;
+                        const float k = m_fexp(gq - max_map[lo + pi]) * inv_kernel_sum[lo + pi]; /* :293 */
+                        float res = go[0] * (in[0] - f[0]);                                     /* :294-297 */
+                        res = fmaf(go[1], in[1] - f[1], res);
+                        res = fmaf(go[2], in[2] - f[2], res);
+                        res *= weight[lo + pi] * k;                                              /* :298 */
+                        acc += res;                                                              /* :300 */
+                    }
+                grad_guidance[lo + q] = acc;
             }
         }
     }

@@ -125,6 +125,13 @@ int orc_render_pixel(const orc_tree* t, const orc_camera* cam, const orc_options
  * weight,guidance [L][H][W]; noisy,out [H][W][4] */
 int orc_filter(int L, int H, int W, const float* weight, const float* guidance,
                const float* noisy, float* out, int num_threads);
+/* training side (filtering.cu:230-301,596-707): forward that also saves rgb_filtered [L][H][W][4],
+ * max_map and inv_kernel_sum [L][H][W]; backward -> grad_weight, grad_guidance [L][H][W] */
+int orc_filter_train_forward(int L, int H, int W, const float* weight, const float* guidance, const float* noisy,
+                             float* out, float* rgb_filtered, float* max_map, float* inv_kernel_sum, int num_threads);
+int orc_filter_backward(int L, int H, int W, const float* grad_out, const float* img_in, const float* weight,
+                        const float* guidance, const float* rgb_filtered, const float* max_map,
+                        const float* inv_kernel_sum, float* grad_weight, float* grad_guidance, int num_threads);
 
 /* instrumentation: march steps per pixel */
 int orc_frame_steps(const orc_tree* t, const orc_camera* cam, const orc_options* opt,

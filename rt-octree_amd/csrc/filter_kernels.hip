@@ -21,6 +21,8 @@
 // wave per SIMD.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "rto_launch.h"
 
 #pragma clang fp contract(off)
@@ -29,9 +31,15 @@ namespace rto {
 
 constexpr int kFiltW = 32, kFiltH = 8;  // output tile per 256-thread workgroup
 
+// what Filtering::forward keeps for backward when requires_grad (filtering.cu:205-216)
+struct LevelSave {
+    float4 rgb_filtered;  // (sum_q k_q rgb_q) / sum_q k_q, alpha 0 (torch::zeros, never written)
+    float max_val, inv_kernel_sum;
+};
+
 template <int S, int TW>
 RTO_DEV void filter_level(const float* __restrict__ g, const float4* __restrict__ rgb, int centre, float w_pix,
-                          float& o0, float& o1, float& o2, bool first) {
+                          float& o0, float& o1, float& o2, bool first, LevelSave* save = nullptr) {
     float max_val = -3.402823466e+38f;
 #pragma unroll 1
     for (int dy = -S; dy <= S; ++dy) {
@@ -71,6 +79,11 @@ RTO_DEV void filter_level(const float* __restrict__ g, const float4* __restrict_
     float r = rg.x, gg = rg.y, b = bs.x;
     const float kernel_sum = bs.y;
     const float inv = 1.0f / kernel_sum;
+    if (save) {
+        save->max_val = max_val;
+        save->inv_kernel_sum = inv;
+        save->rgb_filtered = make_float4(r * inv, gg * inv, b * inv, 0.f);
+    }
     const float w = w_pix * inv;
     r *= w;
     gg *= w;
@@ -86,12 +99,15 @@ RTO_DEV void filter_level(const float* __restrict__ g, const float4* __restrict_
     }
 }
 
-template <int L>
+// SAVE: the training forward (Filtering::forward with requires_grad, filtering.cu:596-665) -- the same
+// pass, also storing rgb_filtered [n][L][H][W] (float4), max_map and inv_kernel_sum [n][L][H][W]
+template <int L, bool SAVE>
 __global__ void __launch_bounds__(256, 4) filter_fused(const float* __restrict__ weight,    // [n][L][H][W]
                                                         const float* __restrict__ guidance,  // [n][L][H][W]
                                                         const float4* __restrict__ img_in,   // [n][H][W]
                                                         float4* __restrict__ img_out,        // [n][H][W]
-                                                        int H, int W) {
+                                                        int H, int W, float4* __restrict__ rgb_filtered,
+                                                        float* __restrict__ max_map, float* __restrict__ inv_kernel_sum) {
     constexpr int TW = kFiltW + 2 * L, TH = kFiltH + 2 * L;
     __shared__ float4 s_rgb[TH * TW];
     __shared__ float s_g[L][TH * TW];
@@ -125,29 +141,166 @@ __global__ void __launch_bounds__(256, 4) filter_fused(const float* __restrict__
     const int centre = (ly + L) * TW + lx + L;
 
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-    filter_level<1, TW>(s_g[0], s_rgb, centre, weight[pidx], o0, o1, o2, true);
-    if constexpr (L >= 2) filter_level<2, TW>(s_g[1], s_rgb, centre, weight[HW + pidx], o0, o1, o2, false);
-    if constexpr (L >= 3) filter_level<3, TW>(s_g[2], s_rgb, centre, weight[2 * HW + pidx], o0, o1, o2, false);
-    if constexpr (L >= 4) filter_level<4, TW>(s_g[3], s_rgb, centre, weight[3 * HW + pidx], o0, o1, o2, false);
-    if constexpr (L >= 5) filter_level<5, TW>(s_g[4], s_rgb, centre, weight[4 * HW + pidx], o0, o1, o2, false);
-    if constexpr (L >= 6) filter_level<6, TW>(s_g[5], s_rgb, centre, weight[5 * HW + pidx], o0, o1, o2, false);
+    LevelSave sv;
+    auto level = [&](auto s_tag, int l, bool first) {
+        constexpr int S = decltype(s_tag)::value;
+        filter_level<S, TW>(s_g[l], s_rgb, centre, weight[l * HW + pidx], o0, o1, o2, first, SAVE ? &sv : nullptr);
+        if constexpr (SAVE) {
+            const int64_t si = ((int64_t)blockIdx.z * L + l) * HW + pidx;
+            rgb_filtered[si] = sv.rgb_filtered;
+            max_map[si] = sv.max_val;
+            inv_kernel_sum[si] = sv.inv_kernel_sum;
+        }
+    };
+    level(std::integral_constant<int, 1>{}, 0, true);
+    if constexpr (L >= 2) level(std::integral_constant<int, 2>{}, 1, false);
+    if constexpr (L >= 3) level(std::integral_constant<int, 3>{}, 2, false);
+    if constexpr (L >= 4) level(std::integral_constant<int, 4>{}, 3, false);
+    if constexpr (L >= 5) level(std::integral_constant<int, 5>{}, 4, false);
+    if constexpr (L >= 6) level(std::integral_constant<int, 6>{}, 5, false);
     img_out[pidx] = make_float4(o0, o1, o2, 1.0f);
+}
+
+// Backward of the filter (filtering.cu:230-301, 667-707), gather form: one thread per pixel q and level,
+//   grad_weight[l][q]   = <grad_out[q], rgb_filtered_l[q]>
+//   grad_guidance[l][q] = sum_{p in window_S(q), p in image} w_l[p] * (exp(g_l[q] - max_l[p]) * inv_l[p])
+//                                                             * <grad_out[p], img_in[q] - rgb_filtered_l[p]>
+// with p in row-major order -- the order oracle/rto_oracle.c orc_filter_backward fixes (the reference
+// scatters the same terms with atomicAdd in hardware order).  Tile + halo of grad_out and, per level, of
+// rgb_filtered and {w, max, inv} are staged in LDS; q lies in every window it is gathered from, so
+// g[q] - max[p] <= 0 and the branch-free exp applies.
+template <int L>
+__global__ void __launch_bounds__(256, 2) filter_backward(const float4* __restrict__ grad_out,      // [n][H][W]
+                                                           const float4* __restrict__ img_in,        // [n][H][W]
+                                                           const float* __restrict__ weight,         // [n][L][H][W]
+                                                           const float* __restrict__ guidance,       // [n][L][H][W]
+                                                           const float4* __restrict__ rgb_filtered,  // [n][L][H][W]
+                                                           const float* __restrict__ max_map,        // [n][L][H][W]
+                                                           const float* __restrict__ inv_kernel_sum, // [n][L][H][W]
+                                                           float* __restrict__ grad_weight,          // [n][L][H][W]
+                                                           float* __restrict__ grad_guidance,        // [n][L][H][W]
+                                                           int H, int W) {
+    constexpr int TW = kFiltW + 2 * L, TH = kFiltH + 2 * L;
+    __shared__ float4 s_go[TH * TW];   // grad_out
+    __shared__ float4 s_f[TH * TW];    // rgb_filtered of the level (w = 1 inside the image, 0 outside)
+    __shared__ float4 s_wmi[TH * TW];  // {weight, max, inv_kernel_sum, -}
+
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * kFiltW - L, y0 = blockIdx.y * kFiltH - L;
+    const int64_t HW = (int64_t)H * W;
+    const int64_t img0 = (int64_t)blockIdx.z * HW, lvl0 = (int64_t)blockIdx.z * L * HW;
+
+    const int lx = tid & (kFiltW - 1), ly = tid / kFiltW;
+    const int qx = blockIdx.x * kFiltW + lx, qy = blockIdx.y * kFiltH + ly;
+    const bool q_in = qx < W && qy < H;
+    const int64_t qidx = (int64_t)qy * W + qx;
+    const int centre = (ly + L) * TW + lx + L;
+    const float4 in_q = q_in ? img_in[img0 + qidx] : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int e = tid; e < TH * TW; e += 256) {
+        const int ty = e / TW, tx = e - ty * TW;
+        const int gx = x0 + tx, gy = y0 + ty;
+        const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
+        s_go[e] = in ? grad_out[img0 + (int64_t)gy * W + gx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll 1
+    for (int l = 0; l < L; ++l) {
+        const int S = l + 1;
+        __syncthreads();  // previous level's taps are done with s_f / s_wmi (and s_go is complete)
+        for (int e = tid; e < TH * TW; e += 256) {
+            const int ty = e / TW, tx = e - ty * TW;
+            const int gx = x0 + tx, gy = y0 + ty;
+            const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
+            const int64_t gi = lvl0 + l * HW + (int64_t)gy * W + gx;
+            float4 f = make_float4(0.f, 0.f, 0.f, 0.f), wmi = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in) {
+                f = rgb_filtered[gi];
+                f.w = 1.f;  // marks "p is an image pixel" (the reference has no thread for the others)
+                wmi = make_float4(weight[gi], max_map[gi], inv_kernel_sum[gi], 0.f);
+            }
+            s_f[e] = f;
+            s_wmi[e] = wmi;
+        }
+        __syncthreads();
+        if (q_in) {
+            const int64_t qi = lvl0 + l * HW + qidx;
+            {  // grad_weight_accumulate :244-247
+                const float4 go = s_go[centre], f = s_f[centre];
+                float t = go.x * f.x;
+                t = __builtin_fmaf(go.y, f.y, t);
+                t = __builtin_fmaf(go.z, f.z, t);
+                grad_weight[qi] = t;
+            }
+            const float gq = guidance[qi];
+            float acc = 0.f;
+#pragma unroll 1
+            for (int dy = -S; dy <= S; ++dy) {
+                const int e0 = centre + dy * TW;
+#pragma unroll 1
+                for (int dx = -S; dx <= S; ++dx) {
+                    const float4 f = s_f[e0 + dx];
+                    const float4 wmi = s_wmi[e0 + dx];
+                    const float4 go = s_go[e0 + dx];
+                    const float k = fexp_f32_le88(gq - wmi.y) * wmi.z;  // :293
+                    float res = go.x * (in_q.x - f.x);                // :294-297
+                    res = __builtin_fmaf(go.y, in_q.y - f.y, res);
+                    res = __builtin_fmaf(go.z, in_q.z - f.z, res);
+                    res *= wmi.x * k;                                  // :298
+                    if (f.w != 0.f) acc += res;                        // :300 (gathered, row-major p)
+                }
+            }
+            grad_guidance[qi] = acc;
+        }
+    }
 }
 
 hipError_t launch_filter(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
                          float* img_out, hipStream_t stream) {
+    return launch_filter_train(weight, guidance, L, H, W, n, img_in, img_out, nullptr, nullptr, nullptr, stream);
+}
+
+// rgb_filtered == nullptr: inference forward; else all three save arrays are written too
+hipError_t launch_filter_train(const float* weight, const float* guidance, int L, int H, int W, int n,
+                               const float* img_in, float* img_out, float* rgb_filtered, float* max_map,
+                               float* inv_kernel_sum, hipStream_t stream) {
     const dim3 grid((W + kFiltW - 1) / kFiltW, (H + kFiltH - 1) / kFiltH, n), block(256);
     const float4* in4 = reinterpret_cast<const float4*>(img_in);
     float4* out4 = reinterpret_cast<float4*>(img_out);
+    float4* rf4 = reinterpret_cast<float4*>(rgb_filtered);
+#define RTO_FILT(LL)                                                                                                   \
+    case LL:                                                                                                           \
+        if (rgb_filtered)                                                                                              \
+            hipLaunchKernelGGL((filter_fused<LL, true>), grid, block, 0, stream, weight, guidance, in4, out4, H, W, rf4, \
+                               max_map, inv_kernel_sum);                                                               \
+        else                                                                                                           \
+            hipLaunchKernelGGL((filter_fused<LL, false>), grid, block, 0, stream, weight, guidance, in4, out4, H, W,    \
+                               (float4*)nullptr, (float*)nullptr, (float*)nullptr);                                    \
+        break;
     switch (L) {  // kernel_apply filtering.cu:338-367 supports SUPPORT 1..6
-        case 1: hipLaunchKernelGGL(filter_fused<1>, grid, block, 0, stream, weight, guidance, in4, out4, H, W); break;
-        case 2: hipLaunchKernelGGL(filter_fused<2>, grid, block, 0, stream, weight, guidance, in4, out4, H, W); break;
-        case 3: hipLaunchKernelGGL(filter_fused<3>, grid, block, 0, stream, weight, guidance, in4, out4, H, W); break;
-        case 4: hipLaunchKernelGGL(filter_fused<4>, grid, block, 0, stream, weight, guidance, in4, out4, H, W); break;
-        case 5: hipLaunchKernelGGL(filter_fused<5>, grid, block, 0, stream, weight, guidance, in4, out4, H, W); break;
-        case 6: hipLaunchKernelGGL(filter_fused<6>, grid, block, 0, stream, weight, guidance, in4, out4, H, W); break;
+        RTO_FILT(1) RTO_FILT(2) RTO_FILT(3) RTO_FILT(4) RTO_FILT(5) RTO_FILT(6)
         default: return hipErrorInvalidValue;
     }
+#undef RTO_FILT
+    return hipGetLastError();
+}
+
+hipError_t launch_filter_backward(const float* grad_out, const float* img_in, const float* weight, const float* guidance,
+                                  const float* rgb_filtered, const float* max_map, const float* inv_kernel_sum, int L,
+                                  int H, int W, int n, float* grad_weight, float* grad_guidance, hipStream_t stream) {
+    const dim3 grid((W + kFiltW - 1) / kFiltW, (H + kFiltH - 1) / kFiltH, n), block(256);
+    const float4* go4 = reinterpret_cast<const float4*>(grad_out);
+    const float4* in4 = reinterpret_cast<const float4*>(img_in);
+    const float4* rf4 = reinterpret_cast<const float4*>(rgb_filtered);
+#define RTO_FILTB(LL)                                                                                                  \
+    case LL:                                                                                                           \
+        hipLaunchKernelGGL(filter_backward<LL>, grid, block, 0, stream, go4, in4, weight, guidance, rf4, max_map,      \
+                           inv_kernel_sum, grad_weight, grad_guidance, H, W);                                          \
+        break;
+    switch (L) {
+        RTO_FILTB(1) RTO_FILTB(2) RTO_FILTB(3) RTO_FILTB(4) RTO_FILTB(5) RTO_FILTB(6)
+        default: return hipErrorInvalidValue;
+    }
+#undef RTO_FILTB
     return hipGetLastError();
 }
 

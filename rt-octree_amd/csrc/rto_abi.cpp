@@ -957,6 +957,34 @@ int rto_filtering_batch(void* stream, const float* weight_map, const float* guid
     return RTO_OK;
 }
 
+int rto_filtering_train_forward(void* stream, const float* weight_map, const float* guidance_map, int L, int H, int W,
+                                int n, const float* img_in, float* img_out, float* rgb_filtered, float* max_map,
+                                float* inv_kernel_sum) {
+    if (!weight_map || !guidance_map || !img_in || !img_out || !rgb_filtered || !max_map || !inv_kernel_sum || H <= 0 ||
+        W <= 0 || n < 1)
+        return set_err(RTO_E_INVALID, "rto_filtering_train_forward: null pointer or bad size");
+    if (L < 1 || L > 6) return set_err(RTO_E_INVALID, "Kernel size == " + std::to_string(L * 2 + 1) + " not supported.");
+    if (img_in == img_out) return set_err(RTO_E_INVALID, "rto_filtering_train_forward: img_in and img_out must differ");
+    hipError_t e = rto::launch_filter_train(weight_map, guidance_map, L, H, W, n, img_in, img_out, rgb_filtered, max_map,
+                                            inv_kernel_sum, (hipStream_t)stream);
+    if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("filter launch failed: ") + hipGetErrorString(e));
+    return RTO_OK;
+}
+
+int rto_filtering_backward(void* stream, const float* grad_output, const float* img_in, const float* weight_map,
+                           const float* guidance_map, const float* rgb_filtered, const float* max_map,
+                           const float* inv_kernel_sum, int L, int H, int W, int n, float* grad_weight,
+                           float* grad_guidance) {
+    if (!grad_output || !img_in || !weight_map || !guidance_map || !rgb_filtered || !max_map || !inv_kernel_sum ||
+        !grad_weight || !grad_guidance || H <= 0 || W <= 0 || n < 1)
+        return set_err(RTO_E_INVALID, "rto_filtering_backward: null pointer or bad size");
+    if (L < 1 || L > 6) return set_err(RTO_E_INVALID, "Kernel size == " + std::to_string(L * 2 + 1) + " not supported.");
+    hipError_t e = rto::launch_filter_backward(grad_output, img_in, weight_map, guidance_map, rgb_filtered, max_map,
+                                               inv_kernel_sum, L, H, W, n, grad_weight, grad_guidance, (hipStream_t)stream);
+    if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("filter backward launch failed: ") + hipGetErrorString(e));
+    return RTO_OK;
+}
+
 int rto_filtering(void* stream, const float* weight_map, const float* guidance_map, int L, int H, int W,
                   const float* img_in, float* img_out) {
     return rto_filtering_batch(stream, weight_map, guidance_map, L, H, W, 1, img_in, img_out);

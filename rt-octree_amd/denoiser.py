@@ -192,6 +192,65 @@ class FusedGuidanceNet:
             pass
 
 
+class _Filtering(torch.autograd.Function):
+    """denoiser::Filtering (filtering.cu:596-707): the guided filter under autograd.  Forward runs the
+    fused HIP kernel (saving rgb_filtered / max_map / inv_kernel_sum per level when a gradient is
+    wanted), backward the gather-form HIP kernel; both through the C ABI on torch's current stream."""
+
+    @staticmethod
+    def forward(ctx, weight_map, guidance_map, img_in, requires_grad):
+        from ._lib import check, lib
+        if not (weight_map.is_cuda and guidance_map.is_cuda and img_in.is_cuda):
+            raise RuntimeError("filtering_autograd needs CUDA(HIP) tensors: the filter has no CPU path")
+        w = weight_map.detach().float().contiguous()
+        g = guidance_map.detach().float().contiguous()
+        x = img_in.detach().float().contiguous()
+        B, L, H, W = g.shape
+        if w.shape != g.shape or tuple(x.shape) != (B, H, W, 4):
+            raise RuntimeError("filtering_autograd: weight/guidance [B,L,H,W] and img_in [B,H,W,4] expected")
+        out = torch.empty_like(x)
+        s = torch.cuda.current_stream(x.device).cuda_stream
+        with torch.cuda.device(x.device):
+            if requires_grad:
+                rf = torch.empty((B, L, H, W, 4), device=x.device, dtype=torch.float32)
+                mx = torch.empty((B, L, H, W), device=x.device, dtype=torch.float32)
+                inv = torch.empty((B, L, H, W), device=x.device, dtype=torch.float32)
+                check(lib().rto_filtering_train_forward(s, w.data_ptr(), g.data_ptr(), L, H, W, B, x.data_ptr(),
+                                                        out.data_ptr(), rf.data_ptr(), mx.data_ptr(), inv.data_ptr()))
+                ctx.save_for_backward(w, g, x, rf, mx, inv)
+            else:
+                check(lib().rto_filtering_batch(s, w.data_ptr(), g.data_ptr(), L, H, W, B, x.data_ptr(), out.data_ptr()))
+        ctx.has_saved = bool(requires_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        from ._lib import check, lib
+        if not ctx.has_saved:
+            raise RuntimeError("filtering_autograd was called with requires_grad=False")
+        w, g, x, rf, mx, inv = ctx.saved_tensors
+        go = grad_output.float().contiguous()
+        B, L, H, W = g.shape
+        gw, gg = torch.empty_like(w), torch.empty_like(g)
+        s = torch.cuda.current_stream(x.device).cuda_stream
+        with torch.cuda.device(x.device):
+            check(lib().rto_filtering_backward(s, go.data_ptr(), x.data_ptr(), w.data_ptr(), g.data_ptr(), rf.data_ptr(),
+                                               mx.data_ptr(), inv.data_ptr(), L, H, W, B, gw.data_ptr(), gg.data_ptr()))
+        return gw, gg, None, None  # (:701-706: no gradient for img_in / the flag)
+
+
+def filtering_autograd(weight_map, guidance_map, imgs_in, requires_grad=False):
+    """`_denoiser.filtering_autograd` (denoiser/extension/bindings.cpp): weight_map, guidance_map
+    [B,L,H,W], imgs_in [B,H,W,4] -> filtered images [B,H,W,4]."""
+    return _Filtering.apply(weight_map, guidance_map, imgs_in, requires_grad)
+
+
+def filtering(model, aux_buffer, img_in, requires_grad=False):
+    """denoiser/network.py:77-84: model(aux) -> (weight_map, guidance_map) -> filtering_autograd."""
+    weight_map, guidance_map = model(aux_buffer)
+    return filtering_autograd(weight_map, guidance_map, img_in, requires_grad=requires_grad)
+
+
 class Denoiser:
     """volrend::Denoiser (denoiser.hpp:11-21, denoiser.cpp:31-61).
 

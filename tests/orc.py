@@ -181,6 +181,40 @@ def filter_levels(weight, guidance, noisy, threads=0):
     return out
 
 
+def filter_train_forward(weight, guidance, noisy, threads=0):
+    """-> out [H,W,4], rgb_filtered [L,H,W,4], max_map [L,H,W], inv_kernel_sum [L,H,W]"""
+    weight = np.ascontiguousarray(weight, np.float32)
+    guidance = np.ascontiguousarray(guidance, np.float32)
+    noisy = np.ascontiguousarray(noisy, np.float32)
+    L, H, W = guidance.shape
+    out = np.zeros((H, W, 4), np.float32)
+    rf = np.zeros((L, H, W, 4), np.float32)
+    mx = np.zeros((L, H, W), np.float32)
+    inv = np.zeros((L, H, W), np.float32)
+    P = lambda a: C.c_void_p(a.ctypes.data)
+    f = lib().orc_filter_train_forward
+    f.restype = C.c_int
+    rc = f(C.c_int(L), C.c_int(H), C.c_int(W), P(weight), P(guidance), P(noisy), P(out), P(rf), P(mx), P(inv), C.c_int(threads))
+    if rc:
+        raise RuntimeError("orc_filter_train_forward failed: %d" % rc)
+    return out, rf, mx, inv
+
+
+def filter_backward(grad_out, img_in, weight, guidance, rgb_filtered, max_map, inv_kernel_sum, threads=0):
+    """-> grad_weight, grad_guidance [L,H,W]"""
+    arrs = [np.ascontiguousarray(a, np.float32) for a in (grad_out, img_in, weight, guidance, rgb_filtered, max_map, inv_kernel_sum)]
+    L, H, W = arrs[3].shape
+    gw = np.zeros((L, H, W), np.float32)
+    gg = np.zeros((L, H, W), np.float32)
+    P = lambda a: C.c_void_p(a.ctypes.data)
+    f = lib().orc_filter_backward
+    f.restype = C.c_int
+    rc = f(C.c_int(L), C.c_int(H), C.c_int(W), *[P(a) for a in arrs], P(gw), P(gg), C.c_int(threads))
+    if rc:
+        raise RuntimeError("orc_filter_backward failed: %d" % rc)
+    return gw, gg
+
+
 def rgba8(rgba):
     rgba = np.ascontiguousarray(rgba, np.float32)
     out = np.empty(rgba.shape, np.uint8)

@@ -28,6 +28,22 @@ def main():
         e1.record(s)
         torch.cuda.synchronize()
         print("filter n=%d %dx%d L=%d: %.3f ms/image" % (n, W, H, L, e0.elapsed_time(e1) / reps / n), flush=True)
+        # training side: forward with saves + backward through the autograd wrapper's ABI calls
+        from rt_octree_amd import denoiser
+        wr, gr = w.clone().requires_grad_(True), g.clone().requires_grad_(True)
+        go = torch.randn_like(img)
+        for timed in (False, True):
+            if timed:
+                torch.cuda.synchronize()
+                e0.record(s)
+            for _ in range(5):
+                o = denoiser.filtering_autograd(wr, gr, img, requires_grad=True)
+                o.backward(go)
+                wr.grad = gr.grad = None
+            if timed:
+                e1.record(s)
+                torch.cuda.synchronize()
+                print("  train forward + backward: %.3f ms/image" % (e0.elapsed_time(e1) / 5 / n), flush=True)
 
 
 if __name__ == "__main__":

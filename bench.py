@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=24)
-    ap.add_argument("--batch", type=int, default=16, help="frames per launch group (1..16)")
+    ap.add_argument("--batch", type=int, default=32, help="frames per launch group (1..32)")
     ap.add_argument("--size", type=int, default=800, help="square image size (config C2/C5)")
     ap.add_argument("--width", type=int, default=0, help="with --height: non-square frames (config C4: 1920x1080)")
     ap.add_argument("--height", type=int, default=0)
@@ -111,7 +111,7 @@ def main():
     W = H = args.size
     if args.width > 0 and args.height > 0:
         W, H = args.width, args.height
-    B = max(1, min(16, args.batch))
+    B = max(1, min(32, args.batch))
     tree_host = None
     if args.tree:
         path = args.tree
@@ -237,7 +237,8 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            pj = json.load(open(pmc))  # measured at pj["frames_per_launch"] frames per launch: per-frame bytes scale
+            traffic = pj.get("hbm_bytes_per_launch") * frames_per_launch / float(pj.get("frames_per_launch", frames_per_launch))
         except Exception:
             traffic = None
 

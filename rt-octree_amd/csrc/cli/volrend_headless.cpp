@@ -8,8 +8,8 @@
 //   * `--ts_module` is only required when the options say denoise = true (the reference constructs
 //     the Denoiser unconditionally and aborts without it, main_headless.cpp:455-456);
 //   * TanksAndTemple pose files are read in sorted order (the reference uses directory order);
-//   * `--batch B` (1..16, default 1) renders B poses per launch of the persistent ray-queue kernel and
-//     denoises them as one batch; images are identical to B = 1, the report is still per frame;
+//   * `--batch B` (1..32, default 32) renders B poses per launch of the persistent ray-queue kernel and
+//     denoises them as one batch; images are identical to B = 1 (one launch per frame, the reference's loop), the report is still per frame;
 //   * extra flags `--shard i/N` (render poses i, i+N, ...: frame sharding across GPUs, one process
 //     per GPU) and `--warmup K` (default 100 like the reference).
 #include <cmath>
@@ -108,7 +108,7 @@ void usage() {
         "  -o,--write_images DIR   write r_<i>.png (or buf_<name>.bin with --write_buffer)\n"
         "  --write_buffer  --max_imgs N  --scale S  -i intrin  -r,--reverse_yz\n"
         "  --shard i/N        render poses i, i+N, ... only     --warmup K (100)\n"
-        "  --batch B          poses per launch (1..16, default 1 = the reference's frame loop)\n"
+        "  --batch B          poses per launch (1..32, default 32; 1 = one launch per frame like the reference's loop)\n"
         "  --quant_direct     render a quantised tree.npz from its codebooks (no expansion to dense fp16)\n"
         "  --print_poses      parse the poses, print them (column-major 4x3) and exit\n");
 }
@@ -203,7 +203,11 @@ int main(int argc, char** argv) {
     const std::string out_dir = args.get("write_images", "");
     if (!out_dir.empty()) fs::create_directories(out_dir);
 
-    const int batch = std::max(1, std::min(16, std::atoi(args.get("batch", "1").c_str())));
+    int batch = std::max(1, std::min(32, std::atoi(args.get("batch", "32").c_str())));
+    {  // no more frame slots than this process has poses to render
+        const size_t n_mine = (ps.trans.size() + (size_t)shard_n - 1 - (size_t)shard_i) / (size_t)shard_n;
+        if ((size_t)batch > n_mine) batch = (int)std::max<size_t>(1, n_mine);
+    }
     rto_ctx* ctx = nullptr;
     CHECK_RTO(rto_ctx_create_batch(width, height, batch, device, &ctx));
 

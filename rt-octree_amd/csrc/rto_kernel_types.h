@@ -68,7 +68,7 @@ struct TileMap {
 
 // One frame of a batched launch (render_persist): its camera, its RNG base state and where its
 // pixels go.  width/height are shared by the batch.
-constexpr int kMaxBatch = 16;
+constexpr int kMaxBatch = 32;
 struct FrameDesc {
     float fx, fy;
     float transform[12];

@@ -42,7 +42,7 @@ def main():
         c.set_c2w(p)
         cams.append(c)
     opt = R.RenderOptions(spp=args.spp, denoise=False)
-    ctx = R.RenderContext(W, H, frames=16)
+    ctx = R.RenderContext(W, H, frames=32)
     stream = torch.cuda.current_stream()
 
     def timed(fn):

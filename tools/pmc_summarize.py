@@ -50,8 +50,8 @@ def main():
     if traffic_out and "FETCH_SIZE" in rp and "WRITE_SIZE" in rp:
         hbm = (rp["FETCH_SIZE"]["mean"] + rp["WRITE_SIZE"]["mean"]) * 1024.0
         with open(traffic_out, "w") as f:
-            json.dump({"hbm_bytes_per_launch": hbm, "frames_per_launch": 16,
-                       "source": os.path.basename(out) + " (render_persist<6>, 16 frames per launch, FETCH_SIZE + WRITE_SIZE in "
+            json.dump({"hbm_bytes_per_launch": hbm, "frames_per_launch": int(os.environ.get("RTO_FRAMES_PER_LAUNCH", "32")),
+                       "source": os.path.basename(out) + " (render_persist<6>, FETCH_SIZE + WRITE_SIZE in "
                        "separate --pmc passes; the traversal's scattered dword loads count 64 B per touched line, as the "
                        "calibration probe tools/pmc_probe.py showed)"}, f, indent=1)
     print(json.dumps({k: {c: round(v["mean"], 1) for c, v in cs.items()} for k, cs in kernels.items()}, indent=1))

@@ -176,15 +176,16 @@ float orc_det_expf(float x) {
  * Deterministic fp32-only expf for the filter's softmax taps (164 per pixel at L = 4): the same
  * structure in float arithmetic, every multiply-add an explicit fmaf -- k = rint(x log2 e) by the
  * 1.5*2^23 trick, two-term Cody-Waite reduction, degree-7 Taylor (Horner), exponent-bit scaling.
- * Max error 0.9 ulp on [-87.3, 88.7] (measured in tests/test_oracle_kat.py); results below FLT_MIN
- * flush to 0.  The reference's __expf (filtering.cu:195) is ex2.approx(x*log2e), ~2 ulp plus the
+ * Max error 0.9 ulp on [-87.3, 88.7] (measured in tests/test_oracle_kat.py); below that the result is
+ * a (coarser) subnormal, and exactly 0 from x = -87.68 down (the argument is clamped at -88, where k = -127
+ * and the scale 2^k is written as +0).  The reference's __expf (filtering.cu:195) is ex2.approx(x*log2e), ~2 ulp plus the
  * rounding of x*log2e: this definition is at least as accurate.  fmaf is correctly rounded on both
  * sides (glibc / v_fma_f32), so the HIP kernel reproduces these bits.
  */
 float orc_fexp(float x) {
     if (x != x) return x;
     if (x > 88.72283935546875f) return INFINITY;
-    if (x < -87.33654022216797f) return 0.0f;
+    x = fmaxf(x, -88.0f); /* k = -127 there: the scale below is +0, i.e. exp flushes to 0 from -88 down */
     const float kf = fmaf(x, 1.44269502162933349609375f, 12582912.0f) - 12582912.0f;
     float r = fmaf(kf, -0.693145751953125f, x);
     r = fmaf(kf, -1.42860676533018704e-06f, r);
@@ -196,10 +197,10 @@ float orc_fexp(float x) {
     p = fmaf(p, r, 0.5f);
     p = fmaf(p, r, 1.0f);
     p = fmaf(p, r, 1.0f);
-    int ki = (int)kf;
+    int ki = (int)kf; /* -127 .. 128 */
     if (ki > 127) { ki = 127; p = p * 2.0f; } /* 2^128 has no fp32 encoding */
     union { uint32_t u; float f; } sc;
-    sc.u = (uint32_t)(ki + 127) << 23;
+    sc.u = (uint32_t)(ki + 127) << 23; /* ki = -127: +0.0 */
     return p * sc.f;
 }
 

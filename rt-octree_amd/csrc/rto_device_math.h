@@ -139,7 +139,7 @@ RTO_DEV float det_expf(float x) {
 RTO_DEV float fexp_f32(float x) {
     if (x != x) return x;
     if (x > 88.72283935546875f) return __builtin_inff();
-    if (x < -87.33654022216797f) return 0.0f;
+    x = __builtin_fmaxf(x, -88.0f);
     const float kf = __builtin_fmaf(x, 1.44269502162933349609375f, 12582912.0f) - 12582912.0f;
     float r = __builtin_fmaf(kf, -0.693145751953125f, x);
     r = __builtin_fmaf(kf, -1.42860676533018704e-06f, r);
@@ -159,11 +159,14 @@ RTO_DEV float fexp_f32(float x) {
     return p * __uint_as_float((uint32_t)(ki + 127) << 23);
 }
 
-// The same function without control flow, for arguments x <= 88 (the filter only ever passes
-// g - max <= 0): identical values, NaN included (cvt of NaN is 0, NaN * 2^0 = NaN, and both
-// comparisons below are false for NaN), one select instead of three branches per tap.
+// The same function without control flow, for finite arguments x <= 88 (the filter only ever passes
+// g - max <= 0): identical values.  The scale 2^k comes straight from the bits of the rounding
+// constant trick: t = x*log2e + 1.5*2^23 holds k in its low mantissa bits (0x4B400000 + k as an
+// integer), and (t_bits << 23) + 0x3f800000 keeps exactly (k + 127) << 23 -- no float->int convert.
 RTO_DEV float fexp_f32_le88(float x) {
-    const float kf = __builtin_fmaf(x, 1.44269502162933349609375f, 12582912.0f) - 12582912.0f;
+    x = __builtin_fmaxf(x, -88.0f);
+    const float t = __builtin_fmaf(x, 1.44269502162933349609375f, 12582912.0f);
+    const float kf = t - 12582912.0f;
     float r = __builtin_fmaf(kf, -0.693145751953125f, x);
     r = __builtin_fmaf(kf, -1.42860676533018704e-06f, r);
     float p = 1.0f / 5040.0f;
@@ -174,8 +177,7 @@ RTO_DEV float fexp_f32_le88(float x) {
     p = __builtin_fmaf(p, r, 0.5f);
     p = __builtin_fmaf(p, r, 1.0f);
     p = __builtin_fmaf(p, r, 1.0f);
-    const float res = p * __uint_as_float((uint32_t)((int)kf + 127) << 23);
-    return x < -87.33654022216797f ? 0.0f : res;
+    return p * __uint_as_float((__float_as_uint(t) << 23) + 0x3f800000u);
 }
 
 // Two arguments at once: the same operations on a 2-vector, which gfx950 executes as packed fp32
@@ -185,7 +187,10 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 typedef int int2v __attribute__((ext_vector_type(2)));
 RTO_DEV float2v splat2(float v) { return float2v{v, v}; }
 RTO_DEV float2v fexp_f32_le88_x2(float2v x) {
-    const float2v kf = __builtin_elementwise_fma(x, splat2(1.44269502162933349609375f), splat2(12582912.0f)) - 12582912.0f;
+    x.x = __builtin_fmaxf(x.x, -88.0f);
+    x.y = __builtin_fmaxf(x.y, -88.0f);
+    const float2v t = __builtin_elementwise_fma(x, splat2(1.44269502162933349609375f), splat2(12582912.0f));
+    const float2v kf = t - 12582912.0f;
     float2v r = __builtin_elementwise_fma(kf, splat2(-0.693145751953125f), x);
     r = __builtin_elementwise_fma(kf, splat2(-1.42860676533018704e-06f), r);
     float2v p = splat2(1.0f / 5040.0f);
@@ -196,15 +201,10 @@ RTO_DEV float2v fexp_f32_le88_x2(float2v x) {
     p = __builtin_elementwise_fma(p, r, splat2(0.5f));
     p = __builtin_elementwise_fma(p, r, splat2(1.0f));
     p = __builtin_elementwise_fma(p, r, splat2(1.0f));
-    const int2v ki = __builtin_convertvector(kf, int2v);
-    const int2v sb = (ki + 127) << 23;
     float2v sc;
-    sc.x = __int_as_float(sb.x);
-    sc.y = __int_as_float(sb.y);
-    float2v res = p * sc;
-    res.x = x.x < -87.33654022216797f ? 0.0f : res.x;
-    res.y = x.y < -87.33654022216797f ? 0.0f : res.y;
-    return res;
+    sc.x = __uint_as_float((__float_as_uint(t.x) << 23) + 0x3f800000u);
+    sc.y = __uint_as_float((__float_as_uint(t.y) << 23) + 0x3f800000u);
+    return p * sc;
 }
 
 RTO_DEV float f_min(float a, float b) { return a < b ? a : b; }

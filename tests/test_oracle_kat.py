@@ -202,13 +202,14 @@ def test_estimator_properties(small_tree_sh9):
 
 
 def test_filter_fp32_exp_accuracy():
-    """orc_fexp (the filter's fp32-only, fma-based exp): <= 1 ulp, exact at 0, flushes below FLT_MIN"""
+    """orc_fexp (the filter's fp32-only, fma-based exp): <= 1 ulp, exact at 0, zero from -87.68 down"""
     L = orc.lib()
     rs = np.random.RandomState(3)
     xs = np.concatenate([rs.uniform(-87.3, 0, 60000), rs.uniform(0, 88.7, 10000), rs.uniform(-1, 1, 10000)]).astype(np.float32)
     got = np.array([L.orc_fexp(float(x)) for x in xs], np.float32)
     assert _ulp_err(got, np.exp(xs.astype(np.float64))).max() <= 1.0
-    assert L.orc_fexp(0.0) == 1.0 and L.orc_fexp(-87.4) == 0.0 and L.orc_fexp(-3.0e38) == 0.0
+    assert L.orc_fexp(0.0) == 1.0 and L.orc_fexp(-87.7) == 0.0 and L.orc_fexp(-3.0e38) == 0.0
+    assert 0.0 < L.orc_fexp(-87.5) < 1.2e-38  # subnormal just below FLT_MIN, then exactly 0
     assert L.orc_fexp(88.8) == np.inf
 
 

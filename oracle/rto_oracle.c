@@ -175,7 +175,7 @@ float orc_det_expf(float x) {
 /*
  * Deterministic fp32-only expf for the filter's softmax taps (164 per pixel at L = 4): the same
  * structure in float arithmetic, every multiply-add an explicit fmaf -- k = rint(x log2 e) by the
- * 1.5*2^23 trick, two-term Cody-Waite reduction, degree-7 Taylor (Horner), exponent-bit scaling.
+ * 1.5*2^23 trick, two-term Cody-Waite reduction, degree-6 minimax polynomial (Horner), exponent-bit scaling.
  * Max error 0.9 ulp on [-87.3, 88.7] (measured in tests/test_oracle_kat.py); below that the result is
  * a (coarser) subnormal, and exactly 0 from x = -87.68 down (the argument is clamped at -88, where k = -127
  * and the scale 2^k is written as +0).  The reference's __expf (filtering.cu:195) is ex2.approx(x*log2e), ~2 ulp plus the
@@ -189,11 +189,10 @@ float orc_fexp(float x) {
     const float kf = fmaf(x, 1.44269502162933349609375f, 12582912.0f) - 12582912.0f;
     float r = fmaf(kf, -0.693145751953125f, x);
     r = fmaf(kf, -1.42860676533018704e-06f, r);
-    float p = 1.0f / 5040.0f;
-    p = fmaf(p, r, 1.0f / 720.0f);
-    p = fmaf(p, r, 1.0f / 120.0f);
-    p = fmaf(p, r, 1.0f / 24.0f);
-    p = fmaf(p, r, 1.0f / 6.0f);
+    float p = 0x1.6c6bdap-10f;      /* degree-6 minimax fit of exp on [-ln2/2, ln2/2] (tools/fit_fexp.py) */
+    p = fmaf(p, r, 0x1.1225e0p-7f);
+    p = fmaf(p, r, 0x1.5555a4p-5f);
+    p = fmaf(p, r, 0x1.5554aep-3f);
     p = fmaf(p, r, 0.5f);
     p = fmaf(p, r, 1.0f);
     p = fmaf(p, r, 1.0f);

@@ -143,11 +143,10 @@ RTO_DEV float fexp_f32(float x) {
     const float kf = __builtin_fmaf(x, 1.44269502162933349609375f, 12582912.0f) - 12582912.0f;
     float r = __builtin_fmaf(kf, -0.693145751953125f, x);
     r = __builtin_fmaf(kf, -1.42860676533018704e-06f, r);
-    float p = 1.0f / 5040.0f;
-    p = __builtin_fmaf(p, r, 1.0f / 720.0f);
-    p = __builtin_fmaf(p, r, 1.0f / 120.0f);
-    p = __builtin_fmaf(p, r, 1.0f / 24.0f);
-    p = __builtin_fmaf(p, r, 1.0f / 6.0f);
+    float p = 0x1.6c6bdap-10f;  // degree-6 minimax fit (tools/fit_fexp.py), <= 0.92 ulp overall
+    p = __builtin_fmaf(p, r, 0x1.1225e0p-7f);
+    p = __builtin_fmaf(p, r, 0x1.5555a4p-5f);
+    p = __builtin_fmaf(p, r, 0x1.5554aep-3f);
     p = __builtin_fmaf(p, r, 0.5f);
     p = __builtin_fmaf(p, r, 1.0f);
     p = __builtin_fmaf(p, r, 1.0f);
@@ -169,11 +168,10 @@ RTO_DEV float fexp_f32_le88(float x) {
     const float kf = t - 12582912.0f;
     float r = __builtin_fmaf(kf, -0.693145751953125f, x);
     r = __builtin_fmaf(kf, -1.42860676533018704e-06f, r);
-    float p = 1.0f / 5040.0f;
-    p = __builtin_fmaf(p, r, 1.0f / 720.0f);
-    p = __builtin_fmaf(p, r, 1.0f / 120.0f);
-    p = __builtin_fmaf(p, r, 1.0f / 24.0f);
-    p = __builtin_fmaf(p, r, 1.0f / 6.0f);
+    float p = 0x1.6c6bdap-10f;  // degree-6 minimax fit (tools/fit_fexp.py), <= 0.92 ulp overall
+    p = __builtin_fmaf(p, r, 0x1.1225e0p-7f);
+    p = __builtin_fmaf(p, r, 0x1.5555a4p-5f);
+    p = __builtin_fmaf(p, r, 0x1.5554aep-3f);
     p = __builtin_fmaf(p, r, 0.5f);
     p = __builtin_fmaf(p, r, 1.0f);
     p = __builtin_fmaf(p, r, 1.0f);
@@ -193,11 +191,10 @@ RTO_DEV float2v fexp_f32_le88_x2(float2v x) {
     const float2v kf = t - 12582912.0f;
     float2v r = __builtin_elementwise_fma(kf, splat2(-0.693145751953125f), x);
     r = __builtin_elementwise_fma(kf, splat2(-1.42860676533018704e-06f), r);
-    float2v p = splat2(1.0f / 5040.0f);
-    p = __builtin_elementwise_fma(p, r, splat2(1.0f / 720.0f));
-    p = __builtin_elementwise_fma(p, r, splat2(1.0f / 120.0f));
-    p = __builtin_elementwise_fma(p, r, splat2(1.0f / 24.0f));
-    p = __builtin_elementwise_fma(p, r, splat2(1.0f / 6.0f));
+    float2v p = splat2(0x1.6c6bdap-10f);
+    p = __builtin_elementwise_fma(p, r, splat2(0x1.1225e0p-7f));
+    p = __builtin_elementwise_fma(p, r, splat2(0x1.5555a4p-5f));
+    p = __builtin_elementwise_fma(p, r, splat2(0x1.5554aep-3f));
     p = __builtin_elementwise_fma(p, r, splat2(0.5f));
     p = __builtin_elementwise_fma(p, r, splat2(1.0f));
     p = __builtin_elementwise_fma(p, r, splat2(1.0f));

@@ -235,7 +235,10 @@ def main():
     achieved = alg_bytes_launch / (kt["traverse_ms"] * 1e-3) / 1e9 if kt["traverse_ms"] > 0 else 0.0
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
+    # the committed counter passes were taken on the default workload only
+    default_workload = (not args.tree and W == 800 and H == 800 and args.spp == 6 and args.basis == 16 and args.depth == 10
+                        and args.shell == 2.5)
+    if os.path.exists(pmc) and default_workload:
         try:
             pj = json.load(open(pmc))  # measured at pj["frames_per_launch"] frames per launch: per-frame bytes scale
             traffic = pj.get("hbm_bytes_per_launch") * frames_per_launch / float(pj.get("frames_per_launch", frames_per_launch))

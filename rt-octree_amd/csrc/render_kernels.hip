@@ -8,13 +8,17 @@
 //   maybe_precalc_basis     renderer/include/volrend/internal/lumisphere.hpp:38-80 (SH)
 //   sample_dst<SPP>         rt_core.cuh:67-193
 //
-// Two kernels with bit-identical results (tests/test_render_parity.py):
+// Three traversal kernels with bit-identical results (tests/test_render_parity.py):
 //   render_generic<SPP>  any N, root-restart float descent -- the plain statement of the algorithm.
-//   render_fast<SPP>     N == 2: integer descent over a 4-byte-per-slot traversal image (child
-//                        offset or leaf sigma in one word), restart from the deepest ancestor
-//                        shared with the previous step (per-lane ancestor stack in LDS),
-//                        8x8-pixel wave tiles in an XCD-interleaved strip order, register-resident
-//                        thresholds/hit lists with static indexing only, table-driven RNG jump.
+//   render_fast<SPP>     N == 2, one frame per launch (the latency path): integer descent over a
+//                        4-byte-per-slot traversal image (child offset or leaf sigma in one word),
+//                        restart from the deepest ancestor shared with the previous step (per-lane
+//                        ancestor stack in LDS), 8x8-pixel wave tiles in an XCD-interleaved strip
+//                        order, register-resident thresholds/hit lists with static indexing only,
+//                        table-driven RNG jump.
+//   render_persist<SPP>  N == 2, up to 32 frames per launch (the throughput path): persistent waves,
+//                        ray compaction, one ray queue per XCD; sample_kernel before it (thresholds)
+//                        and shade_kernel after it (SH colour + pixel epilogue).
 //
 // Why the descent can be done on integers (SURVEY.md section 7 "hard parts"): after the clamp to
 // [0, 1-1e-6] every operation of the reference descent (x*=2; floor; x-=floor) is exact in fp32,
@@ -421,28 +425,10 @@ RTO_DEV void shade_leaf_packed(const TreeDev& tree, uint32_t slot, const float* 
     out[3] += cnt;
 }
 
-// 8-way select of a cached node's words by child index (static register indices only)
-RTO_DEV uint32_t select8(const uint32_t* cw, uint32_t ci) {
-    const uint32_t a = (ci & 1u) ? cw[1] : cw[0];
-    const uint32_t b = (ci & 1u) ? cw[3] : cw[2];
-    const uint32_t c = (ci & 1u) ? cw[5] : cw[4];
-    const uint32_t d = (ci & 1u) ? cw[7] : cw[6];
-    const uint32_t ab = (ci & 2u) ? b : a;
-    const uint32_t cd = (ci & 2u) ? d : c;
-    return (ci & 4u) ? cd : ab;
-}
-
-// Tuning variants of render_fast (bit flags, results identical):
-//   kVarNodeCache  keep the 8 words of the most recently visited node in registers (two dwordx4
-//                  loads per node): a step that lands in a sibling slot needs no memory access
-//   kVarPrio       raise the wave's issue priority as its march gets long (the frame ends with its
-//                  longest ray; short rays are many and latency-tolerant)
-constexpr int kVarNodeCache = 1, kVarPrio = 2;
-
 // STATS: also count the units of SURVEY 8(d)'s algorithmic-byte formula (march steps, descent
 // levels a root-restart walk would visit, distinct hit leaves, ...) into fo.stats.  Separate
 // instantiation; the timed kernel carries none of it.
-template <int SPP, bool STATS, int VAR>
+template <int SPP, bool STATS>
 __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const CamDev cam, const OptDev opt,
                                                     const Pcg32 rng_base, const PcgJumpEntry* __restrict__ jump,
                                                     const TileMap tm, const FrameOut fo) {
@@ -493,17 +479,8 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
         uint32_t pix = 0, piy = 0, piz = 0;
         int prev_lvl = 0;
         uint32_t* stack = s_stack + tid;
-        uint32_t cn = 0xffffffffu;  // cached node (kVarNodeCache)
-        uint32_t cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int iter = 0;  // wave-uniform loop count (kVarPrio)
 
         while (t < tmax) {
-            if (VAR & kVarPrio) {
-                ++iter;
-                if (iter == 40) __builtin_amdgcn_s_setprio(1);
-                if (iter == 80) __builtin_amdgcn_s_setprio(2);
-                if (iter == 140) __builtin_amdgcn_s_setprio(3);
-            }
             float pos[3] = {cen[0] + t * dir[0], cen[1] + t * dir[1], cen[2] + t * dir[2]};
             pos[0] = f_max(f_min(pos[0], 1.f - 1e-6f), 0.f);
             pos[1] = f_max(f_min(pos[1], 1.f - 1e-6f), 0.f);
@@ -521,18 +498,7 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
                 const int sh = 23 - lvl;
                 const uint32_t ci = (((ix >> sh) & 1u) << 2) | (((iy >> sh) & 1u) << 1) | ((iz >> sh) & 1u);
                 slot = node * 8u + ci;
-                if (VAR & kVarNodeCache) {
-                    if (node != cn) {
-                        const uint4* __restrict__ np = reinterpret_cast<const uint4*>(tree.nodew + (size_t)node * 8u);
-                        const uint4 lo = np[0], hi = np[1];
-                        cw[0] = lo.x; cw[1] = lo.y; cw[2] = lo.z; cw[3] = lo.w;
-                        cw[4] = hi.x; cw[5] = hi.y; cw[6] = hi.z; cw[7] = hi.w;
-                        cn = node;
-                    }
-                    w = select8(cw, ci);
-                } else {
-                    w = tree.nodew[slot];
-                }
+                w = tree.nodew[slot];
                 if (nodew_is_leaf(w)) break;
                 node += w;  // two's complement add of the relative offset
                 ++lvl;
@@ -580,7 +546,6 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
             }
             t += delta_t;
         }
-        if (VAR & kVarPrio) __builtin_amdgcn_s_setprio(0);
 
         if (STATS) st_hits = sh_nums;
         if (sh_nums != 0) {
@@ -625,12 +590,13 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
 // (independent poses of the same tree): a frame is only ~10 k waves of very uneven length, so a
 // one-frame launch spends most of its time waiting for its longest rays on a nearly empty chip
 // (profiles/r1_a_*: mean residency 1.7 k of 8 k wave slots).  Here a fixed grid of persistent
-// waves pulls rays from one queue that spans every frame of the batch:
+// waves pulls rays from queues that span every frame of the batch:
 //   * ray compaction: a lane whose ray ended (all SPP thresholds crossed, left the box, missed)
-//     idles only until the wave has kRefillMin such lanes; then the finished lanes shade + store
-//     together and a ballot / mbcnt prefix sum hands each idle lane the next ray of the queue
-//     (one atomicAdd per wave);
-//   * rays are queued in 8x8-pixel tile order, so a wave's 64 rays stay spatially coherent;
+//     idles only until the wave has REFILL such lanes; then the finished lanes terminate their hit
+//     lists and a ballot / mbcnt prefix sum hands each idle lane the next ray of the wave's
+//     reservoir (one atomicAdd per 64-256 rays);
+//   * rays are queued in 8x8-pixel tile order, so a wave's 64 rays stay spatially coherent; one
+//     queue per XCD over an image wedge each, tile-major across the frames (FrameBatch::qstart);
 //   * the end-of-queue drain happens once per batch instead of once per frame.
 // Per-ray arithmetic is exactly render_fast's; results are bit-identical.
 
@@ -1302,21 +1268,15 @@ TileMap make_tile_map(int width, int height, int strip_rows) {
 
 template <int SPP>
 static hipError_t launch_spp(int kernel, const TreeDev& tree, const CamDev& cam, const OptDev& opt,
-                             const Pcg32& rng, const PcgJumpEntry* jump, const FrameOut& fo, int strip_rows,
-                             int variant, hipStream_t stream) {
+                             const Pcg32& rng, const PcgJumpEntry* jump, const FrameOut& fo, int strip_rows, hipStream_t stream) {
     if (kernel == 2) {
         const TileMap tm = make_tile_map(cam.width, cam.height, strip_rows);
         const size_t lds = (size_t)(tree.max_depth + 1) * 256 * sizeof(uint32_t);
         const dim3 grid(8 * tm.per_xcd), block(256);
-#define RTO_LAUNCH_FAST(ST, V) \
-    hipLaunchKernelGGL((render_fast<SPP, ST, V>), grid, block, lds, stream, tree, cam, opt, rng, jump, tm, fo)
-        if (fo.stats) {
-            RTO_LAUNCH_FAST(true, 0);
-        } else {
-            (void)variant;  // the node-cache / priority-ramp instantiations measured slower and are not built
-            RTO_LAUNCH_FAST(false, 0);
-        }
-#undef RTO_LAUNCH_FAST
+        if (fo.stats)
+            hipLaunchKernelGGL((render_fast<SPP, true>), grid, block, lds, stream, tree, cam, opt, rng, jump, tm, fo);
+        else
+            hipLaunchKernelGGL((render_fast<SPP, false>), grid, block, lds, stream, tree, cam, opt, rng, jump, tm, fo);
     } else {
         const int64_t size = (int64_t)cam.width * cam.height;
         hipLaunchKernelGGL(render_generic<SPP>, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, stream, tree, cam,
@@ -1327,16 +1287,16 @@ static hipError_t launch_spp(int kernel, const TreeDev& tree, const CamDev& cam,
 
 hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev& cam, const OptDev& opt,
                          const Pcg32& rng, const PcgJumpEntry* jump, const FrameOut& fo, int strip_rows,
-                         int variant, hipStream_t stream) {
+                         hipStream_t stream) {
     switch (spp) {  // volrend.cu:266-278
-        case 1: return launch_spp<1>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, variant, stream);
-        case 2: return launch_spp<2>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, variant, stream);
-        case 3: return launch_spp<3>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, variant, stream);
-        case 4: return launch_spp<4>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, variant, stream);
-        case 6: return launch_spp<6>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, variant, stream);
-        case 8: return launch_spp<8>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, variant, stream);
-        case 16: return launch_spp<16>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, variant, stream);
-        case 32: return launch_spp<32>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, variant, stream);
+        case 1: return launch_spp<1>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
+        case 2: return launch_spp<2>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
+        case 3: return launch_spp<3>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
+        case 4: return launch_spp<4>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
+        case 6: return launch_spp<6>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
+        case 8: return launch_spp<8>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
+        case 16: return launch_spp<16>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
+        case 32: return launch_spp<32>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -102,7 +102,6 @@ struct rto_ctx {
     bool jump_valid = false;
     int kernel = RTO_KERNEL_AUTO;
     int strip_rows = 1;
-    int variant = 0;
     int refill = 0;  // 0 = the default instantiation (flat traversal, refill at 16 idle lanes)
     bool tile_order_on = true;
     bool stats_on = false;
@@ -708,9 +707,7 @@ extern "C" int rto_debug_zero_queue(rto_ctx* c) { return hipMemset(c->queue + 2,
 int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value) {
     if (!c || !key) return set_err(RTO_E_INVALID, "rto_ctx_set_tuning: null argument");
     const std::string k(key);
-    if (k == "variant") {
-        c->variant = value;
-    } else if (k == "tile_order") {
+    if (k == "tile_order") {
         c->tile_order_on = value != 0;
     } else if (k == "xcd_queues") {
         c->xcd_queues = value != 0;
@@ -848,7 +845,7 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
         fo.stats = ctx->stats;
     }
 
-    hipError_t e = rto::launch_render(kernel, o->spp, tree->dev, cd, od, ctx->rng, ctx->jump, fo, ctx->strip_rows, ctx->variant, stream);
+    hipError_t e = rto::launch_render(kernel, o->spp, tree->dev, cd, od, ctx->rng, ctx->jump, fo, ctx->strip_rows, stream);
     if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("render launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
 }

@@ -18,8 +18,7 @@ TileMap make_tile_map(int width, int height, int strip_rows);
 
 // kernel: 1 = generic, 2 = fast.  spp must be one of {1,2,3,4,6,8,16,32} (hipErrorInvalidValue otherwise)
 hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev& cam, const OptDev& opt,
-                         const Pcg32& rng, const PcgJumpEntry* jump, const FrameOut& fo, int strip_rows,
-                         int variant, hipStream_t stream);
+                         const Pcg32& rng, const PcgJumpEntry* jump, const FrameOut& fo, int strip_rows, hipStream_t stream);
 
 // persistent batched renderer (N == 2 trees): fb.n frames in one launch (traversal kernel, then the
 // shading kernel); `queue` = 2 zeroed u64; ev = nullptr or 3 events recorded before / between / after

@@ -21,7 +21,6 @@ def main():
     ap.add_argument("--spp", type=int, nargs="+", default=[6, 1])
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--kernels", type=int, nargs="+", default=[2, 1])
-    ap.add_argument("--variants", type=int, nargs="+", default=[0])
     ap.add_argument("--strips", type=int, nargs="+", default=[1])
     ap.add_argument("--rounds", type=int, default=1)
     ap.add_argument("--tree", default="")
@@ -44,10 +43,9 @@ def main():
         for spp in args.spp:
             opt = R.RenderOptions(spp=spp, denoise=False)
             for k in args.kernels:
-                for var in (args.variants if k == 2 else [0]):
+                for var in [0]:
                     for strip in (args.strips if k == 2 else [1]):
                         ctx.set_kernel(k)
-                        ctx.set_tuning("variant", var)
                         ctx.set_tuning("strip_rows", strip)
                         ctx.rng_seed()
                         cam.set_c2w(poses[0])

@@ -243,3 +243,32 @@ def test_batched_kernel_full_size_matches_fast(small_tree_sh9):
     for f in range(3):
         aux_f, _, _ = hip_frame(dt, cams[f], 6, frame=f, kernel=R.KERNEL_FAST)
         assert_bits_equal(got[f], aux_f, "frame %d" % f)
+
+
+def test_queue_tuning_never_changes_results(small_tree_sh16):
+    """rto_ctx_set_tuning: single queue / one queue per XCD, frame- / tile-major order, row-major /
+    centre-out / wedge tile tables of any block size, refill thresholds -- which wave renders which ray
+    when is free, the pixels are not."""
+    ht, dt = make_pair(small_tree_sh16)
+    W, H = 132, 76  # ragged vs the 8x8 ray tiles and vs the 4x4-tile blocks
+    cams, want = [], []
+    for f in range(3):
+        ocam, cam = cameras(W, H, POSES[f])
+        cams.append(cam)
+        want.append(oracle_frame(ht, ocam, 6, frame=f)[0])
+    ctx = R.RenderContext(W, H, frames=3)
+    settings = [{"xcd_queues": 0, "tile_order": 0}, {"xcd_queues": 0, "tile_order": 1, "tile_major": 0},
+                {"xcd_queues": 1, "tile_major": 1, "tile_block": 1}, {"tile_block": 3}, {"tile_block": 64},
+                {"tile_block": 4, "refill": 208}, {"refill": 232}, {"refill": 16}]
+    for kv in settings:
+        for k, v in kv.items():
+            ctx.set_tuning(k, v)
+        ctx.rng_seed()
+        R.launch_renderer_batch(dt, cams, R.RenderOptions(spp=6, denoise=False), ctx)
+        for f in range(3):
+            ctx.select_frame(f)
+            assert_bits_equal(ctx.download_aux(), want[f], "%s frame %d" % (kv, f))
+    with pytest.raises(R.RtoError):
+        ctx.set_tuning("tile_block", 0)
+    with pytest.raises(R.RtoError):
+        ctx.set_tuning("no_such_knob", 1)

@@ -164,7 +164,7 @@ void rto_ctx_rng_get(const rto_ctx* c, uint64_t* state, uint64_t* inc);
 /* choose the traversal kernel (RTO_KERNEL_*); default AUTO */
 int rto_ctx_set_kernel(rto_ctx* c, int kernel);
 /* Performance knobs; never change results.  key: "strip_rows" (single-frame kernel: tile rows per XCD
- * strip, >= 1); batched kernel: "refill" (idle lanes that trigger a refill), "tile_order"
+ * strip, >= 1); batched kernel: "refill" (0 = default; 100 * waves/SIMD + idle-lane threshold selects one of the A/B instantiations), "tile_order"
  * (0 = row-major tiles, 1 = centre-out), "xcd_queues" (1 = one ray queue per XCD over an image wedge
  * each, with stealing; 0 = a single queue). */
 int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value);

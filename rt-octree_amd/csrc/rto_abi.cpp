@@ -102,7 +102,7 @@ struct rto_ctx {
     bool jump_valid = false;
     int kernel = RTO_KERNEL_AUTO;
     int strip_rows = 1;
-    int refill = 0;  // 0 = the default instantiation (flat traversal, refill at 16 idle lanes)
+    int refill = 0;  // 0 = the default instantiation; 100 * waves/SIMD + idle-lane threshold picks an A/B one
     bool tile_order_on = true;
     bool stats_on = false;
     unsigned long long* stats = nullptr;  // device, 6 counters

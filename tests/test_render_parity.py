@@ -259,7 +259,7 @@ def test_queue_tuning_never_changes_results(small_tree_sh16):
     ctx = R.RenderContext(W, H, frames=3)
     settings = [{"xcd_queues": 0, "tile_order": 0}, {"xcd_queues": 0, "tile_order": 1, "tile_major": 0},
                 {"xcd_queues": 1, "tile_major": 1, "tile_block": 1}, {"tile_block": 3}, {"tile_block": 64},
-                {"tile_block": 4, "refill": 208}, {"refill": 232}, {"refill": 16}]
+                {"tile_block": 4, "refill": 808}, {"refill": 816}, {"refill": 432}, {"refill": 0}]
     for kv in settings:
         for k, v in kv.items():
             ctx.set_tuning(k, v)

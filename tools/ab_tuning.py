@@ -25,7 +25,8 @@ def main():
         c.set_c2w(p)
         cams.append(c)
     opt = R.RenderOptions(spp=6, denoise=False)
-    ctx = R.RenderContext(W, H, frames=16)
+    B = 32
+    ctx = R.RenderContext(W, H, frames=B)
     stream = torch.cuda.current_stream()
     ref = None
     for rnd in range(3):
@@ -35,12 +36,12 @@ def main():
                 ctx.set_tuning(k, int(v))
             ctx.kernel_timing(True)
             for rep in range(2):
-                for i in range(0, len(cams), 16):
+                for i in range(0, len(cams), B):
                     ctx.rng_seed()
-                    R.launch_renderer_batch(dt, cams[i:i + 16], opt, ctx, stream, rng_jumps=[100 + i + k for k in range(16)])
+                    R.launch_renderer_batch(dt, cams[i:i + B], opt, ctx, stream, rng_jumps=[100 + i + k for k in range(B)])
                 torch.cuda.synchronize()
                 kt = ctx.kernel_timing_read()
-            ctx.select_frame(15)
+            ctx.select_frame(B - 1)
             aux = ctx.download_aux()
             if ref is None:
                 ref = aux

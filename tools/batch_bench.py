@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--frames", type=int, default=48)
     ap.add_argument("--batches", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--rounds", type=int, default=2)
-    ap.add_argument("--refills", type=int, nargs="+", default=[24])
+    ap.add_argument("--refills", type=int, nargs="+", default=[0])
     ap.add_argument("--tree", default="")
     args = ap.parse_args()
     import torch

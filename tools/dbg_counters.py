@@ -12,7 +12,7 @@ cams = []
 for p in synth.orbit_poses(200)[:8]:
     c = R.Camera(W, H, fx, fx); c.set_c2w(p); cams.append(c)
 ctx = R.RenderContext(W, H, frames=8)
-for rf in (16,):
+for rf in (0,):
     ctx.set_tuning("refill", rf)
     R.launch_renderer_batch(dt, cams, R.RenderOptions(spp=6, denoise=False), ctx, rng_jumps=list(range(100, 108)))
     torch.cuda.synchronize()

@@ -201,11 +201,22 @@ def make_tree(depth_limit=6, basis_dim=9, seed=20230418, shell=1.25, radius=1.5,
         idx = occ_idx[s:s + CH]
         c = centers[idx]
         m = idx.size
-        coef = rng.standard_normal((m, 3, B), dtype=np.float32) * amp[None, None, :]
+        # Appearance: smooth fields of position (what a trained PlenOctree looks like at the scale of
+        # a pixel) plus a little per-leaf noise -- a denoiser can only trade variance for resolution
+        # where neighbouring pixels see related colours.  The random draws keep their order and sizes,
+        # so sigma below (everything the traversal reads) does not depend on these choices.
+        noise = rng.standard_normal((m, 3, B), dtype=np.float32)
+        kk = np.arange(B, dtype=np.float32)
+        coef = np.empty((m, 3, B), np.float32)
+        for ch in range(3):
+            fxk, fyk, fzk = 3.0 + 1.7 * ((kk + ch) % 4), 2.5 + 1.3 * ((2 * kk + ch) % 5), 3.5 + 1.1 * ((3 * kk + 2 * ch) % 3)
+            field = np.sin(c[:, 0:1] * fxk[None] + 0.9 * kk[None] + ch) * np.cos(c[:, 1:2] * fyk[None] - 0.4 * kk[None]) \
+                + 0.5 * np.sin(c[:, 2:3] * fzk[None] + 1.7 * ch)
+            coef[:, ch, :] = (field + 0.1 * noise[:, ch, :]) * amp[None, :]
         # smooth DC colour field + a little per-leaf noise (pre-sigmoid, DC basis = 0.282)
         for ch, (fx, fy, fz, ph) in enumerate(((9.0, 5.0, 7.0, 0.0), (6.0, 11.0, 4.0, 1.3), (5.0, 8.0, 10.0, 2.1))):
             dc = 2.2 * np.sin(fx * c[:, 0] + ph) * np.cos(fy * c[:, 1] - ph) + 1.5 * np.sin(fz * c[:, 2] + 2 * ph)
-            coef[:, ch, 0] = (dc + 0.3 * rng.standard_normal(m, dtype=np.float32)) / 0.28209479
+            coef[:, ch, 0] = (dc + 0.03 * rng.standard_normal(m, dtype=np.float32)) / 0.28209479
         sigma = np.exp(rng.uniform(np.log(5.0), np.log(300.0), m)).astype(np.float32)
         rec = np.concatenate([coef.reshape(m, 3 * B), sigma[:, None]], 1)
         data[idx] = rec.astype(np.float16)

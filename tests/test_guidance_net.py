@@ -58,3 +58,24 @@ def test_denoiser_requires_module():
     with pytest.raises(RuntimeError) as e:
         denoiser.Denoiser("")
     assert "No torchscript module is given to denoiser." in str(e.value)
+
+
+def test_committed_trained_weights_load_into_the_reference_layout():
+    """rt-octree_amd/weights/guidance_synth_lego.pt (tools/train_guidance.py): a state_dict with the
+    reference module's parameter names for GuidanceNet(8, 32, 5, 2, 4); folds into the compact net."""
+    import os
+    import torch
+    from rt_octree_amd import denoiser
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rt-octree_amd", "weights",
+                        "guidance_synth_lego.pt")
+    sd = torch.load(path, map_location="cpu")
+    full = denoiser.GuidanceNet(8, 32, 5, 2, 4)
+    full.load_state_dict(sd)  # strict
+    assert all(torch.isfinite(v).all() for v in sd.values())
+    assert "layers.0.conv3.4.weight" in sd and "layers.1.conv1.0.bias" in sd
+    compact = denoiser.GuidanceNetCompact.from_full(full).eval()
+    aux = torch.rand(1, 8, 24, 32)
+    with torch.no_grad():
+        w0, g0 = full.eval()(aux)
+        w1, g1 = compact(aux)
+    assert torch.allclose(w0, w1, atol=1e-4) and torch.allclose(g0, g1, atol=1e-3)

@@ -393,11 +393,15 @@ RTO_DEV void shade_leaf_packed(const TreeDev& tree, uint32_t slot, const float* 
     uint32_t dw[NDW];
 #pragma unroll
     for (int i = 0; i < NDW; ++i) dw[i] = p[i];
-    // half k of the record is packed half (k + odd)
+    // bring half k of the record to packed position k: a funnel shift by 0 or 16 bits per dword
+    // (v_alignbit_b32) instead of extracting every coefficient at both alignments and selecting
+    constexpr int NAL = (DD + 1) / 2;
+    const uint32_t sh = odd * 16u;
+    uint32_t al[NAL];
+#pragma unroll
+    for (int i = 0; i < NAL; ++i) al[i] = __builtin_amdgcn_alignbit(i + 1 < NDW ? dw[i + 1] : 0u, dw[i], sh);
     auto coef = [&](int k) -> float {
-        const uint32_t a = (k & 1) ? (dw[k >> 1] >> 16) : (dw[k >> 1] & 0xffffu);
-        const uint32_t b = ((k + 1) & 1) ? (dw[(k + 1) >> 1] >> 16) : (dw[(k + 1) >> 1] & 0xffffu);
-        return half_bits_to_float((uint16_t)(odd ? b : a));
+        return half_bits_to_float((uint16_t)((k & 1) ? (al[k >> 1] >> 16) : (al[k >> 1] & 0xffffu)));
     };
 #pragma unroll
     for (int c = 0; c < 3; ++c) {

@@ -8,6 +8,9 @@
                         trees written by numpy in the svox key schema, and what the reference's
                         vendored cnpy reads from them (oracle/_ref/cnpy_dump)
   frames_golden.npz     tiny frames from the CPU oracle (det math): tree arrays, poses, aux, rgba8
+  kat_golden.npz        regression vectors from the CPU oracle: octree point
+                        queries incl. faces / corners / the clamp edge, SH basis bit patterns for
+                        SH4/9/16/25, the L = 4 filter on a 48x40 image with its saved tensors and gradients
 
 The reference module `denoiser/network.py` tries to JIT-compile its CUDA extension when
 `_denoiser` is not importable (network.py:7-47).  An EMPTY placeholder module is registered under
@@ -104,8 +107,64 @@ def frames_golden():
     print("frames_golden.npz: %d arrays" % len(out))
 
 
+def kat_golden():
+    import ctypes as C
+    import orc
+    from rt_octree_amd import synth
+    out = {}
+    # G3: query_single_from_root on a depth-6 tree
+    tree = synth.make_tree(depth_limit=6, basis_dim=4, seed=77)
+    ht = orc.HostTree(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+    rs = np.random.RandomState(5)
+    pts = rs.rand(1000, 3).astype(np.float32)
+    edge = np.array([0.0, 1.0, 0.5, 0.25, 1.0 - 1e-6, 1.0 - 1e-7, -0.1, 1.3, 0.5 - 2.0 ** -20, 0.5 + 2.0 ** -20], np.float32)
+    grid = np.stack(np.meshgrid(edge[:6], edge[2:8], edge[4:], indexing="ij"), -1).reshape(-1, 3)[:300]
+    pts = np.concatenate([pts, grid.astype(np.float32)], 0)
+    leaf, cube, local, lev = [], [], [], []
+    for p3 in pts:
+        xyz = (C.c_float * 3)(*[float(v) for v in p3])
+        cs, lv = C.c_float(0), C.c_int(0)
+        leaf.append(orc.lib().orc_query(C.byref(ht.c), xyz, C.byref(cs), C.byref(lv)))
+        cube.append(cs.value)
+        local.append(list(xyz))
+        lev.append(lv.value)
+    out["q.child"], out["q.data"], out["q.scale"], out["q.offset"] = tree.child, tree.data, tree.scale, tree.offset
+    out["q.points"] = pts
+    out["q.leaf"], out["q.cube_sz"] = np.array(leaf, np.int64), np.array(cube, np.float32)
+    out["q.local"], out["q.levels"] = np.array(local, np.float32), np.array(lev, np.int32)
+    # G4: maybe_precalc_basis bit patterns
+    dirs = rs.randn(256, 3).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True).astype(np.float32)
+    dirs[:6] = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1]], np.float32)
+    out["sh.dirs"] = dirs
+    for bd in (4, 9, 16, 25):
+        vals = np.zeros((256, bd), np.float32)
+        for i, d in enumerate(dirs):
+            buf = (C.c_float * 25)()
+            orc.lib().orc_sh_basis(bd, (C.c_float * 3)(*[float(v) for v in d]), buf)
+            vals[i] = np.array(buf[:bd], np.float32)
+        out["sh.basis%d" % bd] = vals
+    # G9: the filter, L = 4, 48x40, with the training-side tensors
+    L, H, W = 4, 40, 48
+    weight = rs.rand(L, H, W).astype(np.float32)
+    weight /= weight.sum(0, keepdims=True)
+    guidance = (rs.rand(L, H, W) * 6).astype(np.float32)
+    noisy = rs.rand(H, W, 4).astype(np.float32)
+    noisy[..., 3] = 1
+    grad_out = rs.randn(H, W, 4).astype(np.float32)
+    img, rf, mx, inv = orc.filter_train_forward(weight, guidance, noisy)
+    gw, gg = orc.filter_backward(grad_out, noisy, weight, guidance, rf, mx, inv)
+    for k, v in (("weight", weight), ("guidance", guidance), ("noisy", noisy), ("grad_out", grad_out), ("out", img),
+                 ("rgb_filtered", rf), ("max_map", mx), ("inv_kernel_sum", inv), ("grad_weight", gw), ("grad_guidance", gg)):
+        out["f." + k] = v
+    np.savez_compressed(os.path.join(HERE, "kat_golden.npz"), **out)
+    print("kat_golden.npz: %d arrays" % len(out))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["guidance", "npz", "frames"]
+    which = sys.argv[1:] or ["guidance", "npz", "frames", "kat"]
+    if "kat" in which:
+        kat_golden()
     if "guidance" in which:
         guidance_golden()
     if "npz" in which:

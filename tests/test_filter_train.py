@@ -161,3 +161,29 @@ def test_guidance_net_trains_through_the_filter():
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.gpu
+def test_hip_filter_matches_committed_golden():
+    """tests/golden/kat_golden.npz f.*: the committed L = 4, 48x40 filter vectors (output, saved tensors,
+    gradients) through the HIP kernels, bit for bit -- no oracle involved at test time."""
+    import os
+    from rt_octree_amd._lib import check, lib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_golden.npz"))
+    L, H, W = g["f.guidance"].shape
+    w, gd, x, go = _dev(g["f.weight"][None]), _dev(g["f.guidance"][None]), _dev(g["f.noisy"][None]), _dev(g["f.grad_out"][None])
+    out = torch.empty_like(x)
+    rf = torch.empty((1, L, H, W, 4), device="cuda:0")
+    mx, inv = torch.empty((1, L, H, W), device="cuda:0"), torch.empty((1, L, H, W), device="cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    check(lib().rto_filtering_train_forward(s, w.data_ptr(), gd.data_ptr(), L, H, W, 1, x.data_ptr(), out.data_ptr(),
+                                            rf.data_ptr(), mx.data_ptr(), inv.data_ptr()))
+    gw, gg = torch.empty_like(w), torch.empty_like(gd)
+    check(lib().rto_filtering_backward(s, go.data_ptr(), x.data_ptr(), w.data_ptr(), gd.data_ptr(), rf.data_ptr(),
+                                       mx.data_ptr(), inv.data_ptr(), L, H, W, 1, gw.data_ptr(), gg.data_ptr()))
+    out2 = torch.empty_like(x)
+    check(lib().rto_filtering_batch(s, w.data_ptr(), gd.data_ptr(), L, H, W, 1, x.data_ptr(), out2.data_ptr()))
+    torch.cuda.synchronize()
+    for name, got in (("out", out), ("out", out2), ("rgb_filtered", rf), ("max_map", mx), ("inv_kernel_sum", inv),
+                      ("grad_weight", gw), ("grad_guidance", gg)):
+        assert np.array_equal(got[0].cpu().numpy().view(np.uint32), g["f." + name].view(np.uint32)), name

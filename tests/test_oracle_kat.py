@@ -220,3 +220,29 @@ def test_unsupported_inputs():
     cam = orc.camera(8, 8, 10, 10, synth.orbit_poses(1)[0][:3, :4].T.reshape(-1))
     with pytest.raises(RuntimeError):
         orc.render_frame(ht, cam, orc.default_options(spp=5), orc.rng())
+
+
+def test_oracle_reproduces_committed_kat_vectors():
+    """tests/golden/kat_golden.npz: point queries, SH basis bit patterns, the
+    L = 4 filter with its saved tensors and gradients -- pins the oracle against silent drift."""
+    import ctypes as C
+    g = np.load(os.path.join(HERE, "golden", "kat_golden.npz"))
+    ht = orc.HostTree(g["q.child"], g["q.data"], g["q.scale"], g["q.offset"], "SH4")
+    for i, p3 in enumerate(g["q.points"]):
+        xyz = (C.c_float * 3)(*[float(v) for v in p3])
+        cs, lv = C.c_float(0), C.c_int(0)
+        leaf = orc.lib().orc_query(C.byref(ht.c), xyz, C.byref(cs), C.byref(lv))
+        assert leaf == g["q.leaf"][i] and lv.value == g["q.levels"][i]
+        assert np.float32(cs.value).view(np.uint32) == g["q.cube_sz"][i].view(np.uint32)
+        assert np.array_equal(np.array(list(xyz), np.float32).view(np.uint32), g["q.local"][i].view(np.uint32)), i
+    for bd in (4, 9, 16, 25):
+        want = g["sh.basis%d" % bd]
+        for i, d in enumerate(g["sh.dirs"]):
+            buf = (C.c_float * 25)()
+            orc.lib().orc_sh_basis(bd, (C.c_float * 3)(*[float(v) for v in d]), buf)
+            assert np.array_equal(np.array(buf[:bd], np.float32).view(np.uint32), want[i].view(np.uint32)), (bd, i)
+    out, rf, mx, inv = orc.filter_train_forward(g["f.weight"], g["f.guidance"], g["f.noisy"])
+    gw, gg = orc.filter_backward(g["f.grad_out"], g["f.noisy"], g["f.weight"], g["f.guidance"], rf, mx, inv)
+    for name, got in (("out", out), ("rgb_filtered", rf), ("max_map", mx), ("inv_kernel_sum", inv),
+                      ("grad_weight", gw), ("grad_guidance", gg)):
+        assert np.array_equal(got.view(np.uint32), g["f." + name].view(np.uint32)), name

@@ -693,7 +693,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                                                        unsigned long long* __restrict__ queue,
                                                        uint32_t* __restrict__ hits, const uint32_t chunk) {
     // queue[8 + 8k]: next ray of queue k; queue[1]: waves that have left (the last one re-arms all)
-    // LDS: [max_depth+1][256] ancestor stack | [SPP+1][256] sorted thresholds | frame table
+    // LDS: [max_depth+1-top_levels][256] ancestor stack | [SPP+1][256] sorted thresholds | frame table
     extern __shared__ uint32_t s_mem[];
     const int tid = threadIdx.x;
     uint32_t* stack = s_mem + tid;
@@ -711,16 +711,14 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
 
     const int W = fb.width, H = fb.height;
     const uint32_t SIZE = (uint32_t)W * (uint32_t)H;
-    const int tiles8_x = (W + 7) >> 3, tiles8_y = (H + 7) >> 3;
-    (void)tiles8_y;
+    const int tiles8_x = (W + 7) >> 3;
     // the queue this wave draws from first: the one of the XCD it runs on (HW_REG_XCC_ID bits 3:0)
     const uint32_t n_queues = (uint32_t)fb.n_queues;
     uint32_t cur_q = n_queues > 1 ? ((uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % n_queues) : 0u;
     uint32_t q_tried = 0;            // queues found empty so far (wave-uniform)
     uint32_t res_t0 = 0, res_tiles = 1;  // tile range of the queue the reservoir was drawn from
 
-    // Loop-invariant scalars pinned in SGPRs: under the 8-waves/SIMD register budget hipcc
-    // otherwise re-loads them from the kernarg segment inside the descent loop (an s_load +
+    // Loop-invariant scalars pinned in SGPRs: hipcc otherwise re-loads them from the kernarg segment inside the descent loop (an s_load +
     // lgkmcnt(0) round trip per level).
     typedef const __attribute__((address_space(1))) uint32_t* gptr_t;  // keep global_load (not flat_load)
     const uint32_t* nodew_p = tree.nodew;

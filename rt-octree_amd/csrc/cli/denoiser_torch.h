@@ -12,8 +12,13 @@ class TorchDenoiser {
 public:
     // throws std::runtime_error("No torchscript module is given to denoiser.") on an empty path and
     // "Error when loading torchscript model from <path>" when the file cannot be loaded
-    TorchDenoiser(const std::string& ts_module_path, int device);
+    // use_fused: when the module is the two-layer compact GuidanceNet that compact_and_compile exports
+    // (parameters layers.{0,1}.conv.{weight,bias}, 8 -> 32 -> 8 channels), run it as librto's fused
+    // MFMA kernel (rto_guidance_net_*, same fp16 weights) instead of libtorch's convolutions; any
+    // other module, or use_fused = false, takes the libtorch path.
+    TorchDenoiser(const std::string& ts_module_path, int device, bool use_fused = true);
     ~TorchDenoiser();
+    bool fused() const;
 
     // aux: device pointer to [n,8,H,W] fp32 (zero-copy from_blob).  On return *weight / *guidance point
     // at contiguous device tensors [n,L,H,W] that stay alive until the next call.

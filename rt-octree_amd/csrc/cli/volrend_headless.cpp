@@ -47,7 +47,7 @@ struct Args {
 const std::map<std::string, std::string> kShort = {{"w", "width"},      {"h", "height"},     {"s", "step_size"},
                                                    {"e", "stop_thresh"}, {"a", "sigma_thresh"}, {"o", "write_images"},
                                                    {"i", "intrin"},      {"r", "reverse_yz"}};
-const char* kFlags[] = {"reverse_yz", "write_buffer", "help", "print_poses", "quant_direct"};
+const char* kFlags[] = {"reverse_yz", "write_buffer", "help", "print_poses", "quant_direct", "torch_net"};
 
 bool is_flag(const std::string& k) {
     for (const char* f : kFlags)
@@ -109,6 +109,8 @@ void usage() {
         "  --write_buffer  --max_imgs N  --scale S  -i intrin  -r,--reverse_yz\n"
         "  --shard i/N        render poses i, i+N, ... only     --warmup K (100)\n"
         "  --batch B          poses per launch (1..32, default 32; 1 = one launch per frame like the reference's loop)\n"
+        "  --torch_net        run the TorchScript GuidanceNet through libtorch even when it is the compact two-layer\n"
+        "                     network the fused HIP kernel implements (default: fused)\n"
         "  --quant_direct     render a quantised tree.npz from its codebooks (no expansion to dense fp16)\n"
         "  --print_poses      parse the poses, print them (column-major 4x3) and exit\n");
 }
@@ -226,7 +228,8 @@ int main(int argc, char** argv) {
     std::unique_ptr<rto::TorchDenoiser> denoiser;
     if (options.denoise) {
         try {
-            denoiser = std::make_unique<rto::TorchDenoiser>(args.get("ts_module", ""), device);
+            denoiser = std::make_unique<rto::TorchDenoiser>(args.get("ts_module", ""), device, !args.has("torch_net"));
+            std::printf("INFO: GuidanceNet runs %s\n", denoiser->fused() ? "as the fused HIP kernel" : "through libtorch");
         } catch (const std::exception& e) {
             std::fprintf(stderr, "ERROR: %s\n", e.what());
             return 1;
@@ -260,6 +263,21 @@ int main(int argc, char** argv) {
         CHECK_RTO(rto_launch_renderer(tree, &cam, &options, ctx, stream));
         if (options.denoise) CHECK_RTO(denoise());
         rto_ctx_rng_advance(ctx, 1LL << 32);
+    }
+    if (batch > 1 && options.denoise && warmup > 0) {
+        // the batched network forward has its own shapes (convolution algorithm search, allocator
+        // growth in libtorch): warm those up as well, like the single-frame denoise above
+        const size_t n_mine = (ps.trans.size() + (size_t)shard_n - 1 - (size_t)shard_i) / (size_t)shard_n;
+        const int shapes[2] = {(int)std::min<size_t>((size_t)batch, n_mine), (int)(n_mine % (size_t)batch)};
+        for (int n : shapes) {
+            if (n < 1) continue;
+            for (int rep = 0; rep < 3; ++rep) {
+                const float *w = nullptr, *g = nullptr;
+                int L = 0;
+                denoiser->forward(rto_ctx_aux(ctx), n, height, width, &w, &g, &L);
+                CHECK_RTO(rto_filtering_batch(stream, w, g, L, height, width, n, rto_ctx_noisy(ctx), rto_ctx_image(ctx)));
+            }
+        }
     }
     rto_timer_reset(ctx, stream);
 

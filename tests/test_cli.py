@@ -100,8 +100,14 @@ def test_cli_denoise_with_torchscript_module(tmp_path):
     ts.save(tsp)
     op = synth.write_opt_json(str(tmp_path / "opt.json"))  # spp 6, denoise true: the reference's opt.json
     out = str(tmp_path / "out")
-    r = _run([tp, pp, "--options", op, "--ts_module", tsp, "-w", "80", "-h", "64", "-o", out, "--warmup", "1"])
+    r = _run([tp, pp, "--options", op, "--ts_module", tsp, "-w", "80", "-h", "64", "-o", out, "--warmup", "1", "--torch_net"])
     assert r.returncode == 0, r.stderr
+    assert "GuidanceNet runs through libtorch" in r.stdout
+    # default: the compact two-layer module is recognised and runs as the fused HIP kernel
+    out_f = str(tmp_path / "out_fused")
+    rf = _run([tp, pp, "--options", op, "--ts_module", tsp, "-w", "80", "-h", "64", "-o", out_f, "--warmup", "1"])
+    assert rf.returncode == 0, rf.stderr
+    assert "GuidanceNet runs as the fused HIP kernel" in rf.stdout
     # the same through the Python host
     dt = R.N3Tree(tp)
     ctx = R.RenderContext(80, 64)
@@ -118,6 +124,13 @@ def test_cli_denoise_with_torchscript_module(tmp_path):
         want = ctx.download_rgba8()
         got = np.array(Image.open(os.path.join(out, "r_%d.png" % i)))
         assert np.array_equal(got, want), i
+        # fused kernel on the same TorchScript weights: the Python FusedGuidanceNet gives the same bytes
+        fused = denoiser.FusedGuidanceNet(torch.jit.load(tsp, map_location="cuda:0"))
+        wm, gm = fused(torch.as_tensor(ctx.aux_view(), device="cuda:0"))
+        R.filtering(None, wm[0].contiguous(), gm[0].contiguous(), ctx.noisy_ptr, ctx.image_ptr)
+        got_f = np.array(Image.open(os.path.join(out_f, "r_%d.png" % i)))
+        assert np.array_equal(got_f, ctx.download_rgba8()), i
+        assert np.abs(got_f.astype(int) - got.astype(int)).max() <= 2  # fp16 accumulation order only
     # denoise = true without --ts_module: the reference's error text
     r = _run([tp, pp, "--options", op, "-w", "80", "-h", "64"])
     assert r.returncode == 1 and "No torchscript module is given to denoiser." in r.stderr

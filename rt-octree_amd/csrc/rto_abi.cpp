@@ -875,6 +875,9 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     if (!tree->fast_ok) return set_err(RTO_E_UNSUPPORTED, "the batched renderer needs an N == 2 tree of depth <= 24");
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");
+    // the traversal kernel addresses the hand-off buffer with 32-bit offsets (frame * spp * pixels + pixel)
+    if ((uint64_t)(slot0 + n) * (uint64_t)o->spp * (uint64_t)frame_px(ctx) > 0xffffffffULL)
+        return set_err(RTO_E_UNSUPPORTED, "frames x spp x pixels exceeds 2^32 hit-list entries: render fewer frames per launch");
     if (ctx->hits_spp < o->spp) {  // grow the hit-list buffer (first use, or a larger spp); stream-ordered free
         if (ctx->hits) {
             HIP_TRY(hipDeviceSynchronize());

@@ -205,14 +205,6 @@ int main(int argc, char** argv) {
     const std::string out_dir = args.get("write_images", "");
     if (!out_dir.empty()) fs::create_directories(out_dir);
 
-    int batch = std::max(1, std::min(32, std::atoi(args.get("batch", "32").c_str())));
-    {  // no more frame slots than this process has poses to render
-        const size_t n_mine = (ps.trans.size() + (size_t)shard_n - 1 - (size_t)shard_i) / (size_t)shard_n;
-        if ((size_t)batch > n_mine) batch = (int)std::max<size_t>(1, n_mine);
-    }
-    rto_ctx* ctx = nullptr;
-    CHECK_RTO(rto_ctx_create_batch(width, height, batch, device, &ctx));
-
     rto_options options;
     rto_options_default(&options);
     const std::string options_path = args.get("options", "");
@@ -224,6 +216,18 @@ int main(int argc, char** argv) {
         options.stop_thresh = (float)std::atof(args.get("stop_thresh", "1e-2").c_str());
         options.sigma_thresh = (float)std::atof(args.get("sigma_thresh", "1e-2").c_str());
     }
+
+    int batch = std::max(1, std::min(32, std::atoi(args.get("batch", "32").c_str())));
+    {  // no more frame slots than this process has poses to render
+        const size_t n_mine = (ps.trans.size() + (size_t)shard_n - 1 - (size_t)shard_i) / (size_t)shard_n;
+        if ((size_t)batch > n_mine) batch = (int)std::max<size_t>(1, n_mine);
+        // the batched kernels address their hit lists with 32-bit offsets: frames x spp x pixels < 2^32
+        const uint64_t per_frame = (uint64_t)std::max(1, options.spp) * (uint64_t)width * (uint64_t)height;
+        const uint64_t cap = 0xffffffffULL / std::max<uint64_t>(1, per_frame);
+        if ((uint64_t)batch > cap) batch = (int)std::max<uint64_t>(1, cap);
+    }
+    rto_ctx* ctx = nullptr;
+    CHECK_RTO(rto_ctx_create_batch(width, height, batch, device, &ctx));
 
     std::unique_ptr<rto::TorchDenoiser> denoiser;
     if (options.denoise) {

@@ -272,3 +272,27 @@ def test_queue_tuning_never_changes_results(small_tree_sh16):
         ctx.set_tuning("tile_block", 0)
     with pytest.raises(R.RtoError):
         ctx.set_tuning("no_such_knob", 1)
+
+
+def test_batched_launches_repeat_bit_for_bit(small_tree_sh16):
+    """work stealing and refill order differ from launch to launch; the frames must not: 8 launches of
+    8 frames, every byte of every output hashed"""
+    import hashlib
+    _, dt = make_pair(small_tree_sh16)
+    W, H = 320, 240
+    cams = []
+    for f in range(8):
+        _, cam = cameras(W, H, POSES[f % len(POSES)])
+        cams.append(cam)
+    ctx = R.RenderContext(W, H, frames=8)
+    seen = set()
+    for rep in range(8):
+        ctx.rng_seed()
+        R.launch_renderer_batch(dt, cams, R.RenderOptions(spp=6, denoise=False), ctx, rng_jumps=list(range(50, 58)))
+        h = hashlib.sha1()
+        for f in range(8):
+            ctx.select_frame(f)
+            h.update(ctx.download_aux().tobytes())
+            h.update(ctx.download_image().tobytes())
+        seen.add(h.hexdigest())
+    assert len(seen) == 1

@@ -64,6 +64,9 @@ def parse_args():
     ap.add_argument("--tree", default="", help="render this tree.npz instead of the synthetic one")
     ap.add_argument("--quant-direct", action="store_true",
                     help="with --tree <quantised tree.npz>: render from the codebooks instead of the expanded fp16 tree")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="groups alternate over this many HIP streams (each with its own context): the tail of one "
+                         "group's kernels overlaps the next group's; per-kernel durations then include the sharing")
     ap.add_argument("--torch-net", action="store_true", help="run GuidanceNet through PyTorch-ROCm (MIOpen) instead of the fused HIP kernel")
     return ap.parse_args()
 
@@ -154,37 +157,47 @@ def main():
     stream = torch.cuda.current_stream(dev)
     aux_v, noisy_v, image_v = ctx.batch_views()
     aux_t = torch.as_tensor(aux_v, device=dev)  # zero-copy [B,8,H,W]
+    # lane = (context, stream, network instance with its own output buffers, aux view)
+    lanes = [(ctx, stream, net, aux_t)]
+    for _ in range(1, max(1, args.streams)):
+        c2 = R.RenderContext(W, H, device=local_rank, frames=B)
+        n2 = None
+        if denoise:
+            n2 = compact.half().to(dev) if args.torch_net else denoiser.FusedGuidanceNet(compact, device=local_rank)
+        lanes.append((c2, torch.cuda.Stream(dev), n2, torch.as_tensor(c2.batch_views()[0], device=dev)))
 
     def pose_of(step):  # global frame index of this rank's `step`-th frame
         return (step * world + rank) % len(poses)
 
-    def group(first_step, n, ev):
+    def group(first_step, n, ev, lane=0):
         """n frames: traversal + shading, GuidanceNet, filter; all asynchronous on `stream`, no host
         sync (the reference synchronises once per frame, render_context.hpp:179-188).  Frame i of the
         reference run uses the RNG advanced (100 + i) times."""
         idx = [pose_of(first_step + k) for k in range(n)]
-        ctx.rng_seed()
+        lctx, lstream, lnet, laux = lanes[lane]
+        lctx.rng_seed()
         if ev:
-            ev[0].record(stream)
-        R.launch_renderer_batch(tree, [cams[i] for i in idx], opt, ctx, stream,
+            ev[0].record(lstream)
+        R.launch_renderer_batch(tree, [cams[i] for i in idx], opt, lctx, lstream,
                                 rng_jumps=[WARM_FRAMES_REF + i for i in idx])
         if ev:
-            ev[1].record(stream)
+            ev[1].record(lstream)
         if denoise:
-            with torch.no_grad():
-                wm, gm = net(aux_t[:n])
+            with torch.no_grad(), torch.cuda.stream(lstream):
+                wm, gm = lnet(laux[:n], stream=lstream) if not args.torch_net else lnet(laux[:n])
             if ev:
-                ev[2].record(stream)
-            R.filtering(stream, wm, gm, ctx.noisy_ptr, ctx.image_ptr)
+                ev[2].record(lstream)
+            lctx.select_frame(0)
+            R.filtering(lstream, wm, gm, lctx.noisy_ptr, lctx.image_ptr)
             if ev:
-                ev[3].record(stream)
+                ev[3].record(lstream)
 
     def run(n_frames, events):
         s = 0
         g = 0
         while s < n_frames:
             n = min(B, n_frames - s)
-            group(s, n, events[g] if events else None)
+            group(s, n, events[g] if events else None, g % len(lanes))
             s += n
             g += 1
 
@@ -194,7 +207,8 @@ def main():
     # ---------------- warm-up + timed region ----------------
     run(args.warmup, None)
     torch.cuda.synchronize(dev)
-    ctx.kernel_timing(True)
+    for lc, _, _, _ in lanes:
+        lc.kernel_timing(True)
     barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -206,8 +220,13 @@ def main():
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kt = ctx.kernel_timing_read()
-    ctx.kernel_timing(False)
+    kts = [lc.kernel_timing_read() for lc, _, _, _ in lanes]
+    for lc, _, _, _ in lanes:
+        lc.kernel_timing(False)
+    n_launch = max(sum(k["launches"] for k in kts), 1)  # per-launch means, weighted over the lanes
+    kt = {"launches": sum(k["launches"] for k in kts),
+          "traverse_ms": sum(k["traverse_ms"] * k["launches"] for k in kts) / n_launch,
+          "shade_ms": sum(k["shade_ms"] * k["launches"] for k in kts) / n_launch}
     # Timer::report formula (render_context.hpp:190-206), per frame, from the per-group event pairs
     render_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
     torch_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps if denoise else 0.0
@@ -349,7 +368,7 @@ def main():
                         % (tree.data_format, tree.capacity, tree.max_depth, W, H, args.spp,
                            " + GuidanceNet(8,32,5,2,4) denoise" if denoise else " raw (no denoise)", B),
             "tree_nodes": int(tree.capacity), "tree_device_mb": tree.device_bytes / 1e6,
-            "frames_per_launch": B, "parallelism": "frames x%d" % world,
+            "frames_per_launch": B, "streams": len(lanes), "parallelism": "frames x%d" % world,
         },
         "reference_timer": {  # Timer::report formula (render_context.hpp:190-206), rank 0, per frame
             "render_ms": tstats["render_ms"], "torch_ms": tstats["torch_ms"], "filter_ms": tstats["filter_ms"],

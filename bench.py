@@ -47,8 +47,8 @@ WARM_FRAMES_REF = 100  # main_headless.cpp:469-479: 100 warm-up frames each adva
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--batch", type=int, default=32, help="frames per launch group (1..32)")
     ap.add_argument("--size", type=int, default=800, help="square image size (config C2/C5)")
     ap.add_argument("--width", type=int, default=0, help="with --height: non-square frames (config C4: 1920x1080)")

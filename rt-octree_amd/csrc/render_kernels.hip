@@ -483,6 +483,7 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
         uint32_t pix = 0, piy = 0, piz = 0;
         int prev_lvl = 0;
         uint32_t* stack = s_stack + tid;
+        const int G = tree.top_levels;  // 0: no top grid
 
         while (t < tmax) {
             float pos[3] = {cen[0] + t * dir[0], cen[1] + t * dir[1], cen[2] + t * dir[2]};
@@ -496,13 +497,31 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
             const uint32_t diff = (ix ^ pix) | (iy ^ piy) | (iz ^ piz);
             int lvl = __clz((int)diff) - 8;
             lvl = lvl < prev_lvl ? lvl : prev_lvl;
-            uint32_t node = lvl ? stack[lvl * 256] : 0u;
-            uint32_t w, slot;
+            uint32_t node, w, slot;
+            bool have_w = false;
+            if (lvl < G) {
+                // restart above the shortcut levels: ONE 8-byte lookup replaces the walk over node levels
+                // 0..G-1 (a chain of dependent loads -- what a lone frame's long rays wait for) and
+                // already carries the word of the slot where that walk ends
+                const uint32_t gs = 24u - (uint32_t)G;
+                const uint32_t key = (((ix >> gs) << G | (iy >> gs)) << G) | (iz >> gs);
+                const uint2 e = tree.topgrid[key];
+                slot = e.x & 0x07ffffffu;
+                lvl = (int)(e.x >> 27);
+                node = slot >> 3;
+                w = e.y;
+                have_w = true;
+            } else {
+                node = lvl ? stack[lvl * 256] : 0u;
+            }
             for (;;) {
-                const int sh = 23 - lvl;
-                const uint32_t ci = (((ix >> sh) & 1u) << 2) | (((iy >> sh) & 1u) << 1) | ((iz >> sh) & 1u);
-                slot = node * 8u + ci;
-                w = tree.nodew[slot];
+                if (!have_w) {
+                    const int sh = 23 - lvl;
+                    const uint32_t ci = (((ix >> sh) & 1u) << 2) | (((iy >> sh) & 1u) << 1) | ((iz >> sh) & 1u);
+                    slot = node * 8u + ci;
+                    w = tree.nodew[slot];
+                }
+                have_w = false;
                 if (nodew_is_leaf(w)) break;
                 node += w;  // two's complement add of the relative offset
                 ++lvl;

@@ -296,3 +296,32 @@ def test_batched_launches_repeat_bit_for_bit(small_tree_sh16):
             h.update(ctx.download_image().tobytes())
         seen.add(h.hexdigest())
     assert len(seen) == 1
+
+
+def test_handles_release_their_device_memory(small_tree_sh9):
+    """create / use / free trees, contexts (all lazily grown buffers included) and fused networks in a
+    loop: free device memory returns to where it started"""
+    import torch
+    from rt_octree_amd import denoiser
+    tree = small_tree_sh9
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    _, cam = cameras(256, 192, POSES[0])
+
+    def cycle():
+        dt = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+        ctx = R.RenderContext(256, 192, frames=4)
+        R.launch_renderer_batch(dt, [cam] * 4, R.RenderOptions(spp=8, denoise=True), ctx)
+        R.launch_renderer(dt, cam, R.RenderOptions(spp=2, denoise=False), ctx)
+        ctx.download_aux()
+        ctx.freeResource()  # RenderContext::freeResource (render_context.hpp)
+        dt.free()
+
+    cycle()  # first use may grow allocator pools / load code objects
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(20):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (8 << 20), (free0, free1)

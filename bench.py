@@ -276,6 +276,25 @@ def main():
             dist.destroy_process_group()
         return
 
+    # STREAM-style copy on this box (report the achieved rate against the measured copy
+    # bandwidth as well as against the 8 TB/s peak): 1 GiB device-to-device, read + write counted
+    copy_gbps = None
+    try:
+        a = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        b = torch.empty_like(a)
+        b.copy_(a)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        copy_gbps = 10 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
+    except Exception:
+        copy_gbps = None
+
     # ---------------- CPU baseline (rank 0, N == 1 only; bounded sample) ----------------
     cpu = None
     if world == 1 and args.cpu_frames > 0:
@@ -377,6 +396,7 @@ def main():
             "kernel": "render_persist<%d>" % args.spp, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": kt["traverse_ms"],
+            "measured_copy_bw": copy_gbps, "frac_of_measured_copy": (achieved / copy_gbps) if copy_gbps else None,
             "launches": kt["launches"], "frames_per_launch": frames_per_launch,
             "shade_kernel_avg_launch_ms": kt["shade_ms"],
             "units_per_frame": {k: v / args.steps for k, v in units.items()},

@@ -1336,12 +1336,14 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
                                     int chunk_override, hipEvent_t* ev, hipStream_t stream) {
     const size_t lds = (size_t)(tree.max_depth + 1 - tree.top_levels + SPP + 1) * 256 * sizeof(uint32_t) +
                        sizeof(FrameDesc) * kMaxBatch;
-    static int blocks_per_cu = 0;  // per instantiation
-    if (blocks_per_cu == 0) {
+    static int blocks_per_cu = 0;  // per instantiation, for the LDS size it was asked with (deeper trees need more)
+    static size_t blocks_for_lds = 0;
+    if (blocks_per_cu == 0 || blocks_for_lds != lds) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_persist<SPP, REFILL, WPS>, 256, lds) != hipSuccess || nb < 1)
             nb = 2;
         blocks_per_cu = nb > 8 ? 8 : nb;
+        blocks_for_lds = lds;
     }
     const int tiles = ((fb.width + 7) / 8) * ((fb.height + 7) / 8) * fb.n;
     int grid = num_cus * blocks_per_cu;

@@ -62,6 +62,9 @@ def parse_args():
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores)")
     ap.add_argument("--tree", default="", help="render this tree.npz instead of the synthetic one")
+    ap.add_argument("--shuffle-nodes", type=int, default=0, metavar="SEED",
+                    help="store the synthetic tree's nodes in a random order (seed > 0): svox-refined trees have no "
+                         "ordering guarantee, make_tree's breadth-first order is the friendliest one; images are unchanged")
     ap.add_argument("--quant-direct", action="store_true",
                     help="with --tree <quantised tree.npz>: render from the codebooks instead of the expanded fp16 tree")
     ap.add_argument("--streams", type=int, default=1,
@@ -73,6 +76,8 @@ def parse_args():
 
 def tree_cache_path(args):
     key = "d%d_s%g_b%d" % (args.depth, args.shell, args.basis)
+    if args.shuffle_nodes:
+        key += "_shuf%d" % args.shuffle_nodes
     tag = hashlib.sha1(open(os.path.join(ROOT, "rt-octree_amd", "synth.py"), "rb").read()).hexdigest()[:10]
     base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
     return os.path.join(base, "rto_bench_tree_%s_%s.npz" % (key, tag))
@@ -123,6 +128,8 @@ def main():
         if rank == 0 and not os.path.exists(path):
             t0 = time.time()
             tree_host = synth.make_tree(depth_limit=args.depth, basis_dim=args.basis, shell=args.shell)
+            if args.shuffle_nodes:
+                tree_host = synth.shuffle_nodes(tree_host, args.shuffle_nodes)
             tree_host.save_npz(path + ".tmp.npz")
             os.replace(path + ".tmp.npz", path)
             print("[bench] generated %s: %s in %.1fs" % (path, tree_host.stats, time.time() - t0), file=sys.stderr)

@@ -37,7 +37,7 @@ extern "C" {
 #define RTO_OK 0
 #define RTO_E_INVALID -1     /* bad argument */
 #define RTO_E_SPP -2         /* spp not in {1,2,3,4,6,8,16,32} (volrend.cu:266-278) */
-#define RTO_E_UNSUPPORTED -3 /* feature outside the headless path (probe, rot_dirs, SG/ASG) */
+#define RTO_E_UNSUPPORTED -3 /* feature outside the headless path (probe, SG/ASG) */
 #define RTO_E_HIP -4         /* HIP runtime error / no device */
 #define RTO_E_IO -5          /* file missing / malformed */
 #define RTO_E_FORMAT -6      /* npz content violates the tree schema (n3tree.cpp:283-291,345) */
@@ -260,6 +260,18 @@ void rto_guidance_net_free(rto_guidance_net* net);
  * loads one dword from its own never-repeated 128-byte line of a zero-filled n_lines*128-byte buffer
  * (the render path's access shape).  Known lines per launch = n_lines; compare with FETCH_SIZE. */
 int rto_probe_gather(uint64_t n_lines, int repeats);
+/* Ceiling probes for the traversal kernel (DESIGN.md "What bounds the traversal"; tools/probe_ceiling.py).
+ * rto_probe_gather_sweep: persistent waves (`wps` per SIMD on every CU) issue `iters` wave-level dword
+ * gathers each; every gather touches exactly `lines_per_gather` (1..64) distinct 64-byte lines of a
+ * zero-filled table of `table_bytes` (rounded down to a power of two), the lanes dealt over the lines
+ * interleaved (blocked = 0) or in runs (blocked = 1); dependent = 1 chains each gather's address on the
+ * previous one's value (the traversal's shape), 0 keeps four in flight per wave.
+ * out = {wall ms per launch, mean shader-clock cycles per wave, waves, gathers per wave}.
+ * rto_probe_valu: 16 independent chains per lane; kind 0 = v_fma_f32, 1 = integer, 2 = the traversal's op
+ * mix.  out = {wall ms, mean cycles per wave, waves, nominal VALU instructions per wave}. */
+int rto_probe_gather_sweep(uint64_t table_bytes, int lines_per_gather, int blocked, int dependent, int wps,
+                           int iters, int repeats, double out[4]);
+int rto_probe_valu(int kind, int wps, int iters, double out[4]);
 
 #ifdef __cplusplus
 }

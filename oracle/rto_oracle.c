@@ -502,11 +502,25 @@ int orc_render_pixel(const orc_tree* tree, const orc_camera* cam, const orc_opti
             v_normalize(dir);
         }
         for (int i = 0; i < 3; ++i) cen[i] = tree->offset[i] + tree->scale[i] * cen[i]; /* :142-144 */
-        /* rodrigues :58-73 is a no-op below 1e-6 (headless never sets rot_dirs) */
+        /* rodrigues(opt.rot_dirs, vdir) :58-73,155 -- rotates the VIEW direction only (the SH lookup),
+         * never the marching direction.  scalar_t = float: cos/sin resolve to the float overloads;
+         * `(1.0 - cos_angle)` is a double, so the third term and the final sum are evaluated in
+         * double and rounded once on assignment. */
         {
             float aa[3] = {opt->rot_dirs[0], opt->rot_dirs[1], opt->rot_dirs[2]};
             float angle = v_norm(aa);
-            if (!(angle < 1e-6)) return -3; /* GUI-only feature, not restated */
+            if (!(angle < 1e-6)) {
+                float k[3];
+                for (int i = 0; i < 3; ++i) k[i] = aa[i] / angle;
+                float cos_angle = cosf(angle), sin_angle = sinf(angle);
+                float cross[3];
+                cross[0] = k[1] * vdir[2] - k[2] * vdir[1]; /* _cross3 common.cuh:54-60 */
+                cross[1] = k[2] * vdir[0] - k[0] * vdir[2];
+                cross[2] = k[0] * vdir[1] - k[1] * vdir[0];
+                float dot = k[0] * vdir[0] + k[1] * vdir[1] + k[2] * vdir[2]; /* _dot3 :46-51 */
+                for (int i = 0; i < 3; ++i)
+                    vdir[i] = vdir[i] * cos_angle + cross[i] * sin_angle + k[i] * dot * (1.0 - cos_angle);
+            }
         }
         orc_pcg32 rng = *rng_base;
         orc_pcg32_advance(&rng, (int64_t)(idx * opt->spp)); /* :157, int product */

@@ -152,9 +152,19 @@ RTO_DEV void sh_basis(int basis_dim, const float* dir, float* out) {
 }
 
 // basis for the ray + the basis_minmax mask (rt_core.cuh:277-284)
-RTO_DEV void ray_basis(const TreeDev& tree, const OptDev& opt, const float* vdir, float* basis_fn) {
+RTO_DEV void ray_basis(const TreeDev& tree, const OptDev& opt, const float* vdir_in, float* basis_fn) {
 #pragma unroll
     for (int i = 0; i < RTO_BASIS_MAX_DEV; ++i) basis_fn[i] = 0.f;
+    float vdir[3] = {vdir_in[0], vdir_in[1], vdir_in[2]};
+    if (opt.rot_on) {  // rodrigues (volrend.cu:58-73): only the view direction of the SH lookup turns
+        const float* k = opt.rot_k;
+        const float cross[3] = {k[1] * vdir[2] - k[2] * vdir[1], k[2] * vdir[0] - k[0] * vdir[2],
+                                k[0] * vdir[1] - k[1] * vdir[0]};
+        const float dot = k[0] * vdir[0] + k[1] * vdir[1] + k[2] * vdir[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)  // float + float, then + (float * float) * double in double, one rounding
+            vdir[i] = (float)((double)(vdir[i] * opt.rot_cos + cross[i] * opt.rot_sin) + (double)(k[i] * dot) * opt.rot_omc);
+    }
     if (tree.format == 1 /*SH*/) sh_basis(tree.basis_dim, vdir, basis_fn);
 #pragma unroll
     for (int i = 0; i < RTO_BASIS_MAX_DEV; ++i)

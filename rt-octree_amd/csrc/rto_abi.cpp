@@ -320,6 +320,33 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
     return RTO_OK;
 }
 
+// RenderOptions -> the fields the kernels read.  rodrigues (volrend.cu:58-73): angle, axis, cos and sin
+// depend on the options only, so they are evaluated here once per launch (float arithmetic, libm cosf /
+// sinf: the same calls the CPU oracle makes) instead of once per pixel.
+rto::OptDev make_opt_dev(const rto_options* o) {
+    rto::OptDev od;
+    od.step_size = o->step_size;
+    od.sigma_thresh = o->sigma_thresh;
+    od.background_brightness = o->background_brightness;
+    std::memcpy(od.render_bbox, o->render_bbox, sizeof(od.render_bbox));
+    od.basis_minmax[0] = o->basis_minmax[0];
+    od.basis_minmax[1] = o->basis_minmax[1];
+    const float* a = o->rot_dirs;
+    const float angle = sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);  // _norm common.cuh:16-20
+    od.rot_on = !(angle < 1e-6);
+    od.rot_k[0] = od.rot_k[1] = od.rot_k[2] = 0.f;
+    od.rot_cos = 1.f;
+    od.rot_sin = 0.f;
+    od.rot_omc = 0.0;
+    if (od.rot_on) {
+        for (int i = 0; i < 3; ++i) od.rot_k[i] = a[i] / angle;
+        od.rot_cos = cosf(angle);
+        od.rot_sin = sinf(angle);
+        od.rot_omc = 1.0 - od.rot_cos;
+    }
+    return od;
+}
+
 int options_from_value(const rto::json::Value& j, rto_options* o) {
     rto_options r;
     rto_options_default(&r);
@@ -801,11 +828,6 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
     if (tree->device != ctx->device) return set_err(RTO_E_INVALID, "tree and context live on different devices");
     if (o->enable_probe)
         return set_err(RTO_E_UNSUPPORTED, "enable_probe is a GUI feature (volrend.cu:100-134), not on the headless path");
-    {
-        const float* a = o->rot_dirs;
-        if (!(std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) < 1e-6))  // rodrigues volrend.cu:62-63
-            return set_err(RTO_E_UNSUPPORTED, "rot_dirs is a GUI feature (volrend.cu:58-73), not on the headless path");
-    }
     if (tree->dev.format == RTO_FMT_SG || tree->dev.format == RTO_FMT_ASG)
         return set_err(RTO_E_UNSUPPORTED, "SG/ASG bases are untested upstream (lumisphere.hpp:14-37) and not built");
     if (!(cam->fx != 0.f) || !(cam->fy != 0.f)) return set_err(RTO_E_INVALID, "camera focal length is zero");
@@ -829,13 +851,7 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
     cd.fx = cam->fx;
     cd.fy = cam->fy;
     std::memcpy(cd.transform, cam->transform, sizeof(cd.transform));
-    rto::OptDev od;
-    od.step_size = o->step_size;
-    od.sigma_thresh = o->sigma_thresh;
-    od.background_brightness = o->background_brightness;
-    std::memcpy(od.render_bbox, o->render_bbox, sizeof(od.render_bbox));
-    od.basis_minmax[0] = o->basis_minmax[0];
-    od.basis_minmax[1] = o->basis_minmax[1];
+    const rto::OptDev od = make_opt_dev(o);
     rto::FrameOut fo;
     fo.aux = rto_ctx_aux(ctx);
     fo.image = o->denoise ? rto_ctx_noisy(ctx) : rto_ctx_image(ctx);  // volrend.cu:206
@@ -865,11 +881,6 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
         return set_err(RTO_E_SPP, "spp == " + std::to_string(o->spp) + " not supported. (supported: 1,2,3,4,6,8,16,32)");
     if (tree->device != ctx->device) return set_err(RTO_E_INVALID, "tree and context live on different devices");
     if (o->enable_probe) return set_err(RTO_E_UNSUPPORTED, "enable_probe is a GUI feature, not on the headless path");
-    {
-        const float* a = o->rot_dirs;
-        if (!(std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) < 1e-6))
-            return set_err(RTO_E_UNSUPPORTED, "rot_dirs is a GUI feature, not on the headless path");
-    }
     if (tree->dev.format == RTO_FMT_SG || tree->dev.format == RTO_FMT_ASG)
         return set_err(RTO_E_UNSUPPORTED, "SG/ASG bases are untested upstream and not built");
     if (!tree->fast_ok) return set_err(RTO_E_UNSUPPORTED, "the batched renderer needs an N == 2 tree of depth <= 24");
@@ -929,13 +940,7 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     hipStream_t stream = (hipStream_t)stream_;
     int rc = ensure_jump_table(ctx, stream);
     if (rc != RTO_OK) return rc;
-    rto::OptDev od;
-    od.step_size = o->step_size;
-    od.sigma_thresh = o->sigma_thresh;
-    od.background_brightness = o->background_brightness;
-    std::memcpy(od.render_bbox, o->render_bbox, sizeof(od.render_bbox));
-    od.basis_minmax[0] = o->basis_minmax[0];
-    od.basis_minmax[1] = o->basis_minmax[1];
+    const rto::OptDev od = make_opt_dev(o);
     hipEvent_t* ev = nullptr;
     if (ctx->kt_on && ctx->kt_count < kKtRing) ev = &ctx->kt_ev[(size_t)ctx->kt_count++ * 3];
     hipError_t e = rto::launch_render_batch(o->spp, tree->dev, od, fb, ctx->jump, ctx->queue,

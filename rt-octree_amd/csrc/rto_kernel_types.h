@@ -56,6 +56,11 @@ struct OptDev {
     float step_size, sigma_thresh, background_brightness;
     float render_bbox[6];
     int basis_minmax[2];
+    // rodrigues(opt.rot_dirs, vdir) (volrend.cu:58-73,155): the per-frame constants of the rotation,
+    // computed once on the host (make_opt_dev); rot_on = 0 below the reference's 1e-6 angle cut-off
+    int rot_on;
+    float rot_k[3], rot_cos, rot_sin;
+    double rot_omc;  // (1.0 - cos_angle), a double in the reference's expression
 };
 
 // Strip-interleaved tile order: tile-row r belongs to XCD ((r / strip_rows) % 8); workgroup b

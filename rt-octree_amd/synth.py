@@ -227,6 +227,27 @@ def make_tree(depth_limit=6, basis_dim=9, seed=20230418, shell=1.25, radius=1.5,
     return SynthTree(child, data, scale, offset, "SH%d" % basis_dim, depth_limit, stats)
 
 
+def shuffle_nodes(tree, seed=1):
+    """The same octree with its nodes stored in a random order (the root stays node 0), child[] offsets
+    recomputed.  svox-refined trees carry no ordering guarantee (refine appends the children of whatever
+    leaves were selected); make_tree's breadth-first order is the friendliest possible one.  Every query
+    returns the same leaf values, so every image is unchanged."""
+    cap = tree.capacity
+    rng = np.random.default_rng(seed)
+    new_of_old = np.concatenate([[0], 1 + rng.permutation(cap - 1)]).astype(np.int64)
+    child = tree.child.reshape(cap, 8).astype(np.int64)
+    node = np.arange(cap, dtype=np.int64)[:, None]
+    tgt_old = node + child                                   # old index of the child node (where child != 0)
+    rel_new = np.where(child != 0, new_of_old[np.where(child != 0, tgt_old, 0)] - new_of_old[node], 0)
+    child_new = np.empty((cap, 8), np.int32)
+    child_new[new_of_old] = rel_new.astype(np.int32)
+    data_new = np.empty_like(tree.data)
+    data_new[new_of_old] = tree.data
+    stats = dict(tree.stats, shuffled_seed=int(seed))
+    return SynthTree(child_new.reshape(cap, 2, 2, 2), data_new, tree.scale, tree.offset, tree.data_format,
+                     tree.depth_limit, stats)
+
+
 # ------------------------------------------------------------------ cameras
 def look_at_c2w(cam_pos, target=(0, 0, 0), up=(0, 0, 1)):
     """NeRF/blender convention: camera looks along -z, +y is up.  Returns a row-major 4x4."""

@@ -1,0 +1,253 @@
+"""Pins the SEMANTICS of the oracle's trace_ray / render_kernel restatement (rt_core.cuh:195-332,
+volrend.cu:84-213) against an independent float64 statement of the rendering equation
+(tests/expected_render.py) -- the reference ships no golden frames and cannot be compiled here, so
+this is the evidence that the restatement computes the right estimator, not merely the same one as
+the HIP kernels:
+
+  * the mean of >= 4096 spp of oracle frames equals sum_j T_j (1 - e^{-tau_j}) c_j + bg T_end per pixel
+    and channel within 5 sigma / sqrt(n) (sigma from the same model), E[alpha] = 1 - e^{-tau}, and the
+    z-scores have unit variance (a wrong `do { ++cnt; ++spp } while` or a wrong optical-depth factor
+    shifts the mean; a wrong sample count per threshold shows up in the variance);
+  * closed-form rays through a hand-built root node: one homogeneous medium, two media, a leaf below
+    sigma_thresh, a ray lying exactly in the face between two leaves, an SH leaf with opt.rot_dirs;
+  * sample_dst for every supported SPP == the order statistics of -log(1 - u) over the pcg32 stream
+    (pcg32 itself is pinned to the reference's header: tests/golden/pcg32_kat.json).
+CPU only; the GPU twin is tests/test_expectation_gpu.py."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import expected_render as E
+import orc
+from rt_octree_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SUPPORTED_SPP = (1, 2, 3, 4, 6, 8, 16, 32)
+
+
+def _mean_of_frames(ht, cam, n_frames, spp, first_frame=0, **optkw):
+    acc = None
+    for k in range(n_frames):
+        aux, _, _ = orc.render_frame(ht, cam, orc.default_options(spp=spp, **optkw), orc.rng(frame=first_frame + k))
+        acc = aux[:4].astype(np.float64) if acc is None else acc + aux[:4]
+    return acc / n_frames
+
+
+def _check_against_model(got, mean, var, n, what, need_stat=True):
+    """got: mean of n samples per pixel (float32 arithmetic inside); mean/var: the float64 model."""
+    se = np.sqrt(var / n)
+    # float32 paths (leaf boundaries a ray grazes, step_size overshoots) move a pixel by up to ~2e-5
+    bad = np.abs(got - mean) > 5.0 * se + 5e-5
+    assert not bad.any(), "%s: %d values off by more than 5 sigma + 5e-5; worst %.2e" % (
+        what, int(bad.sum()), np.abs(got - mean)[bad].max())
+    stat = se > 5e-4  # pixels whose sampling noise dwarfs the float32 effects
+    if not need_stat and stat.sum() < 150:
+        return
+    assert stat.sum() >= 150, (what, int(stat.sum()))
+    z = ((got - mean) / np.maximum(se, 1e-12))[stat]
+    assert 0.8 < np.mean(z * z) < 1.25, "%s: z-scores have variance %.3f (expected 1)" % (what, np.mean(z * z))
+    assert abs(np.mean(z)) < 5.0 / np.sqrt(z.size / 3.0), "%s: biased, mean z = %.3f" % (what, np.mean(z))
+
+
+def _thin(t, factor):
+    """the same tree with every density scaled: thin media make most pixels noisy (a powerful test),
+    dense ones make them nearly deterministic (a precise one)"""
+    d = t.data.astype(np.float32)
+    d[..., -1] *= factor
+    return synth.SynthTree(t.child, d.astype(np.float16), t.scale, t.offset, t.data_format, t.depth_limit, {})
+
+
+@pytest.mark.parametrize("fmt,density", [("SH9", 1.0), ("SH9", 0.08), ("RGBA", 0.08)])
+def test_estimator_mean_matches_rendering_equation(fmt, density):
+    t = _thin(synth.make_tree(depth_limit=5, basis_dim=9, seed=3, shell=1.5), density)
+    if fmt == "RGBA":
+        from helpers import rgba_tree
+        t = _thin(rgba_tree(synth.make_tree(depth_limit=5, basis_dim=9, seed=3, shell=1.5)), density)
+    ht = orc.HostTree(t.child, t.data, t.scale, t.offset, t.data_format)
+    W, H = 24, 20
+    fx = 0.9 * synth.blender_focal(W)
+    pose = synth.orbit_poses(7)[3]
+    cam = orc.camera(W, H, fx, fx, pose[:3, :4].T.reshape(-1))
+    n_frames, spp = 128, 32
+    got = _mean_of_frames(ht, cam, n_frames, spp, background_brightness=0.5)
+    scene = E.Scene(t.child, t.data, t.scale, t.offset, t.data_format)
+    mean, var = E.expected_frame(scene, pose, W, H, fx, fx, bg=0.5)
+    assert (mean[3] > 0.05).sum() > 60  # the object covers a good part of the image
+    _check_against_model(got, mean, var, n_frames * spp, "%s x%g" % (fmt, density), need_stat=density < 1.0)
+
+
+def test_estimator_mean_with_options():
+    """crop box, sigma threshold, step size, basis mask, rot_dirs: every option the kernel reads."""
+    t = _thin(synth.make_tree(depth_limit=5, basis_dim=9, seed=5, shell=1.5), 0.15)
+    ht = orc.HostTree(t.child, t.data, t.scale, t.offset, t.data_format)
+    W, H = 20, 20
+    fx = synth.blender_focal(W)
+    pose = synth.orbit_poses(5)[1]
+    cam = orc.camera(W, H, fx, fx, pose[:3, :4].T.reshape(-1))
+    bbox = [0.05, 0.1, 0.0, 0.95, 0.9, 0.8]
+    rot = [0.2, -0.4, 0.3]
+    got = _mean_of_frames(ht, cam, 128, 32, first_frame=300, render_bbox=bbox, sigma_thresh=3.0, step_size=5e-4,
+                          basis_minmax=[0, 3], rot_dirs=rot, background_brightness=1.0)
+    scene = E.Scene(t.child, t.data, t.scale, t.offset, t.data_format)
+    mean, var = E.expected_frame(scene, pose, W, H, fx, fx, bg=1.0, rot_dirs=rot, bbox=bbox, sigma_thresh=3.0,
+                                 step_size=5e-4, basis_minmax=(0, 3))
+    _check_against_model(got, mean, var, 128 * 32, "options")
+
+
+# ------------------------------------------------------------------ closed forms on a hand-built node
+def _root_only(values, fmt="RGBA"):
+    """One root node with 8 leaves; values[ix][iy][iz] = data vector.  scale 1, offset 0: tree space == world."""
+    data = np.asarray(values, np.float16).reshape(1, 2, 2, 2, -1)
+    child = np.zeros((1, 2, 2, 2), np.int32)
+    return orc.HostTree(child, data, np.ones(3, np.float32), np.zeros(3, np.float32), fmt), data
+
+
+def _trace_many(ht, origin, direction, n_rays, spp, vdir=None, **optkw):
+    """Mean out[4] of n_rays independent calls of the oracle's trace_ray (each with its own RNG stream)."""
+    L = orc.lib()
+    opt = orc.default_options(spp=spp, **optkw)
+    acc = np.zeros(4)
+    base = orc.rng()
+    for k in range(n_rays):
+        r = orc.Pcg32(base.state, base.inc)
+        L.orc_pcg32_advance(C.byref(r), k * 64)
+        d = (C.c_float * 3)(*direction)
+        v = (C.c_float * 3)(*(direction if vdir is None else vdir))
+        c = (C.c_float * 3)(*origin)
+        out = (C.c_float * 4)(0, 0, 0, 0)
+        rc = L.orc_trace_ray(C.byref(ht.c), d, v, c, C.byref(opt), C.c_float(1e9), out, C.byref(r), None)
+        assert rc == 0
+        acc += np.array(out[:], np.float64)
+    return acc / n_rays
+
+
+N_RAYS, SPP = 1024, 32
+TOL = 5.0 * 0.5 / np.sqrt(N_RAYS * SPP) + 1e-4  # 5 sigma of a [0,1]-valued sample mean
+
+
+def test_single_homogeneous_medium():
+    """All 8 leaves hold the same medium: alpha = 1 - exp(-sigma * path), colour = alpha * c."""
+    sigma, col = 3.0, (0.8, 0.3, 0.1)
+    ht, _ = _root_only([[[(*col, sigma)] * 2] * 2] * 2)
+    # along +x through y = z = 0.25: two leaves, path = 1 - 2e-6 plus one step_size per leaf left
+    got = _trace_many(ht, (-1.0, 0.25, 0.25), (1.0, 0.0, 0.0), N_RAYS, SPP, step_size=1e-4)
+    alpha = 1.0 - np.exp(-sigma * (1.0 - 1e-6 + 1e-4))
+    assert abs(got[3] - alpha) < TOL
+    assert np.allclose(got[:3], alpha * np.array(col, np.float16).astype(np.float64), atol=TOL)
+    # the diagonal: path sqrt(3), four leaves' worth of cells are crossed at a single point -> two leaves
+    d = np.ones(3) / np.sqrt(3.0)
+    got = _trace_many(ht, tuple(-d), tuple(d), N_RAYS, SPP, step_size=1e-4)
+    alpha = 1.0 - np.exp(-sigma * np.sqrt(3.0))
+    assert abs(got[3] - alpha) < TOL + sigma * 3e-4  # a few step_size overshoots
+
+
+def test_two_media_front_to_back():
+    a, b = (0.9, 0.1, 0.2, 2.0), (0.1, 0.7, 0.9, 5.0)
+    vals = [[[a] * 2] * 2, [[b] * 2] * 2]  # ix = 0 -> a, ix = 1 -> b
+    ht, data = _root_only(vals)
+    got = _trace_many(ht, (-1.0, 0.3, 0.6), (1.0, 0.0, 0.0), N_RAYS, SPP, step_size=1e-4)
+    ta, tb = a[3] * (0.5 - 1e-6 + 1e-4), b[3] * 0.5
+    ca, cb = np.array(a[:3], np.float16).astype(np.float64), np.array(b[:3], np.float16).astype(np.float64)
+    want_rgb = (1 - np.exp(-ta)) * ca + np.exp(-ta) * (1 - np.exp(-tb)) * cb
+    assert abs(got[3] - (1 - np.exp(-ta - tb))) < TOL
+    assert np.allclose(got[:3], want_rgb, atol=TOL)
+    # from the other side the order of compositing flips
+    got = _trace_many(ht, (2.0, 0.3, 0.6), (-1.0, 0.0, 0.0), N_RAYS, SPP, step_size=1e-4)
+    tb2, ta2 = b[3] * (0.5 - 1e-6 + 1e-4), a[3] * 0.5
+    want_rgb = (1 - np.exp(-tb2)) * cb + np.exp(-tb2) * (1 - np.exp(-ta2)) * ca
+    assert np.allclose(got[:3], want_rgb, atol=TOL)
+
+
+def test_leaf_below_sigma_thresh_is_empty_space():
+    a, b = (0.9, 0.9, 0.9, 0.009), (0.2, 0.4, 0.6, 4.0)  # sigma_a <= sigma_thresh = 0.01
+    ht, _ = _root_only([[[a] * 2] * 2, [[b] * 2] * 2])
+    got = _trace_many(ht, (-1.0, 0.3, 0.6), (1.0, 0.0, 0.0), N_RAYS, SPP)
+    tb = b[3] * 0.5
+    assert abs(got[3] - (1 - np.exp(-tb))) < TOL
+    assert np.allclose(got[:3], (1 - np.exp(-tb)) * np.array(b[:3], np.float16).astype(np.float64), atol=TOL)
+    # with the threshold lowered the thin medium counts
+    got2 = _trace_many(ht, (-1.0, 0.3, 0.6), (1.0, 0.0, 0.0), N_RAYS, SPP, sigma_thresh=1e-3)
+    ta = float(np.float16(a[3])) * (0.5 - 1e-6 + 1e-4)
+    assert abs(got2[3] - (1 - np.exp(-ta - tb))) < TOL and got2[3] > got[3]
+
+
+def test_ray_in_the_face_between_leaves():
+    """A ray lying exactly in the plane y = 0.5 belongs to the upper cells (floor convention)."""
+    lower, upper = (1.0, 0.0, 0.0, 6.0), (0.0, 1.0, 0.0, 1.5)
+    vals = [[[lower] * 2, [upper] * 2]] * 2  # iy = 0 -> lower, iy = 1 -> upper
+    ht, _ = _root_only(vals)
+    got = _trace_many(ht, (-1.0, 0.5, 0.25), (1.0, 0.0, 0.0), N_RAYS, SPP)
+    alpha = 1 - np.exp(-upper[3] * (1.0 - 1e-6 + 1e-4))
+    assert abs(got[3] - alpha) < TOL and got[0] < 1e-6 and abs(got[1] - alpha) < TOL
+
+
+def test_sh_leaf_colour_and_rot_dirs():
+    """An SH4 leaf: colour = sigmoid(<Y(view dir), coeffs>), the view direction turned by opt.rot_dirs
+    (axis-angle) while the ray itself is not."""
+    rs = np.random.RandomState(4)
+    coeffs = rs.uniform(-2, 2, (3, 4))
+    vec = np.concatenate([coeffs.reshape(-1), [50.0]])  # opaque
+    ht, data = _root_only([[[vec] * 2] * 2] * 2, fmt="SH4")
+    d = np.array([0.6, -0.64, 0.48])
+    o = np.array([0.5, 0.5, 0.5]) - 2.0 * d
+    c16 = data.reshape(-1, 13)[0, :12].astype(np.float64).reshape(3, 4)
+    for rot in (None, (0.4, 0.1, -0.7)):
+        L = orc.lib()
+        opt = orc.default_options(spp=1, **({} if rot is None else {"rot_dirs": list(rot)}))
+        # through the frame path (rodrigues lives in render_kernel, volrend.cu:155): a 1x1 image whose
+        # single pixel looks along d
+        from expected_render import rotate_axis_angle, real_sh
+        pose = synth.look_at_c2w(o, target=o + d)
+        cam = orc.camera(1, 1, 50.0, 50.0, pose[:3, :4].T.reshape(-1))  # its pixel looks 0.8 degrees off d
+        aux, _, _ = orc.render_frame(ht, cam, opt, orc.rng())
+        org, dd = E.pinhole_ray(pose, 1, 1, 50.0, 50.0, 0, 0)
+        vd = dd if rot is None else rotate_axis_angle(dd, rot)
+        want = 1.0 / (1.0 + np.exp(-(c16 @ real_sh(vd[None], 4)[0])))
+        assert aux[3, 0, 0] == 1.0
+        assert np.allclose(aux[:3, 0, 0], want, atol=2e-6), (rot, aux[:3, 0, 0], want)
+
+
+# ------------------------------------------------------------------ sample_dst
+def _pcg32_py(state, inc, n):
+    """pcg32 (O'Neill's XSH-RR 64/32) in Python integers."""
+    out = []
+    M = (1 << 64) - 1
+    for _ in range(n):
+        old = state
+        state = (old * 6364136223846793005 + inc) & M
+        xorshifted = (((old >> 18) ^ old) >> 27) & 0xffffffff
+        rot = old >> 59
+        out.append(((xorshifted >> rot) | (xorshifted << ((-rot) & 31))) & 0xffffffff)
+    return out, state
+
+
+def test_python_pcg32_matches_reference_kat():
+    kat = json.load(open(os.path.join(HERE, "golden", "pcg32_kat.json")))
+    got, _ = _pcg32_py(int(kat["state0"], 16), int(kat["inc"], 16), 16)
+    assert got == kat["next_uint"]
+
+
+@pytest.mark.parametrize("spp", SUPPORTED_SPP)
+def test_sample_dst_is_the_order_statistics_of_exponentials(spp):
+    """sample_dst<SPP> (rt_core.cuh:67-193): SPP draws of -log(1 - u), u = next_float() in sequence order,
+    returned ascending with a FLT_MAX sentinel -- against float64 logs of the (reference-pinned) pcg32
+    stream.  det_logf is correctly rounded, so the float32 values agree to <= 1 ulp."""
+    L = orc.lib()
+    base = orc.rng()
+    for trial in range(64):
+        r = orc.Pcg32(base.state, base.inc)
+        L.orc_pcg32_advance(C.byref(r), trial * 1000003)
+        words, end_state = _pcg32_py(r.state, r.inc, spp)
+        u = (np.array(words, np.uint32) >> 9 | np.uint32(0x3f800000)).view(np.float32) - np.float32(1.0)
+        want = np.sort(-np.log((np.float32(1.0) - u).astype(np.float64)))
+        dst = (C.c_float * (spp + 1))()
+        L.orc_sample_dst(spp, C.byref(r), dst)
+        got = np.array(dst[:spp], np.float32)
+        assert r.state == end_state  # exactly SPP draws consumed
+        assert dst[spp] == np.finfo(np.float32).max
+        assert np.all(np.diff(got) >= 0)
+        ulp = np.spacing(np.abs(want).astype(np.float32)).astype(np.float64)
+        assert np.all(np.abs(got.astype(np.float64) - want) <= 1.0 * ulp), (spp, trial)

@@ -64,6 +64,47 @@ def test_options_paths_bit_exact(small_tree_sh9):
         assert_bits_equal(rgba_h, rgba_o, "rgba")
 
 
+@pytest.mark.parametrize("rot", [(0.3, -0.2, 0.5), (0.0, 0.0, 0.7853982), (1e-7, 0.0, 0.0)])
+def test_rot_dirs_rodrigues_bit_exact(small_tree_sh16, rot):
+    """opt.rot_dirs turns the VIEW direction of the SH lookup (rodrigues, volrend.cu:58-73,155); the
+    marching direction is untouched.  Generic, fast and batched kernels vs the oracle; the last case
+    lies below the 1e-6 cut-off and must equal the unrotated frame."""
+    ht, dt = make_pair(small_tree_sh16)
+    ocam, cam = cameras(64, 56, POSES[2])
+    aux_o, rgba_o, _ = oracle_frame(ht, ocam, 4, rot_dirs=list(rot))
+    aux_0, _, _ = oracle_frame(ht, ocam, 4)
+    if rot[0] == 1e-7:
+        assert_bits_equal(aux_o, aux_0, "below the cut-off")
+    else:
+        assert not np.array_equal(aux_o[:3], aux_0[:3])  # colours move ...
+        assert_bits_equal(aux_o[3], aux_0[3], "alpha")     # ... the traversal does not
+    for kernel in (R.KERNEL_GENERIC, R.KERNEL_FAST):
+        aux_h, rgba_h, _ = hip_frame(dt, cam, 4, kernel=kernel, rot_dirs=list(rot))
+        assert_bits_equal(aux_h, aux_o, "aux")
+        assert_bits_equal(rgba_h, rgba_o, "rgba")
+    ctx = R.RenderContext(64, 56, frames=2)
+    R.launch_renderer_batch(dt, [cam, cam], R.RenderOptions(spp=4, denoise=False, rot_dirs=list(rot)), ctx, rng_jumps=[7, 0])
+    ctx.select_frame(1)
+    assert_bits_equal(ctx.download_aux(), aux_o, "batched aux")
+
+
+def test_node_order_never_changes_pixels(small_tree_sh9):
+    """The same octree with its nodes stored in a random order (synth.shuffle_nodes) renders the same
+    image through every kernel: node order is a file-layout accident, not scene content."""
+    shuffled = synth.shuffle_nodes(small_tree_sh9, seed=5)
+    ht, dt = make_pair(small_tree_sh9)
+    _, dts = make_pair(shuffled)
+    ocam, cam = cameras(72, 64, POSES[1])
+    aux_o, rgba_o, _ = oracle_frame(ht, ocam, 6)
+    for kernel in (R.KERNEL_GENERIC, R.KERNEL_FAST):
+        aux_h, rgba_h, _ = hip_frame(dts, cam, 6, kernel=kernel)
+        assert_bits_equal(aux_h, aux_o, "aux")
+        assert_bits_equal(rgba_h, rgba_o, "rgba")
+    ctx = R.RenderContext(72, 64, frames=1)
+    R.launch_renderer_batch(dts, [cam], R.RenderOptions(spp=6, denoise=False), ctx)
+    assert_bits_equal(ctx.download_aux(), aux_o, "batched aux")
+
+
 def test_camera_inside_box_and_miss(small_tree_sh9):
     """tmin clamps at 0 for a camera inside the volume; rays that miss return background
     (rt_core.cuh:219-222; SURVEY appendix B 3,4)."""

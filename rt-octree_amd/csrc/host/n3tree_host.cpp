@@ -159,6 +159,8 @@ bool HostTree::open(const std::string& path, bool keep_quantized) {
     if (!(ch.kind == 'i' && ch.word_size == 4) || ch.shape.size() != 4 || ch.fortran_order)
         throw std::runtime_error("tree.npz: child must be a C-ordered int32 [capacity,N,N,N] array");
     N = (int)ch.shape[1];
+    if (N < 1 || ch.shape[2] != ch.shape[1] || ch.shape[3] != ch.shape[1])
+        throw std::runtime_error("tree.npz: child must be [capacity,N,N,N] with equal N");
     if (N != 2) std::fprintf(stderr, "WARNING: N != 2 probably doesn't work.\n");
     child = ch.as<int32_t>();
     const size_t N3 = (size_t)N * N * N;
@@ -167,11 +169,14 @@ bool HostTree::open(const std::string& path, bool keep_quantized) {
         std::fprintf(stderr, "INFO: Decoding quantized colors\n");
         const NpyArray& qc = z.at("quant_colors");
         if (qc.word_size != 2) throw std::runtime_error("codebook must be stored in half precision");
+        if (qc.shape.size() < 2) throw std::runtime_error("tree.npz: quant_colors must be [n_quantised,65536,3]");
         const NpyArray& qm = z.at("quant_map");
         if (qm.word_size != 2 || qm.shape.size() < 2) throw std::runtime_error("tree.npz: quant_map must be uint16");
         capacity = (int64_t)qm.shape[1];
         int n_basis = (int)qm.shape[0];
         if ((int)qc.shape[0] != n_basis) throw std::runtime_error("codebook and map basis numbers does not match");
+        if (z.has("data_retained") && z.at("data_retained").shape.empty())
+            throw std::runtime_error("tree.npz: data_retained must be fp16 [n_retain,capacity,N,N,N,3]");
         const int n_retain = z.has("data_retained") ? (int)z.at("data_retained").shape[0] : 0;
         n_basis += n_retain;
         const NpyArray& sg = z.at("sigma");
@@ -180,6 +185,14 @@ bool HostTree::open(const std::string& path, bool keep_quantized) {
         if (sg.num_vals() < n_child || qm.num_vals() < (size_t)(n_basis - n_retain) * n_child)
             throw std::runtime_error("tree.npz: quantised arrays are too small for the tree");
         if (data_dim < 3 * n_basis + 1) throw std::runtime_error("tree.npz: data_dim too small for the quantised bases");
+        // both branches below index the codebook with 16-bit ids and data_retained per slot
+        if (qc.num_vals() < (size_t)(n_basis - n_retain) * 65536 * 3)
+            throw std::runtime_error("tree.npz: quant_colors must be [n_quantised,65536,3]");
+        if (n_retain) {
+            const NpyArray& rt = z.at("data_retained");
+            if (rt.word_size != 2 || rt.num_vals() < (size_t)n_retain * n_child * 3)
+                throw std::runtime_error("tree.npz: data_retained must be fp16 [n_retain,capacity,N,N,N,3]");
+        }
         if (keep_quantized) {  // render straight from the codebooks: nothing is expanded
             quantized = true;
             this->n_basis = n_basis;
@@ -187,14 +200,7 @@ bool HostTree::open(const std::string& path, bool keep_quantized) {
             q_map = qm.as<uint16_t>();
             q_colors = qc.as<uint16_t>();
             q_sigma = sg.as<uint16_t>();
-            if (n_retain) {
-                const NpyArray& rt = z.at("data_retained");
-                if (rt.word_size != 2 || rt.num_vals() < (size_t)n_retain * n_child * 3)
-                    throw std::runtime_error("tree.npz: data_retained must be fp16 [n_retain,capacity,N,N,N,3]");
-                q_retained = rt.as<uint16_t>();
-            }
-            if (qc.num_vals() < (size_t)(n_basis - n_retain) * 65536 * 3)
-                throw std::runtime_error("tree.npz: quant_colors must be [n_quantised,65536,3]");
+            if (n_retain) q_retained = z.at("data_retained").as<uint16_t>();
             data = nullptr;
         } else {
         decoded.assign(n_child * (size_t)data_dim, 0);
@@ -216,10 +222,7 @@ bool HostTree::open(const std::string& path, bool keep_quantized) {
             out[off + (size_t)data_dim - 1] = sigma[i];
         }
         if (n_retain) {
-            const NpyArray& rt = z.at("data_retained");
-            if (rt.word_size != 2 || rt.num_vals() < (size_t)n_retain * n_child * 3)
-                throw std::runtime_error("tree.npz: data_retained must be fp16 [n_retain,capacity,N,N,N,3]");
-            const uint16_t* rp = rt.as<uint16_t>();
+            const uint16_t* rp = z.at("data_retained").as<uint16_t>();
             for (size_t i = 0; i < n_child; ++i) {
                 const size_t off = i * (size_t)data_dim;
                 for (int j = 0; j < n_retain; ++j) {
@@ -236,6 +239,7 @@ bool HostTree::open(const std::string& path, bool keep_quantized) {
         }
     } else {
         const NpyArray& d = z.at("data");
+        if (d.shape.empty()) throw std::runtime_error("tree.npz: data must be [capacity,N,N,N,data_dim]");
         capacity = (int64_t)d.shape[0];
         if (d.word_size != 2) throw std::runtime_error("data must be stored in half precision");
         if (d.fortran_order) throw std::runtime_error("tree.npz: data must be C-ordered");

@@ -7,6 +7,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <cstdint>
 #include <cstring>
 #include <fstream>
 #include <stdexcept>
@@ -88,8 +89,16 @@ NpyArray parse_npy(const uint8_t* b, size_t n, std::shared_ptr<std::vector<uint8
         }
     }
     a.data = b + hoff + hlen;
-    a.nbytes = a.num_vals() * a.word_size;
-    if (hoff + hlen + a.nbytes > n) fail("truncated .npy payload");
+    {  // element count and byte size with overflow checks (a crafted shape must not wrap around)
+        size_t vals = 1;
+        for (size_t d : a.shape) {
+            if (d != 0 && vals > SIZE_MAX / d) fail("array shape overflows size_t");
+            vals *= d;
+        }
+        if (a.word_size != 0 && vals > SIZE_MAX / a.word_size) fail("array size overflows size_t");
+        a.nbytes = vals * a.word_size;
+    }
+    if (a.nbytes > n - (hoff + hlen)) fail("truncated .npy payload");
     a.owned = std::move(owner);
     return a;
 }

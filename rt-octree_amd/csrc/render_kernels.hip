@@ -721,7 +721,7 @@ template <int SPP, int REFILL, int WPS>
 __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, const OptDev opt, const FrameBatch fb,
                                                        unsigned long long* __restrict__ queue,
                                                        uint32_t* __restrict__ hits, const uint32_t chunk) {
-    // queue[8 + 8k]: next ray of queue k; queue[1]: waves that have left (the last one re-arms all)
+    // queue[8 + 8k]: next ray of queue k (zeroed on the stream before the launch)
     // LDS: [max_depth+1-top_levels][256] ancestor stack | [SPP+1][256] sorted thresholds | frame table
     extern __shared__ uint32_t s_mem[];
     const int tid = threadIdx.x;
@@ -1010,14 +1010,6 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
         }
     }
 #endif
-    // the last wave out re-arms the queue for the next launch (stream order makes it visible)
-    if ((tid & 63) == 0) {
-        const unsigned long long waves = (unsigned long long)gridDim.x * (blockDim.x >> 6);
-        if (atomicAdd(queue + 1, 1ULL) == waves - 1ULL) {
-            for (int k = 0; k < kMaxQueues; ++k) queue[8 + 8 * k] = 0ULL;
-            queue[1] = 0ULL;
-        }
-    }
 }
 
 // One hit leaf of a quantised tree, shaded straight from the codebooks (TreeDev::qrec / qcolors): the
@@ -1343,18 +1335,21 @@ hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev&
 template <int SPP, int REFILL, int WPS>
 static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                     const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
-                                    int chunk_override, hipEvent_t* ev, hipStream_t stream) {
+                                    int chunk_override, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
     const size_t lds = (size_t)(tree.max_depth + 1 - tree.top_levels + SPP + 1) * 256 * sizeof(uint32_t) +
                        sizeof(FrameDesc) * kMaxBatch;
-    static int blocks_per_cu = 0;  // per instantiation, for the LDS size it was asked with (deeper trees need more)
-    static size_t blocks_for_lds = 0;
-    if (blocks_per_cu == 0 || blocks_for_lds != lds) {
+    const void* fn = reinterpret_cast<const void*>(&render_persist<SPP, REFILL, WPS>);
+    OccupancyCache local;
+    if (!occ) occ = &local;
+    if (occ->blocks_per_cu == 0 || occ->fn != fn || occ->lds != lds) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_persist<SPP, REFILL, WPS>, 256, lds) != hipSuccess || nb < 1)
             nb = 2;
-        blocks_per_cu = nb > 8 ? 8 : nb;
-        blocks_for_lds = lds;
+        occ->blocks_per_cu = nb > 8 ? 8 : nb;
+        occ->fn = fn;
+        occ->lds = lds;
     }
+    const int blocks_per_cu = occ->blocks_per_cu;
     const int tiles = ((fb.width + 7) / 8) * ((fb.height + 7) / 8) * fb.n;
     int grid = num_cus * blocks_per_cu;
     if (grid > (tiles + 3) / 4) grid = (tiles + 3) / 4;  // never more waves than 8x8 tiles
@@ -1367,6 +1362,9 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
                                               : (rays_per_wave >= 2048 ? 256u : rays_per_wave >= 512 ? 128u : 64u);
     const int64_t size = (int64_t)fb.width * fb.height;
     hipLaunchKernelGGL(sample_kernel<SPP>, dim3((unsigned)((size + 255) / 256), fb.n), dim3(256), 0, stream, fb, jump);
+    // arm the ray queues on the launch stream (576 B): a launch never depends on how the previous one on
+    // this context ended
+    if (hipMemsetAsync(queue, 0, kQueueWords * sizeof(unsigned long long), stream) != hipSuccess) return hipErrorLaunchFailure;
     if (ev) (void)hipEventRecord(ev[0], stream);
     hipLaunchKernelGGL((render_persist<SPP, REFILL, WPS>), dim3(grid), dim3(256), lds, stream, tree, opt, fb, queue, hits, chunk);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
@@ -1403,11 +1401,11 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
 template <int SPP>
 static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                    const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
-                                   int refill, hipEvent_t* ev, hipStream_t stream) {
+                                   int refill, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
     const int chunk_override = (refill / 1000) * 64;  // tuning: refill = 1000 * tiles_per_dequeue + threshold
     refill %= 1000;
     if (SPP == 6) {  // tuning instantiations only for the benchmark configuration
-#define RTO_F(R, O) return launch_batch_impl<SPP, R, O>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, ev, stream)
+#define RTO_F(R, O) return launch_batch_impl<SPP, R, O>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, occ, ev, stream)
         switch (refill) {  // A/B set kept for tools/ab_tuning.py: 100 * waves/SIMD + refill threshold
             case 808: RTO_F(8, 8);
             case 816: RTO_F(16, 8);
@@ -1423,21 +1421,21 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
     // (2.75 ms vs 2.92 for 16 idle lanes at 8 waves/SIMD; 4 to 8 waves/SIMD differ by < 2 % -- the
     // kernel is bound by the L1s, not by latency hiding -- and larger refill rounds waste fewer issue
     // slots on the partially filled ray set-up)
-    return launch_batch_impl<SPP, 32, 6>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, ev, stream);
+    return launch_batch_impl<SPP, 32, 6>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, occ, ev, stream);
 }
 
 hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
-                               int refill, hipEvent_t* ev, hipStream_t stream) {
+                               int refill, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
     switch (spp) {
-        case 1: return launch_batch_spp<1>(tree, opt, fb, jump, queue, hits, num_cus, refill, ev, stream);
-        case 2: return launch_batch_spp<2>(tree, opt, fb, jump, queue, hits, num_cus, refill, ev, stream);
-        case 3: return launch_batch_spp<3>(tree, opt, fb, jump, queue, hits, num_cus, refill, ev, stream);
-        case 4: return launch_batch_spp<4>(tree, opt, fb, jump, queue, hits, num_cus, refill, ev, stream);
-        case 6: return launch_batch_spp<6>(tree, opt, fb, jump, queue, hits, num_cus, refill, ev, stream);
-        case 8: return launch_batch_spp<8>(tree, opt, fb, jump, queue, hits, num_cus, refill, ev, stream);
-        case 16: return launch_batch_spp<16>(tree, opt, fb, jump, queue, hits, num_cus, refill, ev, stream);
-        case 32: return launch_batch_spp<32>(tree, opt, fb, jump, queue, hits, num_cus, refill, ev, stream);
+        case 1: return launch_batch_spp<1>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
+        case 2: return launch_batch_spp<2>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
+        case 3: return launch_batch_spp<3>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
+        case 4: return launch_batch_spp<4>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
+        case 6: return launch_batch_spp<6>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
+        case 8: return launch_batch_spp<8>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
+        case 16: return launch_batch_spp<16>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
+        case 32: return launch_batch_spp<32>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
         default: return hipErrorInvalidValue;
     }
 }

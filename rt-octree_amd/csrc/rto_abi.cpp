@@ -52,6 +52,17 @@ struct DeviceGuard {
     }
 };
 
+// The raw filtering entry points take device pointers only: launch on the device that owns the output
+// buffer (a process that drives several GPUs may have another one current).
+int device_of(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return a.device;
+}
+
 bool spp_supported(int spp) {  // volrend.cu:266-278
     return spp == 1 || spp == 2 || spp == 3 || spp == 4 || spp == 6 || spp == 8 || spp == 16 || spp == 32;
 }
@@ -79,7 +90,8 @@ struct rto_ctx {
     int frames = 1;  // frame slots (batched launches render slots 0..n-1)
     int sel = 0;     // slot the single-frame entry points and accessors refer to
     int num_cus = 256;
-    unsigned long long* queue = nullptr;  // persistent-kernel ray queue {next, waves_done}
+    unsigned long long* queue = nullptr;  // persistent-kernel ray queues (kQueueWords u64)
+    rto::OccupancyCache occ;              // of the persistent kernel instantiation last launched
     uint32_t* tile_order = nullptr;       // centre-out order of the 8x8 ray tiles (persistent kernel)
     uint32_t* wedge_order = nullptr;      // the same tiles grouped into 8 angular wedges (one ray queue per XCD)
     int wedge_start[rto::kMaxQueues + 1] = {0};
@@ -883,9 +895,38 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     if (o->enable_probe) return set_err(RTO_E_UNSUPPORTED, "enable_probe is a GUI feature, not on the headless path");
     if (tree->dev.format == RTO_FMT_SG || tree->dev.format == RTO_FMT_ASG)
         return set_err(RTO_E_UNSUPPORTED, "SG/ASG bases are untested upstream and not built");
-    if (!tree->fast_ok) return set_err(RTO_E_UNSUPPORTED, "the batched renderer needs an N == 2 tree of depth <= 24");
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");
+    if (!tree->fast_ok) {
+        // No traversal image (N != 2, depth > 24 or >= 2^27 leaf slots): the same frames, one launch of
+        // the generic kernel each -- same images, without the batching gain.
+        const rto::OptDev od = make_opt_dev(o);
+        const size_t px = frame_px(ctx);
+        for (int f = 0; f < n; ++f) {
+            if (cams[f].width != ctx->width || cams[f].height != ctx->height)
+                return set_err(RTO_E_INVALID, "camera size does not match the render context");
+            if (!(cams[f].fx != 0.f) || !(cams[f].fy != 0.f)) return set_err(RTO_E_INVALID, "camera focal length is zero");
+            rto::CamDev cd;
+            cd.width = cams[f].width;
+            cd.height = cams[f].height;
+            cd.fx = cams[f].fx;
+            cd.fy = cams[f].fy;
+            std::memcpy(cd.transform, cams[f].transform, sizeof(cd.transform));
+            const int64_t jumps = rng_jumps ? rng_jumps[f] : (int64_t)f;
+            const rto::PcgJumpEntry j = pcg_jump(ctx->rng.inc, (uint64_t)jumps << 32);
+            rto::Pcg32 rng = ctx->rng;
+            rng.state = j.mult * ctx->rng.state + j.plus;
+            const size_t slot = (size_t)(slot0 + f);
+            rto::FrameOut fo;
+            fo.aux = ctx->aux + slot * RTO_AUX_CHANNELS * px;
+            fo.image = (o->denoise ? ctx->noisy : ctx->image) + slot * 4 * px;
+            fo.stats = nullptr;
+            hipError_t e = rto::launch_render(RTO_KERNEL_GENERIC, o->spp, tree->dev, cd, od, rng, ctx->jump, fo,
+                                              ctx->strip_rows, (hipStream_t)stream_);
+            if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("render launch failed: ") + hipGetErrorString(e));
+        }
+        return RTO_OK;
+    }
     // the traversal kernel addresses the hand-off buffer with 32-bit offsets (frame * spp * pixels + pixel)
     if ((uint64_t)(slot0 + n) * (uint64_t)o->spp * (uint64_t)frame_px(ctx) > 0xffffffffULL)
         return set_err(RTO_E_UNSUPPORTED, "frames x spp x pixels exceeds 2^32 hit-list entries: render fewer frames per launch");
@@ -945,7 +986,7 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     if (ctx->kt_on && ctx->kt_count < kKtRing) ev = &ctx->kt_ev[(size_t)ctx->kt_count++ * 3];
     hipError_t e = rto::launch_render_batch(o->spp, tree->dev, od, fb, ctx->jump, ctx->queue,
                                             ctx->hits + (size_t)slot0 * o->spp * px,  // = fb.f[0].hits: the kernel indexes frames from here
-                                            ctx->num_cus, ctx->refill, ev, stream);
+                                            ctx->num_cus, ctx->refill, &ctx->occ, ev, stream);
     if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("batched render launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
 }
@@ -957,6 +998,10 @@ int rto_filtering_batch(void* stream, const float* weight_map, const float* guid
     if (L < 1 || L > 6)  // filtering.cu:362-366
         return set_err(RTO_E_INVALID, "Kernel size == " + std::to_string(L * 2 + 1) + " not supported.");
     if (img_in == img_out) return set_err(RTO_E_INVALID, "rto_filtering: img_in and img_out must differ");
+    const int pdev_ = device_of(img_out);
+    if (pdev_ < 0) return set_err(RTO_E_INVALID, "filtering: the output pointer is not device memory");
+    DeviceGuard guard(pdev_);
+    if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");
     hipError_t e = rto::launch_filter(weight_map, guidance_map, L, H, W, n, img_in, img_out, (hipStream_t)stream);
     if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("filter launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
@@ -970,6 +1015,10 @@ int rto_filtering_train_forward(void* stream, const float* weight_map, const flo
         return set_err(RTO_E_INVALID, "rto_filtering_train_forward: null pointer or bad size");
     if (L < 1 || L > 6) return set_err(RTO_E_INVALID, "Kernel size == " + std::to_string(L * 2 + 1) + " not supported.");
     if (img_in == img_out) return set_err(RTO_E_INVALID, "rto_filtering_train_forward: img_in and img_out must differ");
+    const int pdev_ = device_of(img_out);
+    if (pdev_ < 0) return set_err(RTO_E_INVALID, "filtering: the output pointer is not device memory");
+    DeviceGuard guard(pdev_);
+    if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");
     hipError_t e = rto::launch_filter_train(weight_map, guidance_map, L, H, W, n, img_in, img_out, rgb_filtered, max_map,
                                             inv_kernel_sum, (hipStream_t)stream);
     if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("filter launch failed: ") + hipGetErrorString(e));
@@ -984,6 +1033,10 @@ int rto_filtering_backward(void* stream, const float* grad_output, const float* 
         !grad_weight || !grad_guidance || H <= 0 || W <= 0 || n < 1)
         return set_err(RTO_E_INVALID, "rto_filtering_backward: null pointer or bad size");
     if (L < 1 || L > 6) return set_err(RTO_E_INVALID, "Kernel size == " + std::to_string(L * 2 + 1) + " not supported.");
+    const int pdev_ = device_of(grad_guidance);
+    if (pdev_ < 0) return set_err(RTO_E_INVALID, "filtering: the output pointer is not device memory");
+    DeviceGuard guard(pdev_);
+    if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");
     hipError_t e = rto::launch_filter_backward(grad_output, img_in, weight_map, guidance_map, rgb_filtered, max_map,
                                                inv_kernel_sum, L, H, W, n, grad_weight, grad_guidance, (hipStream_t)stream);
     if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("filter backward launch failed: ") + hipGetErrorString(e));

@@ -21,6 +21,18 @@ namespace {
 // rto_abi.cpp owns the thread-local error string; this translation unit reports through it
 extern "C" int rto_set_error_(int code, const char* msg);
 int fail(int code, const std::string& m) { return rto_set_error_(code, m.c_str()); }
+
+// the network's weights live on net->device: launch (and free) there, whatever device is current
+struct DeviceScope {
+    int prev = -1;
+    explicit DeviceScope(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceScope() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
 }  // namespace
 
 extern "C" {
@@ -73,6 +85,7 @@ int rto_guidance_net_forward(const rto_guidance_net* net, void* stream, const fl
                              float* weight_map, float* guidance_map) {
     if (!net || !aux || !weight_map || !guidance_map || n < 1 || H < 1 || W < 1)
         return fail(RTO_E_INVALID, "rto_guidance_net_forward: bad argument");
+    DeviceScope scope(net->device);
     const hipError_t e = rto::launch_guidance_net(aux, net->w1, net->b1, net->w2, net->b2, net->c1, net->levels, n, H, W,
                                                   weight_map, guidance_map, (hipStream_t)stream);
     if (e != hipSuccess) return fail(RTO_E_HIP, std::string("GuidanceNet launch failed: ") + hipGetErrorString(e));
@@ -81,6 +94,7 @@ int rto_guidance_net_forward(const rto_guidance_net* net, void* stream, const fl
 
 void rto_guidance_net_free(rto_guidance_net* net) {
     if (!net) return;
+    DeviceScope scope(net->device);
     if (net->w1) (void)hipFree(net->w1);
     if (net->w2) (void)hipFree(net->w2);
     if (net->b1) (void)hipFree(net->b1);

@@ -84,7 +84,7 @@ struct FrameDesc {
 };
 constexpr uint32_t kNoHit = 0xffffffffu;
 constexpr int kMaxQueues = 8;  // XCDs of an MI355X
-// ctx queue memory (u64 words): [1] waves that have left, [2..7] debug counters, [8 + 8k] next ray of queue k
+// ctx queue memory (u64 words): [2..7] debug counters, [8 + 8k] next ray of queue k
 constexpr int kQueueWords = 8 + 8 * kMaxQueues;
 struct FrameBatch {
     int n, width, height;

@@ -20,11 +20,19 @@ TileMap make_tile_map(int width, int height, int strip_rows);
 hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev& cam, const OptDev& opt,
                          const Pcg32& rng, const PcgJumpEntry* jump, const FrameOut& fo, int strip_rows, hipStream_t stream);
 
+// occupancy of the persistent kernel, cached per render context (which is per device and per thread): the
+// answer depends on the instantiation and on its dynamic LDS size (deeper trees need more)
+struct OccupancyCache {
+    const void* fn = nullptr;
+    size_t lds = 0;
+    int blocks_per_cu = 0;
+};
+
 // persistent batched renderer (N == 2 trees): fb.n frames in one launch (traversal kernel, then the
-// shading kernel); `queue` = 2 zeroed u64; ev = nullptr or 3 events recorded before / between / after
+// shading kernel); `queue` = kQueueWords u64 (zeroed on the stream before every launch); ev = nullptr or 3 events recorded before / between / after
 hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
-                               int refill, hipEvent_t* ev, hipStream_t stream);
+                               int refill, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream);
 
 // quant_map [nq][ns] + data_retained [nr][ns][3] -> slot-major records of `rec` u16 (TreeDev::qrec)
 hipError_t launch_pack_quant(const uint16_t* qmap, const uint16_t* retained, int64_t ns, int nr, int nq, int rec,

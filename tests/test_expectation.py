@@ -29,9 +29,14 @@ SUPPORTED_SPP = (1, 2, 3, 4, 6, 8, 16, 32)
 
 
 def _mean_of_frames(ht, cam, n_frames, spp, first_frame=0, **optkw):
+    """Independently SEEDED frames.  (The reference decorrelates frames by jumping the one pcg32 stream
+    2^32 draws ahead per frame; streams 2^32 apart share their low 32 state bits and are visibly
+    correlated in rare-event tails -- one 64x64 pixel showed 21 misses in 4096 samples where 6.6 are
+    expected, 5.6 sigma, and 6-7 with seeded streams -- so a statistical test must not use them.)"""
     acc = None
     for k in range(n_frames):
-        aux, _, _ = orc.render_frame(ht, cam, orc.default_options(spp=spp, **optkw), orc.rng(frame=first_frame + k))
+        aux, _, _ = orc.render_frame(ht, cam, orc.default_options(spp=spp, **optkw),
+                                     orc.rng(seed=977 + 7919 * (first_frame + k)))
         acc = aux[:4].astype(np.float64) if acc is None else acc + aux[:4]
     return acc / n_frames
 

@@ -105,6 +105,34 @@ def test_node_order_never_changes_pixels(small_tree_sh9):
     assert_bits_equal(ctx.download_aux(), aux_o, "batched aux")
 
 
+def test_batched_launch_on_a_tree_without_traversal_image():
+    """N = 3 (any tree the N == 2 traversal image cannot encode): rto_launch_renderer_batch renders the
+    same frames through per-frame launches of the generic kernel instead of refusing."""
+    rs = np.random.RandomState(9)
+    child = np.zeros((3, 3, 3, 3), np.int32)
+    child[0, 1, 1, 1] = 1  # node 1 = centre cell of the root
+    child[0, 2, 0, 1] = 2
+    data = np.zeros((3, 3, 3, 3, 4), np.float16)
+    data[..., :3] = rs.uniform(0, 1, (3, 3, 3, 3, 3))
+    data[..., 3] = rs.uniform(0, 12, (3, 3, 3, 3)) * (rs.uniform(size=(3, 3, 3, 3)) < 0.6)
+    t = synth.SynthTree(child, data, np.full(3, 1 / 3.0, np.float32), np.full(3, 0.5, np.float32), "RGBA", 2, {})
+    ht, dt = make_pair(t)
+    assert dt.N == 3
+    cams, ocams = [], []
+    for i in range(3):
+        ocam, cam = cameras(40, 32, POSES[i])
+        cams.append(cam)
+        ocams.append(ocam)
+    ctx = R.RenderContext(40, 32, frames=3)
+    R.launch_renderer_batch(dt, cams, R.RenderOptions(spp=4, denoise=False), ctx, rng_jumps=[2, 0, 5])
+    for i, j in enumerate([2, 0, 5]):
+        aux_o, rgba_o, _ = oracle_frame(ht, ocams[i], 4, frame=j)
+        ctx.select_frame(i)
+        assert_bits_equal(ctx.download_aux(), aux_o, "aux %d" % i)
+        assert_bits_equal(ctx.download_image(), rgba_o, "rgba %d" % i)
+    assert aux_o[3].max() > 0
+
+
 def test_camera_inside_box_and_miss(small_tree_sh9):
     """tmin clamps at 0 for a camera inside the volume; rays that miss return background
     (rt_core.cuh:219-222; SURVEY appendix B 3,4)."""

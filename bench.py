@@ -6,25 +6,32 @@
 A "step" is one frame of config C2: batched-regular-tracking render (800x800, SPP 6) + GuidanceNet
 (the compact network as one fused MFMA kernel; --torch-net runs it through PyTorch-ROCm/MIOpen) +
 guided filter, i.e. what one iteration of the reference's timed loop does
-(main_headless.cpp:485-543).  Frames are issued in groups of --batch poses (default 8): one launch
+(main_headless.cpp:485-543).  Frames are issued in groups of --batch poses (default 32): one launch
 of the persistent ray-queue traversal kernel + one shading launch, one batched GuidanceNet forward,
 one batched filter launch per group -- a frame alone cannot fill 256 CUs (DESIGN.md "Batching").
 Every image is bit-identical to rendering the poses one by one (tests/test_render_parity.py).
 
 Inputs are synthetic (no dataset exists on either machine): a seeded lego-like SH16 PlenOctree of
-~2.1 M nodes, a 200-pose blender orbit, GuidanceNet(8,32,5,2,4) with seeded default init folded to
-the compact fp16 network.  Everything is resident in HBM before the timed region.  Frames shard
-across ranks (pose i -> rank i mod N, RNG jump-ahead per pose so every image equals the 1-GPU run);
-no data-path collective exists or is invented -- the only collectives are the barrier and the
-max-reduction of the elapsed time.
+~2.1 M nodes, a 200-pose blender orbit, the GuidanceNet trained by tools/train_guidance.py.
+Everything is resident in HBM before the timed region.  Frames shard across ranks (pose i -> rank
+i mod N, RNG jump-ahead per pose so every image equals the 1-GPU run); no data-path collective exists
+or is invented -- the only collectives are the barrier and the max-reduction of the elapsed time.
+--scenes K (config C3): K different synthetic scenes; --scene-map pose (every rank holds every scene,
+frame g -> rank g mod N) or scene (scene s -> rank s mod N), or both.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- traversal kernel (render_persist): ALGORITHMIC bytes (SURVEY.md 8d formula; the
-                  units are counted by the single-frame kernel's counting instantiation in an
-                  untimed pass over the same frames) / average launch duration (HIP events on the
-                  launch stream, recorded around that kernel inside librto), against 8 TB/s HBM.
-  cpu_baseline -- the CPU oracle (oracle/, kind "port": the reference has no CPU renderer) on a
-                  bounded sample of the same frames, all host cores.
+Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
+  roofline       -- traversal kernel (render_persist).  `achieved` / `frac` = HBM bytes per launch from the
+                    rocprofv3 counter passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE, separate
+                    passes, this workload) / this run's average launch duration (HIP events on the launch
+                    stream, recorded around that kernel inside librto), against 8 TB/s.  The ALGORITHMIC
+                    figure of SURVEY.md 8d (a root-restart walk priced at 4 B per level, which the kernel
+                    does not perform) is kept as `algorithmic_gbps` / `algorithmic_frac`.  `tcp` relates the
+                    kernel's L1 line accesses to the gather ceilings measured by tools/probe_ceiling.py --
+                    the resource that actually bounds it.
+  reference_loop -- the reference's own loop shape: ONE frame per launch with a host synchronisation per
+                    frame (Timer::record, render_context.hpp:179-188), single-frame kernel.
+  cpu_baseline   -- the CPU oracle (oracle/, kind "port": the reference has no CPU renderer) on a
+                    bounded sample of the same frames, all host cores.
 """
 import argparse
 import hashlib
@@ -44,7 +51,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured fl
 WARM_FRAMES_REF = 100  # main_headless.cpp:469-479: 100 warm-up frames each advance the RNG
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
@@ -58,24 +65,47 @@ def parse_args():
     ap.add_argument("--basis", type=int, default=16, help="SH basis per channel (16 = the NeRF-synthetic PlenOctrees)")
     ap.add_argument("--depth", type=int, default=10)
     ap.add_argument("--shell", type=float, default=2.5)
+    ap.add_argument("--radius", type=float, default=1.5, help="scene half-extent in world units (invradius = 1/(2 radius))")
+    ap.add_argument("--fx", type=float, default=0.0, help="focal length in pixels (0 = the blender camera_angle_x of NeRF-synthetic; "
+                                                          "config C4 uses the TanksAndTemple intrinsics, 1160)")
+    ap.add_argument("--cam-radius", type=float, default=4.0311, help="radius of the camera orbit (world units)")
     ap.add_argument("--no-denoise", action="store_true", help="config C5: raw SPP render only")
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores)")
+    ap.add_argument("--ref-loop-frames", type=int, default=48,
+                    help="frames of the one-frame-per-launch pass reported as reference_loop (0 = skip)")
     ap.add_argument("--tree", default="", help="render this tree.npz instead of the synthetic one")
     ap.add_argument("--shuffle-nodes", type=int, default=0, metavar="SEED",
                     help="store the synthetic tree's nodes in a random order (seed > 0): svox-refined trees have no "
                          "ordering guarantee, make_tree's breadth-first order is the friendliest one; images are unchanged")
+    ap.add_argument("--scenes", type=int, default=1, help="config C3: number of different synthetic scenes (1..8)")
+    ap.add_argument("--scene-map", choices=("pose", "scene", "both"), default="pose",
+                    help="with --scenes: 'pose' = every rank holds all scenes, frame g -> rank g mod N; 'scene' = scene s -> "
+                         "rank s mod N; 'both' = time both, headline the pose mapping")
     ap.add_argument("--quant-direct", action="store_true",
                     help="with --tree <quantised tree.npz>: render from the codebooks instead of the expanded fp16 tree")
     ap.add_argument("--streams", type=int, default=1,
                     help="groups alternate over this many HIP streams (each with its own context): the tail of one "
                          "group's kernels overlaps the next group's; per-kernel durations then include the sharing")
     ap.add_argument("--torch-net", action="store_true", help="run GuidanceNet through PyTorch-ROCm (MIOpen) instead of the fused HIP kernel")
-    return ap.parse_args()
+    ap.add_argument("--c4", action="store_true", help="shorthand for configs[3]: " + " ".join(C4_ARGS))
+    ap.add_argument("--plan-only", action="store_true",
+                    help="no GPU work: join the process group (gloo), print every rank's frame plan as JSON and exit -- "
+                         "pins the rank / scene / pose / RNG-jump bookkeeping of a multi-GPU run on a CPU box")
+    ap.add_argument("--exact-filter", action="store_true",
+                    help="run the bit-exact guided filter (164 exps per pixel) instead of the factorised one")
+    args = ap.parse_args(argv)
+    if args.c4:
+        args = ap.parse_args((list(argv) if argv is not None else sys.argv[1:]) + C4_ARGS)
+    return args
 
 
-def tree_cache_path(args):
+def tree_cache_path(args, scene=0):
     key = "d%d_s%g_b%d" % (args.depth, args.shell, args.basis)
+    if args.radius != 1.5:
+        key += "_r%g" % args.radius
+    if scene:
+        key += "_scene%d" % scene
     if args.shuffle_nodes:
         key += "_shuf%d" % args.shuffle_nodes
     tag = hashlib.sha1(open(os.path.join(ROOT, "rt-octree_amd", "synth.py"), "rb").read()).hexdigest()[:10]
@@ -83,8 +113,87 @@ def tree_cache_path(args):
     return os.path.join(base, "rto_bench_tree_%s_%s.npz" % (key, tag))
 
 
+def workload_id(args, W, H):
+    """key into profiles/pmc_traffic.json: the BASELINE configurations the counter passes were taken on"""
+    if args.tree or args.shuffle_nodes or args.scenes != 1 or args.quant_direct or args.shell != 2.5:
+        return None
+    key = (W, H, args.spp, args.basis, args.depth, bool(args.no_denoise), args.radius, args.fx, args.cam_radius)
+    return {(800, 800, 6, 16, 10, False, 1.5, 0.0, 4.0311): "c2", (800, 800, 1, 16, 10, True, 1.5, 0.0, 4.0311): "c5",
+            (1920, 1080, 6, 25, 10, False, 1.12, 1160.0, 2.6): "c4"}.get(key)
+
+
+# BASELINE.json configs[3] (TanksAndTemple Truck 1920x1080 SPP 6 + denoise) as a synthetic stand-in: SH25, a tree
+# twice the size of C2's (smaller world radius = the model fills the volume), T&T intrinsics, a close orbit
+C4_ARGS = ["--width", "1920", "--height", "1080", "--basis", "25", "--depth", "10", "--radius", "1.12", "--fx", "1160",
+           "--cam-radius", "2.6"]
+
+
+def scenes_of_rank(rank, world, n_scenes, scene_map):
+    """scenes a rank must hold: all of them when frames are interleaved, its own share when scenes are dealt out"""
+    if n_scenes == 1 or scene_map == "pose":
+        return list(range(n_scenes))
+    return [s for s in range(n_scenes) if s % world == rank] or [rank % n_scenes]
+
+
+def pose_schedule(step, rank, world, n_poses, n_scenes, scene_map):
+    """(scene, pose) of this rank's `step`-th frame.
+    'pose': the global frame sequence g = 0, 1, 2, ... runs scene after scene (scene = (g // n_poses) mod
+            n_scenes, pose = g mod n_poses) and frame g belongs to rank g mod world (one scene: pose i -> rank i mod N);
+    'scene': rank r renders the scenes s with s mod world == r, one after the other, all poses each."""
+    if n_scenes > 1 and scene_map == "scene":
+        mine = scenes_of_rank(rank, world, n_scenes, scene_map)
+        return mine[(step // n_poses) % len(mine)], step % n_poses
+    g = step * world + rank
+    return (g // n_poses) % n_scenes, g % n_poses
+
+
+def plan_groups(n_frames, B, rank, world, n_poses, n_scenes, scene_map):
+    """a rank's frames 0..n_frames-1 cut into launch groups of <= B frames of one scene: [(scene, [poses])]"""
+    groups = []
+    s = 0
+    while s < n_frames:
+        sc, first = pose_schedule(s, rank, world, n_poses, n_scenes, scene_map)
+        idx = [first]
+        while len(idx) < B and s + len(idx) < n_frames:
+            sc2, p2 = pose_schedule(s + len(idx), rank, world, n_poses, n_scenes, scene_map)
+            if sc2 != sc:
+                break
+            idx.append(p2)
+        groups.append((sc, idx))
+        s += len(idx)
+    return groups
+
+
+def plan_only(args):
+    """--plan-only: what every rank WOULD render (no GPU): {"world", "plans": {map: [[(scene, [poses]) ...] per rank]},
+    "rng_jumps": the per-frame jump of pose i}; ranks exchange their plans over gloo."""
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    B = max(1, min(32, args.batch))
+    n_scenes = 1 if args.tree else max(1, min(8, args.scenes))
+    maps = ["pose", "scene"] if n_scenes > 1 else ["pose"]
+    mine = {m: plan_groups(args.steps, B, rank, world, 200, n_scenes, m) for m in maps}
+    plans = [mine]
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        plans = [None] * world
+        dist.all_gather_object(plans, mine)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"world": world, "steps": args.steps, "batch": B, "scenes": n_scenes,
+                          "plans": {m: [plans[r][m] for r in range(world)] for m in maps},
+                          "rng_jump_of_pose": "%d + pose" % WARM_FRAMES_REF}))
+
+
 def main():
     args = parse_args()
+    if args.plan_only:
+        return plan_only(args)
     import torch
     import torch.distributed as dist
 
@@ -120,23 +229,35 @@ def main():
     if args.width > 0 and args.height > 0:
         W, H = args.width, args.height
     B = max(1, min(32, args.batch))
+    n_scenes = 1 if args.tree else max(1, min(8, args.scenes))
+    maps = ["pose", "scene"] if (args.scene_map == "both" and n_scenes > 1) else [args.scene_map if args.scene_map != "both" else "pose"]
     tree_host = None
     if args.tree:
-        path = args.tree
+        paths = [args.tree]
     else:
-        path = tree_cache_path(args)
-        if rank == 0 and not os.path.exists(path):
-            t0 = time.time()
-            tree_host = synth.make_tree(depth_limit=args.depth, basis_dim=args.basis, shell=args.shell)
-            if args.shuffle_nodes:
-                tree_host = synth.shuffle_nodes(tree_host, args.shuffle_nodes)
-            tree_host.save_npz(path + ".tmp.npz")
-            os.replace(path + ".tmp.npz", path)
-            print("[bench] generated %s: %s in %.1fs" % (path, tree_host.stats, time.time() - t0), file=sys.stderr)
+        paths = [tree_cache_path(args, s) for s in range(n_scenes)]
+        for s, path in enumerate(paths):
+            # scene generation is spread over the ranks (rank r writes the scenes s with s mod world == r)
+            if s % world == rank and not os.path.exists(path):
+                t0 = time.time()
+                th = synth.make_tree(depth_limit=args.depth, basis_dim=args.basis, shell=args.shell, radius=args.radius,
+                                     sdf=synth.scene_variant(s), seed=20230418 + s)
+                if args.shuffle_nodes:
+                    th = synth.shuffle_nodes(th, args.shuffle_nodes)
+                tmp = "%s.tmp%d.npz" % (path, rank)
+                th.save_npz(tmp)
+                os.replace(tmp, path)
+                print("[bench] generated %s: %s in %.1fs" % (path, th.stats, time.time() - t0), file=sys.stderr)
+                if s == 0:
+                    tree_host = th
     barrier()
-    tree = R.N3Tree(path, device=local_rank, quant_direct=args.quant_direct)  # the reference's own input path: tree.npz -> device
-    poses = synth.orbit_poses(200)
-    fx = synth.blender_focal(W)
+    need = set()
+    for m in maps:
+        need |= set(scenes_of_rank(rank, world, n_scenes, m))
+    trees = {s: R.N3Tree(paths[s], device=local_rank, quant_direct=args.quant_direct) for s in sorted(need)}  # tree.npz -> device
+    tree = trees[min(trees)]
+    poses = synth.orbit_poses(200, radius=args.cam_radius)
+    fx = args.fx if args.fx > 0 else synth.blender_focal(W)
     cams = []
     for p in poses:
         c = R.Camera(W, H, fx, fx)
@@ -145,7 +266,8 @@ def main():
     ctx = R.RenderContext(W, H, device=local_rank, frames=B)
     denoise = not args.no_denoise
     opt = R.RenderOptions(spp=args.spp, denoise=denoise)
-    net = full = None
+    net = full = compact = None
+    trained = False
     if denoise:
         torch.manual_seed(0)
         full = denoiser.GuidanceNet(8, 32, 5, 2, 4)
@@ -162,8 +284,7 @@ def main():
         else:
             net = denoiser.FusedGuidanceNet(compact, device=local_rank)  # same weights, one HIP kernel
     stream = torch.cuda.current_stream(dev)
-    aux_v, noisy_v, image_v = ctx.batch_views()
-    aux_t = torch.as_tensor(aux_v, device=dev)  # zero-copy [B,8,H,W]
+    aux_t = torch.as_tensor(ctx.batch_views()[0], device=dev)  # zero-copy [B,8,H,W]
     # lane = (context, stream, network instance with its own output buffers, aux view)
     lanes = [(ctx, stream, net, aux_t)]
     for _ in range(1, max(1, args.streams)):
@@ -173,19 +294,22 @@ def main():
             n2 = compact.half().to(dev) if args.torch_net else denoiser.FusedGuidanceNet(compact, device=local_rank)
         lanes.append((c2, torch.cuda.Stream(dev), n2, torch.as_tensor(c2.batch_views()[0], device=dev)))
 
-    def pose_of(step):  # global frame index of this rank's `step`-th frame
-        return (step * world + rank) % len(poses)
+    filter_mode = R.FILTER_EXACT if args.exact_filter else R.FILTER_FAST
 
-    def group(first_step, n, ev, lane=0):
-        """n frames: traversal + shading, GuidanceNet, filter; all asynchronous on `stream`, no host
-        sync (the reference synchronises once per frame, render_context.hpp:179-188).  Frame i of the
-        reference run uses the RNG advanced (100 + i) times."""
-        idx = [pose_of(first_step + k) for k in range(n)]
+    def frame_of(step, scene_map):  # (scene, pose) of this rank's `step`-th frame
+        return pose_schedule(step, rank, world, len(poses), n_scenes, scene_map)
+
+    def group(scene, idx, ev, lane=0):
+        """The frames `idx` (poses of one scene): traversal + shading, GuidanceNet, filter; all asynchronous
+        on the lane's stream, no host sync (the reference synchronises once per frame,
+        render_context.hpp:179-188).  Frame i of the reference run uses the RNG advanced (100 + i) times
+        (SURVEY 8e)."""
+        n = len(idx)
         lctx, lstream, lnet, laux = lanes[lane]
         lctx.rng_seed()
         if ev:
             ev[0].record(lstream)
-        R.launch_renderer_batch(tree, [cams[i] for i in idx], opt, lctx, lstream,
+        R.launch_renderer_batch(trees[scene], [cams[i] for i in idx], opt, lctx, lstream,
                                 rng_jumps=[WARM_FRAMES_REF + i for i in idx])
         if ev:
             ev[1].record(lstream)
@@ -195,52 +319,94 @@ def main():
             if ev:
                 ev[2].record(lstream)
             lctx.select_frame(0)
-            R.filtering(lstream, wm, gm, lctx.noisy_ptr, lctx.image_ptr)
+            R.filtering(lstream, wm, gm, lctx.noisy_ptr, lctx.image_ptr, mode=filter_mode)
             if ev:
                 ev[3].record(lstream)
 
-    def run(n_frames, events):
-        s = 0
-        g = 0
-        while s < n_frames:
-            n = min(B, n_frames - s)
-            group(s, n, events[g] if events else None, g % len(lanes))
-            s += n
-            g += 1
+    def plan(n_frames, scene_map):
+        return plan_groups(n_frames, B, rank, world, len(poses), n_scenes, scene_map)
 
-    n_groups = (args.steps + B - 1) // B
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_groups)]
+    def timed(scene_map):
+        warm, work = plan(args.warmup, scene_map), plan(args.steps, scene_map)
+        events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in work]
+        for g, (sc, idx) in enumerate(warm):
+            group(sc, idx, None, g % len(lanes))
+        torch.cuda.synchronize(dev)
+        for lc, _, _, _ in lanes:
+            lc.kernel_timing(True)
+        barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for g, (sc, idx) in enumerate(work):
+            group(sc, idx, events[g], g % len(lanes))
+        torch.cuda.synchronize(dev)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        kts = [lc.kernel_timing_read() for lc, _, _, _ in lanes]
+        for lc, _, _, _ in lanes:
+            lc.kernel_timing(False)
+        n_launch = max(sum(k["launches"] for k in kts), 1)  # per-launch means, weighted over the lanes
+        kt = {"launches": sum(k["launches"] for k in kts),
+              "traverse_ms": sum(k["traverse_ms"] * k["launches"] for k in kts) / n_launch,
+              "shade_ms": sum(k["shade_ms"] * k["launches"] for k in kts) / n_launch}
+        # Timer::report formula (render_context.hpp:190-206), per frame, from the per-group event pairs
+        render_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
+        torch_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps if denoise else 0.0
+        filter_ms = sum(e[2].elapsed_time(e[3]) for e in events) / args.steps if denoise else 0.0
+        all_ms = render_ms + torch_ms + filter_ms
+        return elapsed, kt, {"render_ms": render_ms, "torch_ms": torch_ms, "filter_ms": filter_ms,
+                             "fps": 1000.0 / all_ms if all_ms > 0 else 0.0, "frames": args.steps}
 
-    # ---------------- warm-up + timed region ----------------
-    run(args.warmup, None)
-    torch.cuda.synchronize(dev)
-    for lc, _, _, _ in lanes:
-        lc.kernel_timing(True)
-    barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    run(args.steps, events)
-    torch.cuda.synchronize(dev)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kts = [lc.kernel_timing_read() for lc, _, _, _ in lanes]
-    for lc, _, _, _ in lanes:
-        lc.kernel_timing(False)
-    n_launch = max(sum(k["launches"] for k in kts), 1)  # per-launch means, weighted over the lanes
-    kt = {"launches": sum(k["launches"] for k in kts),
-          "traverse_ms": sum(k["traverse_ms"] * k["launches"] for k in kts) / n_launch,
-          "shade_ms": sum(k["shade_ms"] * k["launches"] for k in kts) / n_launch}
-    # Timer::report formula (render_context.hpp:190-206), per frame, from the per-group event pairs
-    render_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
-    torch_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps if denoise else 0.0
-    filter_ms = sum(e[2].elapsed_time(e[3]) for e in events) / args.steps if denoise else 0.0
-    all_ms = render_ms + torch_ms + filter_ms
-    tstats = {"render_ms": render_ms, "torch_ms": torch_ms, "filter_ms": filter_ms,
-              "fps": 1000.0 / all_ms if all_ms > 0 else 0.0, "frames": args.steps}
+    # ---------------- warm-up + timed region(s) ----------------
+    elapsed, kt, tstats = timed(maps[0])
+    alt = None
+    if len(maps) > 1:
+        e2, _, t2 = timed(maps[1])
+        alt = {"scene_map": maps[1], "value": args.steps * world / e2, "ms_per_step": e2 / args.steps * 1e3,
+               "reference_timer_fps": t2["fps"]}
+
+    # ---------------- untimed: the reference's loop shape (one frame per launch, sync per frame) ----------------
+    ref_loop = None
+    if args.ref_loop_frames > 0 and not args.quant_direct:
+        nf = args.ref_loop_frames
+        one = R.RenderContext(W, H, device=local_rank, frames=1)
+        one_aux = torch.as_tensor(one.batch_views()[0], device=dev)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        sums = [0.0, 0.0, 0.0]
+        t_wall = 0.0
+        for k in range(-8, nf):  # 8 untimed warm-up frames
+            sc, i = frame_of(max(k, 0), maps[0])
+            t1 = time.perf_counter()
+            one.rng_seed()
+            one.rng_advance((WARM_FRAMES_REF + i) << 32)
+            evs[0].record(stream)
+            R.launch_renderer(trees[sc], cams[i], opt, one, stream)
+            evs[1].record(stream)
+            if denoise:
+                with torch.no_grad():
+                    wm, gm = net(one_aux[:1], stream=stream) if not args.torch_net else net(one_aux[:1])
+                evs[2].record(stream)
+                one.select_frame(0)
+                R.filtering(stream, wm, gm, one.noisy_ptr, one.image_ptr, mode=filter_mode)
+                evs[3].record(stream)
+            (evs[3] if denoise else evs[1]).synchronize()  # Timer::record: the host waits for every frame
+            if k >= 0:
+                t_wall += time.perf_counter() - t1
+                sums[0] += evs[0].elapsed_time(evs[1])
+                if denoise:
+                    sums[1] += evs[1].elapsed_time(evs[2])
+                    sums[2] += evs[2].elapsed_time(evs[3])
+        tot = sum(sums)
+        ref_loop = {"batch": 1, "frames": nf, "fps": 1000.0 * nf / tot if tot > 0 else 0.0,
+                    "render_ms": sums[0] / nf, "torch_ms": sums[1] / nf, "filter_ms": sums[2] / nf,
+                    "wall_fps": nf / t_wall if t_wall > 0 else 0.0,
+                    "note": "one rto_launch_renderer (single-frame kernel) + GuidanceNet + filter per frame, host waits for each "
+                            "frame like Timer::record (render_context.hpp:179-188); fps = 1000 / (render + torch + filter)"}
+        one.free()
 
     # ---------------- untimed: work units of the same frames -> algorithmic bytes ----------------
     ctx.select_frame(0)
@@ -248,35 +414,60 @@ def main():
     ctx.enable_stats(True)
     ctx.get_stats(reset=True)
     opt_nd = R.RenderOptions(spp=args.spp, denoise=False)
-    # the counting kernel shades from dense records: a codebook-direct tree is counted on its
-    # expanded twin (same traversal, same hits)
-    count_tree = R.N3Tree(path, device=local_rank) if args.quant_direct else tree
-    for s in range(args.steps):  # same poses, same RNG bases as the timed frames
-        i = pose_of(s)
+    count_steps = min(args.steps, 64)  # per-frame means need no more
+    for s in range(count_steps):  # same poses, same RNG bases as the timed frames
+        sc, i = frame_of(s, maps[0])
+        # the counting kernel shades from dense records: a codebook-direct tree is counted on its
+        # expanded twin (same traversal, same hits)
+        count_tree = R.N3Tree(paths[sc], device=local_rank) if args.quant_direct else trees[sc]
         ctx.rng_seed()
         ctx.rng_advance((WARM_FRAMES_REF + i) << 32)
         R.launch_renderer(count_tree, cams[i], opt_nd, ctx, stream)
+        if args.quant_direct:
+            torch.cuda.synchronize(dev)
+            count_tree.free()
     units = ctx.get_stats(reset=True)
     ctx.enable_stats(False)
-    if count_tree is not tree:
-        count_tree.free()
     px = W * H
     alg_bytes_frame = (4 * units["levels"] + 2 * units["steps"] + 2 * (tree.data_dim - 1) * units["hit_leaves"]
-                       + 48 * px * args.steps) / args.steps
+                       + 48 * px * count_steps) / count_steps
     frames_per_launch = args.steps / max(kt["launches"], 1)
     alg_bytes_launch = alg_bytes_frame * frames_per_launch
-    achieved = alg_bytes_launch / (kt["traverse_ms"] * 1e-3) / 1e9 if kt["traverse_ms"] > 0 else 0.0
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    # the committed counter passes were taken on the default workload only
-    default_workload = (not args.tree and W == 800 and H == 800 and args.spp == 6 and args.basis == 16 and args.depth == 10
-                        and args.shell == 2.5)
-    if os.path.exists(pmc) and default_workload:
+    t_launch = kt["traverse_ms"] * 1e-3
+    alg_gbps = alg_bytes_launch / t_launch / 1e9 if t_launch > 0 else 0.0
+
+    # counter passes of THIS workload committed under profiles/ (tools/profile_round.sh); bytes and L1 line
+    # accesses scale with the frames of a launch
+    traffic = tcp = traffic_src = None
+    wid = workload_id(args, W, H)
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if wid and os.path.exists(pmc_path):
         try:
-            pj = json.load(open(pmc))  # measured at pj["frames_per_launch"] frames per launch: per-frame bytes scale
-            traffic = pj.get("hbm_bytes_per_launch") * frames_per_launch / float(pj.get("frames_per_launch", frames_per_launch))
-        except Exception:
-            traffic = None
+            doc = json.load(open(pmc_path))
+            pj = doc.get("workloads", {}).get(wid)
+            if pj:
+                scale = frames_per_launch / float(pj["frames_per_launch"])
+                traffic = (pj["fetch_bytes"] + pj["write_bytes"]) * scale
+                traffic_src = pj.get("source")
+                ce = doc.get("ceilings")
+                if pj.get("tcp_line_accesses") and ce:
+                    cus = float(pj.get("cus", 256))
+                    clk = pj["kernel_clocks"]  # shader clocks of the profiled launch (GRBM_GUI_ACTIVE / XCDs)
+                    lines = pj["tcp_line_accesses"] / cus
+                    l1_miss = pj["tcp_tcc_read_req"] / cus
+                    l2_miss = l1_miss * pj["tcc_miss"] / max(pj["tcc_hit"] + pj["tcc_miss"], 1)
+                    model_clk = ((lines - l1_miss) / ce["l1_hit_lines_per_clk"] + (l1_miss - l2_miss) / ce["l2_lines_per_clk"]
+                                 + l2_miss / ce["mall_lines_per_clk"])
+                    tcp = {"line_accesses_per_clk_per_cu": lines / clk, "l1_hit_rate": 1.0 - l1_miss / lines,
+                           "l2_hit_rate": 1.0 - l2_miss / max(l1_miss, 1.0),
+                           "ceilings_lines_per_clk_per_cu": ce, "frac": model_clk / clk,
+                           "note": "frac = (L1-hit lines / ceiling + L2-served lines / ceiling + lines from beyond L2 / ceiling) / "
+                                   "kernel clocks: the share of the kernel the L1s need for its gathers at the rates "
+                                   "tools/probe_ceiling.py measured for scattered dword loads (profiles/r2_probe_ceiling.json)"}
+        except Exception as e:  # a malformed profile must not break the bench line
+            print("[bench] ignoring %s: %r" % (pmc_path, e), file=sys.stderr)
+            traffic = tcp = None
+    achieved = traffic / t_launch / 1e9 if (traffic and t_launch > 0) else None
 
     if rank != 0:
         if world > 1:
@@ -307,7 +498,7 @@ def main():
     if world == 1 and args.cpu_frames > 0:
         import orc
         if tree_host is None:
-            z = np.load(path)
+            z = np.load(paths[0])
             child, data, scale, offset = z["child"], z["data"], z["invradius3"], z["offset"]
             fmt = str(z["data_format"])
         else:
@@ -320,7 +511,7 @@ def main():
         t_render = t_net = t_filter = 0.0
         cpu_steps = 0
         for s in range(args.cpu_frames):
-            i = pose_of(s)
+            i = s % len(poses)  # scene 0, poses 0, 1, ...
             ocam = orc.camera(W, H, fx, fx, np.ascontiguousarray(poses[i][:3, :4].T, np.float32).reshape(-1))
             base = orc.rng(frame=WARM_FRAMES_REF + i)
             t1 = time.perf_counter()
@@ -354,9 +545,8 @@ def main():
         ctx.set_kernel(R.KERNEL_FAST)
         acc = np.zeros((H, W, 4), np.float64)
         ref_opt = R.RenderOptions(spp=32, denoise=False)
-        for k in range(args.psnr_frames):  # independent RNG jumps far away from the timed frames
-            ctx.rng_seed()
-            ctx.rng_advance((100000 + k) << 32)
+        for k in range(args.psnr_frames):  # independently SEEDED frames (2^32-strided pcg32 streams are correlated)
+            ctx.rng_seed(977 + 7919 * k)
             R.launch_renderer(tree, cams[0], ref_opt, ctx, stream)
             acc += ctx.download_image()
         ref_img = (acc / args.psnr_frames).astype(np.float32)
@@ -368,14 +558,41 @@ def main():
         if denoise:
             with torch.no_grad():
                 wm, gm = net(aux_t[:1])
-            R.filtering(stream, wm, gm, ctx.noisy_ptr, ctx.image_ptr)
-            psnr["denoised_db"] = _psnr(ctx.download_image(), ref_img)
+            R.filtering(stream, wm, gm, ctx.noisy_ptr, ctx.image_ptr, mode=R.FILTER_EXACT)
+            exact = ctx.download_image()
+            psnr["denoised_db"] = _psnr(exact, ref_img)
+            R.filtering(stream, wm, gm, ctx.noisy_ptr, ctx.image_ptr, mode=R.FILTER_FAST)
+            fast = ctx.download_image()
+            psnr["denoised_factorised_filter_db"] = _psnr(fast, ref_img)
+            psnr["factorised_vs_exact_filter_db"] = _psnr(fast, exact)
             psnr["note"] = ("GuidanceNet trained by tools/train_guidance.py on this synthetic scene (pose 0 held out); "
                             "no ts_*.ts of the reference exists offline" if trained else
                             "GuidanceNet has seeded RANDOM weights: the denoised figure shows the pipeline runs, not denoiser quality")
-        psnr["hip_vs_cpu_oracle"] = "bit-exact (tests/test_render_parity.py), PSNR = inf"
+        psnr["hip_vs_cpu_oracle"] = ("traversal / shading / exact filter: bit-exact against this repository's CPU oracle "
+                                     "(tests/), whose estimator semantics are pinned by tests/test_expectation.py; NOT a "
+                                     "comparison with frames of the CUDA reference (none exist offline)")
 
     total_frames = args.steps * world
+    use = achieved if achieved is not None else alg_gbps
+    roof = {
+        "kernel": "render_persist<%d>" % args.spp, "bound": "hbm",
+        "achieved": use, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": use / HBM_PEAK_GBS,
+        "basis": ("counters: FETCH_SIZE + WRITE_SIZE of this workload (profiles/pmc_traffic.json) / this run's launch duration"
+                  if achieved is not None else
+                  "ALGORITHMIC bytes (no counter pass is committed for this workload): see algorithmic_note"),
+        "traffic": traffic, "traffic_source": traffic_src,
+        "algorithmic_bytes_per_launch": alg_bytes_launch, "algorithmic_gbps": alg_gbps,
+        "algorithmic_frac": alg_gbps / HBM_PEAK_GBS,
+        "algorithmic_note": "SURVEY 8d formula: 4 B per level of a root-restart walk + 2 B per step + SH record per hit leaf + 48 B per "
+                            "pixel; the kernel skips most of those levels (top grid, ancestor stack) and the rest is mostly served by "
+                            "L1/L2, so this is NOT bandwidth and may exceed the peak",
+        "avg_launch_ms": kt["traverse_ms"],
+        "measured_copy_bw": copy_gbps,
+        "launches": kt["launches"], "frames_per_launch": frames_per_launch,
+        "shade_kernel_avg_launch_ms": kt["shade_ms"],
+        "units_per_frame": {k: v / count_steps for k, v in units.items()},
+        "tcp": tcp,
+    }
     out = {
         "metric": "FPS @ 800x800 (Lego SPP=6) + PSNR vs ref; 1/2/4/8 GPU scaling",
         "value": total_frames / elapsed,
@@ -390,24 +607,23 @@ def main():
         "dtype": "f32" if not denoise else "f32 (traversal, filter) + f16 x f16 -> f32 (GuidanceNet conv, %s)" % ("MIOpen" if args.torch_net else "fused MFMA kernel"),
         "data": "synthetic",
         "config": {
-            "workload": "configs[1]: lego-like synthetic PlenOctree %s (%d nodes, depth %d), %dx%d SPP=%d%s, 1 frame per step issued in groups of %d, frames sharded pose i -> rank i mod N"
-                        % (tree.data_format, tree.capacity, tree.max_depth, W, H, args.spp,
-                           " + GuidanceNet(8,32,5,2,4) denoise" if denoise else " raw (no denoise)", B),
+            "workload": "configs[%s]: %slego-like synthetic PlenOctree %s (%d nodes, depth %d), %dx%d SPP=%d%s, 1 frame per step issued in groups of <= %d, frames sharded %s"
+                        % ({"c2": "1", "c4": "3 stand-in", "c5": "4"}.get(wid, "2" if n_scenes > 1 else "1-like"),
+                           ("%d scenes, " % n_scenes) if n_scenes > 1 else "",
+                           tree.data_format, tree.capacity, tree.max_depth, W, H, args.spp,
+                           " + GuidanceNet(8,32,5,2,4) denoise" if denoise else " raw (no denoise)", B,
+                           "scene s -> rank s mod N" if (maps[0] == "scene" and n_scenes > 1) else "frame g -> rank g mod N"),
             "tree_nodes": int(tree.capacity), "tree_device_mb": tree.device_bytes / 1e6,
-            "frames_per_launch": B, "streams": len(lanes), "parallelism": "frames x%d" % world,
+            "frames_per_launch": frames_per_launch, "frames_per_launch_cap": B, "streams": len(lanes),
+            "scenes": n_scenes, "scene_map": maps[0], "filter": "exact" if args.exact_filter else "factorised",
+            "parallelism": "frames x%d" % world,
         },
         "reference_timer": {  # Timer::report formula (render_context.hpp:190-206), rank 0, per frame
             "render_ms": tstats["render_ms"], "torch_ms": tstats["torch_ms"], "filter_ms": tstats["filter_ms"],
             "fps": tstats["fps"], "frames": tstats["frames"]},
-        "roofline": {
-            "kernel": "render_persist<%d>" % args.spp, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": kt["traverse_ms"],
-            "measured_copy_bw": copy_gbps, "frac_of_measured_copy": (achieved / copy_gbps) if copy_gbps else None,
-            "launches": kt["launches"], "frames_per_launch": frames_per_launch,
-            "shade_kernel_avg_launch_ms": kt["shade_ms"],
-            "units_per_frame": {k: v / args.steps for k, v in units.items()},
-        },
+        "reference_loop": ref_loop,
+        "alt_scene_map": alt,
+        "roofline": roof,
         "psnr": psnr,
         "cpu_baseline": cpu,
     }

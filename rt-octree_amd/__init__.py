@@ -7,11 +7,11 @@ The directory name carries a hyphen (it is the name the build contract asks for)
 from ._lib import LIB_PATH, RtoError, build_library, lib  # noqa: F401
 from .volrend import (  # noqa: F401
     Camera, N3Tree, RenderContext, RenderOptions, Timer, launch_renderer, launch_renderer_batch, filtering,
-    SUPPORTED_SPP, KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST,
+    SUPPORTED_SPP, KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST, FILTER_EXACT, FILTER_FAST,
 )
 
 __all__ = [
     "LIB_PATH", "RtoError", "build_library", "lib", "Camera", "N3Tree", "RenderContext",
     "RenderOptions", "Timer", "launch_renderer", "launch_renderer_batch", "filtering", "SUPPORTED_SPP",
-    "KERNEL_AUTO", "KERNEL_GENERIC", "KERNEL_FAST",
+    "KERNEL_AUTO", "KERNEL_GENERIC", "KERNEL_FAST", "FILTER_EXACT", "FILTER_FAST",
 ]

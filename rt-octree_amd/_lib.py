@@ -86,6 +86,7 @@ SYMBOLS = {
     "rto_launch_renderer": (C.c_int, [_P, C.POINTER(CCamera), C.POINTER(COptions), _P, _P]),
     "rto_launch_renderer_batch": (C.c_int, [_P, C.POINTER(CCamera), C.POINTER(C.c_int64), C.c_int, C.POINTER(COptions), _P, _P]),
     "rto_filtering_batch": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rto_filtering_batch_mode": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int]),
     "rto_filtering_train_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "rto_filtering_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rto_filtering": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),

@@ -47,7 +47,7 @@ struct Args {
 const std::map<std::string, std::string> kShort = {{"w", "width"},      {"h", "height"},     {"s", "step_size"},
                                                    {"e", "stop_thresh"}, {"a", "sigma_thresh"}, {"o", "write_images"},
                                                    {"i", "intrin"},      {"r", "reverse_yz"}};
-const char* kFlags[] = {"reverse_yz", "write_buffer", "help", "print_poses", "quant_direct", "torch_net"};
+const char* kFlags[] = {"reverse_yz", "write_buffer", "help", "print_poses", "quant_direct", "torch_net", "fast_filter"};
 
 bool is_flag(const std::string& k) {
     for (const char* f : kFlags)
@@ -111,6 +111,8 @@ void usage() {
         "  --batch B          poses per launch (1..32, default 32; 1 = one launch per frame like the reference's loop)\n"
         "  --torch_net        run the TorchScript GuidanceNet through libtorch even when it is the compact two-layer\n"
         "                     network the fused HIP kernel implements (default: fused)\n"
+        "  --fast_filter      guided filter with factorised exponentials (4 exps per pixel instead of 164; agrees with\n"
+        "                     the default, bit-exact form to ~1e-6 relative)\n"
         "  --quant_direct     render a quantised tree.npz from its codebooks (no expansion to dense fp16)\n"
         "  --print_poses      parse the poses, print them (column-major 4x3) and exit\n");
 }
@@ -218,6 +220,7 @@ int main(int argc, char** argv) {
     }
 
     int batch = std::max(1, std::min(32, std::atoi(args.get("batch", "32").c_str())));
+    const int filter_mode = args.has("fast_filter") ? RTO_FILTER_FACTORISED : RTO_FILTER_EXACT;
     {  // no more frame slots than this process has poses to render
         const size_t n_mine = (ps.trans.size() + (size_t)shard_n - 1 - (size_t)shard_i) / (size_t)shard_n;
         if ((size_t)batch > n_mine) batch = (int)std::max<size_t>(1, n_mine);
@@ -254,7 +257,7 @@ int main(int argc, char** argv) {
         denoiser->forward(rto_ctx_aux(ctx), 1, height, width, &w, &g, &L);
         rto_timer_stop(ctx, RTO_T_TORCH);
         rto_timer_start(ctx, RTO_T_FILTER);
-        const int rc = rto_ctx_filtering(ctx, stream, w, g, L);
+        const int rc = rto_filtering_batch_mode(stream, w, g, L, height, width, 1, rto_ctx_noisy(ctx), rto_ctx_image(ctx), filter_mode);
         rto_timer_stop(ctx, RTO_T_FILTER);
         return rc;
     };
@@ -279,7 +282,7 @@ int main(int argc, char** argv) {
                 const float *w = nullptr, *g = nullptr;
                 int L = 0;
                 denoiser->forward(rto_ctx_aux(ctx), n, height, width, &w, &g, &L);
-                CHECK_RTO(rto_filtering_batch(stream, w, g, L, height, width, n, rto_ctx_noisy(ctx), rto_ctx_image(ctx)));
+                CHECK_RTO(rto_filtering_batch_mode(stream, w, g, L, height, width, n, rto_ctx_noisy(ctx), rto_ctx_image(ctx), filter_mode));
             }
         }
     }
@@ -318,7 +321,7 @@ int main(int argc, char** argv) {
                 denoiser->forward(rto_ctx_aux(ctx), n, height, width, &w, &gd, &L);
                 rto_timer_stop(ctx, RTO_T_TORCH);
                 rto_timer_start(ctx, RTO_T_FILTER);
-                CHECK_RTO(rto_filtering_batch(stream, w, gd, L, height, width, n, rto_ctx_noisy(ctx), rto_ctx_image(ctx)));
+                CHECK_RTO(rto_filtering_batch_mode(stream, w, gd, L, height, width, n, rto_ctx_noisy(ctx), rto_ctx_image(ctx), filter_mode));
                 rto_timer_stop(ctx, RTO_T_FILTER);
             }
             CHECK_RTO(rto_timer_record(ctx, options.denoise));

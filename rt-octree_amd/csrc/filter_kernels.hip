@@ -254,6 +254,213 @@ __global__ void __launch_bounds__(256, 2) filter_backward(const float4* __restri
     }
 }
 
+
+// ------------------------------------------------------------------ factorised forward (tolerance path)
+// filter_fast<L>: the same filter with the exponentials factorised.  For a pixel p and level l
+//     out_l(p) = w_l(p) * sum_q e^{g(q) - m_p} rgb(q) / sum_q e^{g(q) - m_p}
+// and the factor e^{-m_p} cancels: any constant c common to the window gives the same quotient.  With
+// c_l = the maximum of g_l over the workgroup's staged tile, E_l(q) = e^{g_l(q) - c_l} is computed ONCE per
+// staged pixel (not once per tap: 4 exps per pixel instead of 164 at L = 4) and the level becomes a box
+// filter of P_l = {E r, E g, E b, E}:  out_l(p) = w_l(p) * box(P_l).rgb / box(P_l).w.  Each thread owns 4
+// vertically adjacent pixels, so a window row's sum (2S+1 LDS reads) is shared by up to 4 outputs:
+// 59 16-byte LDS reads per pixel instead of 164 + 164, and two packed adds per read instead of an exp and
+// two packed FMAs.  Not bit-identical to filter_fused (products are rounded before they are summed, the sums
+// run in another order, v_exp_f32 replaces the polynomial): relative differences of ~1e-6, > 120 dB
+// between the two routes -- the north-star's tolerance for float paths is 1e-4 dB.  filter_fused stays the
+// bit-exact route (tests, CLI default) and the training forward.
+// Guard: E must not underflow inside a window.  GuidanceNet ends in ReLU6, so g lies in [0, 6]; for
+// arbitrary maps a tile whose in-image range of g_l exceeds 80 takes the per-pixel-maximum route below
+// (workgroup-uniform branch, taps read from global memory: slow, correct).
+constexpr int kFastW = 32, kFastH = 32, kFastRows = 4;  // outputs per workgroup; rows per thread
+
+template <int S, int SW>
+RTO_DEV void box_rows(const float4* __restrict__ s_p, int base, float4 (&acc)[kFastRows]) {
+    // rows j = 0 .. 2S + kFastRows - 1 of the window stack of this thread's kFastRows outputs; output o
+    // takes rows o .. o + 2S
+#pragma unroll
+    for (int o = 0; o < kFastRows; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 2 * S + kFastRows; ++j) {
+        const float4* row = s_p + base + (j - S) * SW;
+        float2v rg = {0.f, 0.f}, bs = {0.f, 0.f};
+#pragma unroll
+        for (int dx = -S; dx <= S; ++dx) {
+            const float4 t = row[dx];
+            rg += float2v{t.x, t.y};
+            bs += float2v{t.z, t.w};
+        }
+#pragma unroll
+        for (int o = 0; o < kFastRows; ++o) {
+            if (j - o >= 0 && j - o <= 2 * S) {
+                acc[o].x += rg.x;
+                acc[o].y += rg.y;
+                acc[o].z += bs.x;
+                acc[o].w += bs.y;
+            }
+        }
+    }
+}
+
+// a level of filter_fast for a tile whose guidance range would underflow the factorised exponentials:
+// per-pixel maximum as in the exact form, taps from global memory (rare, slow, correct)
+__device__ __noinline__ float4 filter_level_wide(const float* __restrict__ g, const float4* __restrict__ img_in, int S, int H,
+                                                 int W, int px, int py, float w) {
+    if (px >= W || py >= H) return make_float4(0.f, 0.f, 0.f, 0.f);
+    float m = -3.402823466e+38f;
+    for (int dy = -S; dy <= S; ++dy)
+        for (int dx = -S; dx <= S; ++dx) {
+            const int qx = px + dx, qy = py + dy;
+            if (qx >= 0 && qx < W && qy >= 0 && qy < H) m = fmaxf(m, g[(int64_t)qy * W + qx]);
+        }
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, ks = 0.f;
+    for (int dy = -S; dy <= S; ++dy)
+        for (int dx = -S; dx <= S; ++dx) {
+            const int qx = px + dx, qy = py + dy;
+            if (qx >= 0 && qx < W && qy >= 0 && qy < H) {
+                const int64_t qi = (int64_t)qy * W + qx;
+                const float k = __builtin_amdgcn_exp2f((g[qi] - m) * 1.44269504088896340736f);
+                const float4 t = img_in[qi];
+                a0 += k * t.x;
+                a1 += k * t.y;
+                a2 += k * t.z;
+                ks += k;
+            }
+        }
+    const float ww = w / ks;
+    return make_float4(a0 * ww, a1 * ww, a2 * ww, 0.f);
+}
+
+template <int L>
+__global__ void __launch_bounds__(256, 3) filter_fast(const float* __restrict__ weight,    // [n][L][H][W]
+                                                     const float* __restrict__ guidance,  // [n][L][H][W]
+                                                     const float4* __restrict__ img_in,   // [n][H][W]
+                                                     float4* __restrict__ img_out,        // [n][H][W]
+                                                     int H, int W) {
+    constexpr int SW = kFastW + 2 * L, SH = kFastH + 2 * L, NE = SW * SH;
+    constexpr int PER = (NE + 255) / 256;  // staged elements per thread
+    extern __shared__ float4 s_dyn[];
+    float4* s_rgb = s_dyn;       // [SH][SW] noisy tile, 0 outside the image
+    float4* s_p = s_dyn + NE;    // [SH][SW] P_l of the current level
+    __shared__ float s_red[2][4];
+
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * kFastW - L, y0 = blockIdx.y * kFastH - L;
+    const int64_t HW = (int64_t)H * W;
+    weight += (int64_t)blockIdx.z * L * HW;
+    guidance += (int64_t)blockIdx.z * L * HW;
+    img_in += (int64_t)blockIdx.z * HW;
+    img_out += (int64_t)blockIdx.z * HW;
+
+    // staged element e of this thread -> global index (or -1 outside the image)
+    int gidx[PER];  // (a frame has < 2^31 pixels: rto_ctx_create refuses more)
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = tid + i * 256;
+        const int ty = e / SW, tx = e - ty * SW;
+        const int gx = x0 + tx, gy = y0 + ty;
+        const bool in = e < NE && gx >= 0 && gx < W && gy >= 0 && gy < H;
+        gidx[i] = in ? gy * W + gx : -1;
+        if (e < NE) s_rgb[e] = in ? img_in[gidx[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    const int lx = tid & (kFastW - 1), ry = tid / kFastW;  // column, row group
+    const int px = blockIdx.x * kFastW + lx, py0 = blockIdx.y * kFastH + ry * kFastRows;
+    const int base = (ry * kFastRows + L) * SW + lx + L;     // staged index of this thread's first output
+    float o[kFastRows][3];
+#pragma unroll
+    for (int r = 0; r < kFastRows; ++r) o[r][0] = o[r][1] = o[r][2] = 0.f;
+
+    auto level = [&](auto l_tag) {
+        constexpr int l = decltype(l_tag)::value;
+        // ---- tile maximum / minimum of g_l over the image pixels of the staged tile
+        float gv[PER];
+        float mx = -3.402823466e+38f, mn = 3.402823466e+38f;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            gv[i] = gidx[i] >= 0 ? guidance[l * HW + gidx[i]] : 0.f;
+            if (gidx[i] >= 0) {
+                mx = fmaxf(mx, gv[i]);
+                mn = fminf(mn, gv[i]);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+            mn = fminf(mn, __shfl_xor(mn, d, 64));
+        }
+        if ((tid & 63) == 0) {
+            s_red[0][tid >> 6] = mx;
+            s_red[1][tid >> 6] = mn;
+        }
+        __syncthreads();  // also: the previous level's box reads of s_p are done
+        const float c = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
+        const float lo = fminf(fminf(s_red[1][0], s_red[1][1]), fminf(s_red[1][2], s_red[1][3]));
+        const bool wide = !(c - lo <= 80.f);  // workgroup-uniform (NaNs take the slow route too)
+        if (!wide) {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int e = tid + i * 256;
+                if (e < NE) {
+                    const float E = gidx[i] >= 0 ? __builtin_amdgcn_exp2f((gv[i] - c) * 1.44269504088896340736f) : 0.f;
+                    const float4 t = s_rgb[e];
+                    s_p[e] = make_float4(E * t.x, E * t.y, E * t.z, E);
+                }
+            }
+        }
+        __syncthreads();  // P_l complete (and s_red may be rewritten)
+        float wl[kFastRows];
+#pragma unroll
+        for (int r = 0; r < kFastRows; ++r)
+            wl[r] = (px < W && py0 + r < H) ? weight[l * HW + (int64_t)(py0 + r) * W + px] : 0.f;
+        if (!wide) {
+            float4 acc[kFastRows];
+            box_rows<l + 1, SW>(s_p, base, acc);  // support S = l + 1
+#pragma unroll
+            for (int r = 0; r < kFastRows; ++r) {
+                const float ww = wl[r] / acc[r].w;
+                o[r][0] += acc[r].x * ww;
+                o[r][1] += acc[r].y * ww;
+                o[r][2] += acc[r].z * ww;
+            }
+        } else {  // per-pixel maximum, taps from global memory
+#pragma unroll
+            for (int r = 0; r < kFastRows; ++r) {
+                const float4 c4 = filter_level_wide(guidance + l * HW, img_in, l + 1, H, W, px, py0 + r, wl[r]);
+                o[r][0] += c4.x;
+                o[r][1] += c4.y;
+                o[r][2] += c4.z;
+            }
+        }
+    };
+    level(std::integral_constant<int, 0>{});
+    if constexpr (L >= 2) level(std::integral_constant<int, 1>{});
+    if constexpr (L >= 3) level(std::integral_constant<int, 2>{});
+    if constexpr (L >= 4) level(std::integral_constant<int, 3>{});
+    if constexpr (L >= 5) level(std::integral_constant<int, 4>{});
+    if constexpr (L >= 6) level(std::integral_constant<int, 5>{});
+#pragma unroll
+    for (int r = 0; r < kFastRows; ++r)
+        if (px < W && py0 + r < H) img_out[(int64_t)(py0 + r) * W + px] = make_float4(o[r][0], o[r][1], o[r][2], 1.0f);
+}
+
+hipError_t launch_filter_fast(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
+                              float* img_out, hipStream_t stream) {
+    const dim3 grid((W + kFastW - 1) / kFastW, (H + kFastH - 1) / kFastH, n), block(256);
+    const float4* in4 = reinterpret_cast<const float4*>(img_in);
+    float4* out4 = reinterpret_cast<float4*>(img_out);
+#define RTO_FFAST(LL)                                                                                              \
+    case LL: {                                                                                                     \
+        const size_t lds = (size_t)2 * (kFastW + 2 * LL) * (kFastH + 2 * LL) * sizeof(float4);                     \
+        hipLaunchKernelGGL(filter_fast<LL>, grid, block, lds, stream, weight, guidance, in4, out4, H, W);          \
+    } break;
+    switch (L) {
+        RTO_FFAST(1) RTO_FFAST(2) RTO_FFAST(3) RTO_FFAST(4) RTO_FFAST(5) RTO_FFAST(6)
+        default: return hipErrorInvalidValue;
+    }
+#undef RTO_FFAST
+    return hipGetLastError();
+}
+
 hipError_t launch_filter(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
                          float* img_out, hipStream_t stream) {
     return launch_filter_train(weight, guidance, L, H, W, n, img_in, img_out, nullptr, nullptr, nullptr, stream);

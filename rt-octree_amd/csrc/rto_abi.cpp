@@ -1007,6 +1007,23 @@ int rto_filtering_batch(void* stream, const float* weight_map, const float* guid
     return RTO_OK;
 }
 
+int rto_filtering_batch_mode(void* stream, const float* weight_map, const float* guidance_map, int L, int H, int W, int n,
+                             const float* img_in, float* img_out, int mode) {
+    if (mode == RTO_FILTER_EXACT) return rto_filtering_batch(stream, weight_map, guidance_map, L, H, W, n, img_in, img_out);
+    if (mode != RTO_FILTER_FACTORISED) return set_err(RTO_E_INVALID, "rto_filtering_batch_mode: unknown mode");
+    if (!weight_map || !guidance_map || !img_in || !img_out || H <= 0 || W <= 0 || n < 1)
+        return set_err(RTO_E_INVALID, "rto_filtering: null pointer or bad size");
+    if (L < 1 || L > 6) return set_err(RTO_E_INVALID, "Kernel size == " + std::to_string(L * 2 + 1) + " not supported.");
+    if (img_in == img_out) return set_err(RTO_E_INVALID, "rto_filtering: img_in and img_out must differ");
+    const int pdev_ = device_of(img_out);
+    if (pdev_ < 0) return set_err(RTO_E_INVALID, "filtering: the output pointer is not device memory");
+    DeviceGuard guard(pdev_);
+    if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");
+    hipError_t e = rto::launch_filter_fast(weight_map, guidance_map, L, H, W, n, img_in, img_out, (hipStream_t)stream);
+    if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("filter launch failed: ") + hipGetErrorString(e));
+    return RTO_OK;
+}
+
 int rto_filtering_train_forward(void* stream, const float* weight_map, const float* guidance_map, int L, int H, int W,
                                 int n, const float* img_in, float* img_out, float* rgb_filtered, float* max_map,
                                 float* inv_kernel_sum) {

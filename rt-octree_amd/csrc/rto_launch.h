@@ -45,6 +45,11 @@ hipError_t launch_rgba8(const float* rgba, uint8_t* out, int64_t n_pixels, hipSt
 hipError_t launch_filter(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
                          float* img_out, hipStream_t stream);
 
+// the same filter with the exponentials factorised out of the taps (filter_kernels.hip filter_fast): the
+// tolerance path, ~1e-6 relative to launch_filter
+hipError_t launch_filter_fast(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
+                              float* img_out, hipStream_t stream);
+
 // training side: forward that also saves rgb_filtered [n][L][H][W][4], max_map / inv_kernel_sum
 // [n][L][H][W] (filtering.cu:205-216), and the backward (filtering.cu:230-301) in gather form
 hipError_t launch_filter_train(const float* weight, const float* guidance, int L, int H, int W, int n,

@@ -148,15 +148,35 @@ def compact_and_compile(model, device=None, example_hw=(800, 800)):
 class FusedGuidanceNet:
     """The compact GuidanceNet as ONE hand-written gfx950 kernel (csrc/guidance_kernels.hip, MFMA fp16
     with fp32 accumulation) instead of two MIOpen convolutions plus seven elementwise launches.
-    Built from a GuidanceNetCompact, or from a TorchScript export of compact_and_compile (its
-    parameters are named layers.<i>.conv.weight / .bias); callable like the module:
-    aux [n,8,H,W] float32 cuda -> (weight_map, guidance_map) [n,L,H,W] float32."""
+    Built from a GuidanceNetCompact, from a TorchScript trace of that module (parameters named
+    layers.<i>.conv.weight / .bias), or from a ts_*.ts as the REFERENCE's exporter writes it -- a traced
+    closure without parameters whose conv weights are constants of the graph (network.py:194-201);
+    callable like the module: aux [n,8,H,W] float32 cuda -> (weight_map, guidance_map) [n,L,H,W] float32."""
+
+    @staticmethod
+    def graph_conv_constants(ts_module):
+        """{weight, bias} tensors of the convolution nodes of a TorchScript forward graph, in order."""
+        g = ts_module.forward.inlined_graph if hasattr(ts_module.forward, "inlined_graph") else ts_module.inlined_graph
+        out = []
+        for n in g.nodes():
+            if n.kind() in ("aten::_convolution_mode", "aten::conv2d", "aten::_convolution", "aten::convolution"):
+                ins = list(n.inputs())
+                w, b = ins[1].toIValue(), ins[2].toIValue()
+                if not (torch.is_tensor(w) and torch.is_tensor(b)):
+                    return []
+                out.append((w, b))
+        return out
 
     def __init__(self, module, device=0):
         import ctypes as C
         from ._lib import check, lib
         sd = {k: v.detach().float().cpu().contiguous() for k, v in module.state_dict().items()}
         keys = ("layers.0.conv.weight", "layers.0.conv.bias", "layers.1.conv.weight", "layers.1.conv.bias")
+        if not sd and isinstance(module, torch.jit.ScriptModule):  # reference-format export
+            convs = self.graph_conv_constants(module)
+            if len(convs) == 2:
+                sd = {k: v.detach().float().cpu().contiguous()
+                      for k, v in zip(keys, (convs[0][0], convs[0][1], convs[1][0], convs[1][1]))}
         if not all(k in sd for k in keys) or any(k.startswith("layers.2.") for k in sd):
             raise ValueError("FusedGuidanceNet needs a two-layer compact GuidanceNet (layers.{0,1}.conv.*)")
         w1, b1, w2, b2 = (sd[k] for k in keys)

@@ -58,6 +58,26 @@ def scene_sdf(p):
     return d
 
 
+def scene_variant(k):
+    """SDF of synthetic scene k (config C3's "8 scenes"): scene 0 is scene_sdf itself, scene k > 0 the same
+    model turned about the z axis, uniformly scaled and with a different part removed -- other topology,
+    other node counts, other ray statistics."""
+    if k == 0:
+        return scene_sdf
+    ang = np.float32(0.7 * k)
+    ca, sa = np.cos(ang), np.sin(ang)
+    scl = np.float32(0.78 + 0.045 * k)
+    cut = np.asarray([(0.8, 0.0, -0.3), (-0.3, 0.0, 0.3), (0.0, 0.5, -0.35), (0.0, -0.5, -0.35)][k % 4], np.float32)
+
+    def sdf(p):
+        p = p.astype(np.float32, copy=False)
+        q = np.stack([ca * p[..., 0] + sa * p[..., 1], -sa * p[..., 0] + ca * p[..., 1], p[..., 2]], -1) / scl
+        d = scene_sdf(q)
+        hole = np.linalg.norm(q - cut, axis=-1) - np.float32(0.28)  # carve a ball out of the model
+        return np.maximum(d, -hole) * scl
+    return sdf
+
+
 # ------------------------------------------------------------------ tree
 class SynthTree:
     """Host arrays of a synthetic PlenOctree, in the reference's layout."""

@@ -365,6 +365,8 @@ class RenderContext:
             lib().rto_ctx_free(self._h)
             self._h = C.c_void_p(0)
 
+    free = freeResource
+
     def __del__(self):
         try:
             self.freeResource()
@@ -405,14 +407,18 @@ def _dev_ptr(t):
     raise TypeError("expected a device tensor or pointer")
 
 
-def filtering(stream, weight_map, guidance_map, img_in, img_out):
+FILTER_EXACT, FILTER_FAST = 0, 1  # RTO_FILTER_EXACT / RTO_FILTER_FACTORISED (include/rto.h)
+
+
+def filtering(stream, weight_map, guidance_map, img_in, img_out, mode=FILTER_EXACT):
     """denoiser::filtering(stream, weight_map[L,H,W], guidance_map[L,H,W], img_in, img_out)
     (filtering.h:7-13).  Tensors are contiguous float32 device tensors (torch) or raw pointers with
-    `shape`; img_in / img_out are [H,W,4]."""
+    `shape`; img_in / img_out are [H,W,4].  mode: FILTER_EXACT (bit-identical to the oracle) or
+    FILTER_FAST (factorised exponentials, ~1e-6 relative)."""
     for t in (weight_map, guidance_map):
         if hasattr(t, "is_contiguous") and not t.is_contiguous():
             raise RtoError(-1, "weight_map / guidance_map must be contiguous")  # CHECK_CONTIGUOUS
     L, H, W = (int(s) for s in guidance_map.shape[-3:])
     n = int(guidance_map.shape[0]) if len(guidance_map.shape) == 4 else 1  # [n,L,H,W]: n images per launch
-    check(lib().rto_filtering_batch(_stream_ptr(stream), _dev_ptr(weight_map), _dev_ptr(guidance_map), L, H, W, n,
-                                    _dev_ptr(img_in), _dev_ptr(img_out)))
+    check(lib().rto_filtering_batch_mode(_stream_ptr(stream), _dev_ptr(weight_map), _dev_ptr(guidance_map), L, H, W, n,
+                                         _dev_ptr(img_in), _dev_ptr(img_out), int(mode)))

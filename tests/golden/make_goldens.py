@@ -7,6 +7,8 @@
   npz_dense.npz / npz_quant.npz + npz_cnpy.json
                         trees written by numpy in the svox key schema, and what the reference's
                         vendored cnpy reads from them (oracle/_ref/cnpy_dump)
+  ts_ref_format.ts      a ts module written by the reference's OWN exporter (compact_and_compile + torch.jit.save):
+                        a traced closure, conv weights as graph constants -- what volrend_headless must recognise
   frames_golden.npz     tiny frames from the CPU oracle (det math): tree arrays, poses, aux, rgba8
   kat_golden.npz        regression vectors from the CPU oracle: octree point
                         queries incl. faces / corners / the clamp edge, SH basis bit patterns for
@@ -52,6 +54,24 @@ def guidance_golden():
         out["csd." + k] = v.numpy()
     np.savez_compressed(os.path.join(HERE, "guidance_golden.npz"), **out)
     print("guidance_golden.npz: %d tensors" % len(out))
+
+
+def ts_ref_format():
+    """A ts_*.ts exactly as the reference's exporter writes it: `compact_and_compile` (denoiser/network.py:170-208)
+    traces a closure, so the file is a parameter-less module whose conv weights are graph constants, and
+    `runner.compact` saves it with torch.jit.save (runner.py:171-175).  Traced on the CPU (no GPU here);
+    loading it with a device argument relocates the constants.  The weights are the trained
+    rt-octree_amd/weights/guidance_synth_lego.pt."""
+    import torch
+    sys.modules.setdefault("_denoiser", types.ModuleType("_denoiser"))
+    sys.path.insert(0, REF)
+    from denoiser import network as refnet
+    model = refnet.GuidanceNet(8, 32, 5, 2, 4).eval()
+    model.load_state_dict(torch.load(os.path.join(ROOT, "rt-octree_amd", "weights", "guidance_synth_lego.pt"), map_location="cpu"))
+    ts = refnet.compact_and_compile(model, torch.device("cpu"))
+    out = os.path.join(HERE, "ts_ref_format.ts")
+    torch.jit.save(ts, out)
+    print("ts_ref_format.ts: %d bytes" % os.path.getsize(out))
 
 
 def npz_goldens():
@@ -162,7 +182,9 @@ def kat_golden():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["guidance", "npz", "frames", "kat"]
+    which = sys.argv[1:] or ["guidance", "npz", "frames", "kat", "ts"]
+    if "ts" in which:
+        ts_ref_format()
     if "kat" in which:
         kat_golden()
     if "guidance" in which:

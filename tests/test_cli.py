@@ -136,6 +136,33 @@ def test_cli_denoise_with_torchscript_module(tmp_path):
     assert r.returncode == 1 and "No torchscript module is given to denoiser." in r.stderr
 
 
+@pytest.mark.gpu
+def test_cli_reference_format_ts_takes_the_fused_kernel(tmp_path):
+    """A ts_*.ts as the reference's exporter writes it (tests/golden/ts_ref_format.ts: traced closure, weights
+    as graph constants, no parameters) runs as the fused HIP kernel, and its PNGs agree with the libtorch
+    route of the same file to fp16 accumulation order."""
+    from PIL import Image
+    tree, tp, poses, pp = _scene(tmp_path, n=2)
+    tsp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ts_ref_format.ts")
+    op = synth.write_opt_json(str(tmp_path / "opt.json"))
+    out_f, out_t = str(tmp_path / "fused"), str(tmp_path / "torch")
+    rf = _run([tp, pp, "--options", op, "--ts_module", tsp, "-w", "80", "-h", "64", "-o", out_f, "--warmup", "1"])
+    assert rf.returncode == 0, rf.stderr
+    assert "GuidanceNet runs as the fused HIP kernel" in rf.stdout
+    rt = _run([tp, pp, "--options", op, "--ts_module", tsp, "-w", "80", "-h", "64", "-o", out_t, "--warmup", "1", "--torch_net"])
+    assert rt.returncode == 0, rt.stderr
+    assert "GuidanceNet runs through libtorch" in rt.stdout
+    for i in range(2):
+        a = np.array(Image.open(os.path.join(out_f, "r_%d.png" % i))).astype(int)
+        b = np.array(Image.open(os.path.join(out_t, "r_%d.png" % i))).astype(int)
+        assert np.abs(a - b).max() <= 2, i
+    # the Python host recognises the same file
+    import torch
+    from rt_octree_amd import denoiser
+    fused = denoiser.FusedGuidanceNet(torch.jit.load(tsp, map_location="cuda:0"))
+    assert fused.c1 == 32 and fused.levels == 4
+
+
 def _parse_poses(out):
     lines = [l for l in out.splitlines() if l and not l.startswith("INFO")]
     head = lines[0].split()

@@ -79,3 +79,30 @@ def test_committed_trained_weights_load_into_the_reference_layout():
         w0, g0 = full.eval()(aux)
         w1, g1 = compact(aux)
     assert torch.allclose(w0, w1, atol=1e-4) and torch.allclose(g0, g1, atol=1e-3)
+
+
+def test_reference_format_ts_fixture_is_recognised():
+    """tests/golden/ts_ref_format.ts was written by the reference's OWN exporter (compact_and_compile traces a
+    closure, network.py:194-201; torch.jit.save, runner.py:171-175): a module without parameters whose
+    conv weights are graph constants.  The host finds them and they equal this repository's fold of the
+    same checkpoint bit for bit."""
+    import os
+    import torch
+    from rt_octree_amd import denoiser
+    here = os.path.dirname(os.path.abspath(__file__))
+    m = torch.jit.load(os.path.join(here, "golden", "ts_ref_format.ts"), map_location="cpu")
+    assert list(m.named_parameters()) == [] and len(m.state_dict()) == 0
+    convs = denoiser.FusedGuidanceNet.graph_conv_constants(m)
+    assert [tuple(w.shape) for w, _ in convs] == [(32, 8, 3, 3), (8, 32, 3, 3)]
+    full = denoiser.GuidanceNet(8, 32, 5, 2, 4)
+    full.load_state_dict(torch.load(os.path.join(here, "..", "rt-octree_amd", "weights", "guidance_synth_lego.pt"), map_location="cpu"))
+    sd = denoiser.GuidanceNetCompact.from_full(full).half().state_dict()
+    for i, (w, b) in enumerate(convs):
+        assert torch.equal(w, sd["layers.%d.conv.weight" % i]) and torch.equal(b, sd["layers.%d.conv.bias" % i])
+    # and the traced graph computes what the compact network computes (fp16 convolutions on the CPU)
+    torch.manual_seed(1)
+    aux = torch.rand(1, 8, 20, 24)
+    with torch.no_grad():
+        w_ts, g_ts = m(aux)
+        w_c, g_c = denoiser.GuidanceNetCompact.from_full(full).half()(aux.half())
+    assert torch.allclose(w_ts, w_c.float(), atol=2e-3) and torch.allclose(g_ts, g_c.float(), atol=1e-2)

@@ -83,3 +83,111 @@ def test_two_ranks_gather_equals_single_process():
     for i in range(7):
         assert np.array_equal(frames[i], single[i]), "frame %d differs between 2-rank and 1-rank runs" % i
     assert timing["frames"] == 7 and abs(timing["render_ms"] - 1.0) < 1e-12 and abs(timing["fps"] - 1000.0 / 6.0) < 1e-9
+
+
+# ------------------------------------------------------------------ bench.py's frame schedule
+def _bench():
+    sys.path.insert(0, os.path.dirname(HERE))
+    import importlib
+    return importlib.import_module("bench")
+
+
+def test_bench_schedule_partitions_frames_over_ranks():
+    """pose i -> rank i mod N (one scene); with K scenes both mappings render every (scene, pose) of a full
+    cycle exactly once, and a launch group never mixes scenes."""
+    b = _bench()
+    for world in (1, 2, 4, 8):
+        seen = sorted(b.pose_schedule(s, r, world, 200, 1, "pose") for r in range(world) for s in range(200 // world))
+        assert seen == [(0, p) for p in range(200)]
+        assert all(b.pose_schedule(s, r, world, 200, 1, "pose")[1] % world == r for r in range(world) for s in range(25))
+    K = 8
+    for world in (1, 2, 4, 8):
+        for m in ("pose", "scene"):
+            per_rank = K * 200 // world
+            seen = sorted(b.pose_schedule(s, r, world, 200, K, m) for r in range(world) for s in range(per_rank))
+            assert seen == [(sc, p) for sc in range(K) for p in range(200)], (world, m)
+            for r in range(world):
+                assert {sc for sc, _ in (b.pose_schedule(s, r, world, 200, K, m) for s in range(per_rank))} == set(b.scenes_of_rank(r, world, K, m))
+                for sc, idx in b.plan_groups(per_rank, 32, r, world, 200, K, m):
+                    assert 1 <= len(idx) <= 32 and len(set(idx)) == len(idx)
+    # more ranks than scenes: every rank still has work
+    assert b.scenes_of_rank(5, 8, 3, "scene") == [2]
+
+
+def test_bench_plan_two_ranks_over_gloo(tmp_path):
+    """`torchrun --nproc-per-node 2 bench.py --plan-only`: the driver's launch line on a CPU box, up to (not
+    including) the GPU calls -- RANK / WORLD_SIZE parsing, rendezvous on 127.0.0.1, the exchanged plans."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "96", "--warmup", "0",
+           "--scenes", "2", "--plan-only"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    doc = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert doc["world"] == 2 and doc["scenes"] == 2
+    for m in ("pose", "scene"):
+        assert len(doc["plans"][m]) == 2
+        frames = [[(sc, p) for sc, idx in rank_plan for p in idx] for rank_plan in doc["plans"][m]]
+        assert all(len(f) == 96 for f in frames)
+        assert not set(frames[0]) & set(frames[1])  # no frame is rendered twice
+    # pose map: rank r renders the poses with p mod 2 == r of scene 0 (192 global frames < 200 poses)
+    assert all(p % 2 == r for r in range(2) for _, idx in doc["plans"]["pose"][r] for p in idx)
+    # scene map: rank r renders scene r
+    assert all(sc == r for r in range(2) for sc, _ in doc["plans"]["scene"][r])
+
+
+def _nccl_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    import rt_octree_amd as R
+    from rt_octree_amd import sharding, synth
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    tree = synth.make_tree(depth_limit=5, basis_dim=9, seed=7)
+    dt = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format, device=rank)
+    poses = synth.orbit_poses(7)
+    W, H = 40, 32
+    fx = synth.blender_focal(W)
+    ctx = R.RenderContext(W, H, device=rank)
+    local = {}
+    for i in sharding.shard_indices(7, rank, world):
+        cam = R.Camera(W, H, fx, fx)
+        cam.set_c2w(poses[i])
+        ctx.rng_seed()
+        ctx.rng_advance(sharding.frame_rng_jumps(i) << 32)
+        R.launch_renderer(dt, cam, R.RenderOptions(spp=2, denoise=False), ctx)
+        local[i] = ctx.download_rgba8()
+    frames = sharding.gather_frames(local, 7, rank, world, dist=dist, device=dev)  # RCCL all_gather of device tensors
+    if rank == 0:
+        q.put(np.stack(frames))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_gpus_gather_over_rccl_equals_single_gpu():
+    """The final gather over RCCL with device tensors, one process per GPU.  Needs two GPUs: skipped on the
+    1-GPU test box, exercised by the first multi-GPU run."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    frames = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    single = _render_frames(range(7))  # the CPU oracle, bit-exact with the HIP kernels
+    for i in range(7):
+        assert np.array_equal(frames[i], single[i]), "frame %d differs between the 2-GPU run and the oracle" % i

@@ -28,6 +28,16 @@ def main():
         e1.record(s)
         torch.cuda.synchronize()
         print("filter n=%d %dx%d L=%d: %.3f ms/image" % (n, W, H, L, e0.elapsed_time(e1) / reps / n), flush=True)
+        g6 = g.clamp(0, 6).contiguous()
+        for _ in range(3):
+            R.filtering(s, w, g6, img, out, mode=R.FILTER_FAST)
+        torch.cuda.synchronize()
+        e0.record(s)
+        for _ in range(reps):
+            R.filtering(s, w, g6, img, out, mode=R.FILTER_FAST)
+        e1.record(s)
+        torch.cuda.synchronize()
+        print("  factorised: %.3f ms/image" % (e0.elapsed_time(e1) / reps / n), flush=True)
         # training side: forward with saves + backward through the autograd wrapper's ABI calls
         from rt_octree_amd import denoiser
         wr, gr = w.clone().requires_grad_(True), g.clone().requires_grad_(True)

@@ -7,8 +7,8 @@ import json
 import os
 import sys
 
-FAMILIES = ("render_persist", "shade_kernel", "raygen_kernel", "sample_kernel", "filter_fused", "guidance_fused",
-            "render_fast")
+FAMILIES = ("render_persist", "shade_kernel", "raygen_kernel", "sample_kernel", "filter_fused", "filter_fast",
+            "guidance_fused", "render_fast")
 
 
 def family(name):

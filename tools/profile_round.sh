@@ -1,19 +1,33 @@
 #!/bin/bash
-# Evidence run for profiles/: kernel trace + separate PMC passes of the default bench workload.
-# usage (on the GPU box, from the repo root): bash tools/profile_round.sh TAG   -> gpurun_out/TAG_*
-TAG=${1:-rX}
+# Evidence run for profiles/: bench lines, kernel trace and separate PMC passes for the BASELINE configurations
+# C2 (default), C5 (SPP 1 raw) and C4 (1920x1080 stand-in).
+# usage (on the GPU box, from the repo root): bash tools/profile_round.sh TAG [c2 c5 c4]   -> gpurun_out/TAG_*
+TAG=${1:-rX}; shift
+CFGS=${@:-c2 c5 c4}
 O=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-B="bench.py --cpu-frames 0 --psnr-frames 0 --steps 96 --warmup 32"
-python3 bench.py --cpu-frames 2 > $O/${TAG}_bench_c2.json 2> $O/${TAG}_bench_c2.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -- python3 $B > $O/${TAG}_bench_under_rocprof.json 2>/dev/null
-cp $(find $O/${TAG}_trace -name '*kernel_stats.csv' | head -1) $O/${TAG}_bench_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch -- python3 $B > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_pmc_write -- python3 $B > /dev/null 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --output-format csv -d $O/${TAG}_pmc_tcc -- python3 $B > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD --output-format csv -d $O/${TAG}_pmc_sq -- python3 $B > /dev/null 2>&1
-python3 tools/pmc_summarize.py $O/${TAG}_pmc_summary.json $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_tcc $O/${TAG}_pmc_sq --traffic $O/${TAG}_pmc_traffic.json
-rm -rf $O/${TAG}_trace $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_tcc $O/${TAG}_pmc_sq
-# the other configurations of BASELINE.json: C5 (SPP 1 raw) and the C4 shape (1920x1080, SH25, denoise)
-python3 bench.py --spp 1 --no-denoise --cpu-frames 0 --psnr-frames 0 --steps 192 --warmup 32 > $O/${TAG}_bench_c5_spp1_raw.json 2>/dev/null
-python3 bench.py --width 1920 --height 1080 --basis 25 --depth 9 --cpu-frames 0 --psnr-frames 0 --steps 96 --warmup 32 > $O/${TAG}_bench_c4_1080p_sh25.json 2>/dev/null
+for C in $CFGS; do
+  case $C in
+    c2) A="" ; STEPS=96 ;;
+    c5) A="--spp 1 --no-denoise" ; STEPS=96 ;;
+    c4) A="--c4" ; STEPS=64 ;;
+  esac
+  B="bench.py $A --cpu-frames 0 --psnr-frames 0 --ref-loop-frames 0 --steps $STEPS --warmup 32"
+  # the plain bench line of the configuration (C2: the full default line with CPU baseline and PSNR)
+  if [ $C = c2 ]; then python3 bench.py > $O/${TAG}_bench_c2.json 2> $O/${TAG}_bench_c2.err
+  else python3 bench.py $A --cpu-frames 0 --psnr-frames 16 > $O/${TAG}_bench_$C.json 2> $O/${TAG}_bench_$C.err; fi
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_${C}_trace -- python3 $B > $O/${TAG}_${C}_bench_under_rocprof.json 2>/dev/null
+  cp $(find $O/${TAG}_${C}_trace -name '*kernel_stats.csv' | head -1) $O/${TAG}_${C}_kernel_stats.csv
+  i=0
+  for SET in "FETCH_SIZE" "WRITE_SIZE" \
+             "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
+             "GRBM_GUI_ACTIVE GRBM_COUNT TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum" \
+             "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD" \
+             "SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_BUSY_CYCLES"; do
+    i=$((i+1))
+    rocprofv3 --pmc $SET --output-format csv -d $O/${TAG}_${C}_pmc_$i -- python3 $B > /dev/null 2> $O/${TAG}_${C}_pmc_$i.err || tail -2 $O/${TAG}_${C}_pmc_$i.err
+  done
+  RTO_FRAMES_PER_LAUNCH=32 python3 tools/pmc_summarize.py $O/${TAG}_${C}_pmc_summary.json $O/${TAG}_${C}_pmc_1 $O/${TAG}_${C}_pmc_2 $O/${TAG}_${C}_pmc_3 $O/${TAG}_${C}_pmc_4 $O/${TAG}_${C}_pmc_5 $O/${TAG}_${C}_pmc_6 > /dev/null
+  rm -rf $O/${TAG}_${C}_trace $O/${TAG}_${C}_pmc_[1-6] $O/${TAG}_${C}_pmc_[1-6].err
+done
+python3 tools/pmc_traffic.py $O/${TAG}_pmc_traffic.json $O/r2_probe_ceiling.json $(for C in $CFGS; do echo $C=$O/${TAG}_${C}_pmc_summary.json; done)

@@ -90,3 +90,26 @@ def test_golden_quant_file_direct():
         b.select_frame(f)
         assert_bits_equal(a.download_image(), b.download_image(), "image f%d" % f)
     assert float(np.abs(a.download_image()[..., :3]).max()) > 0
+
+
+def test_shuffled_quant_tree_is_relaid_like_any_other(tmp_path):
+    """a quantised file whose nodes are stored in a random order: the breadth-first relayout at upload gathers
+    quant_map / sigma / data_retained per slot too -- direct and expanded routes still equal the ordered tree."""
+    W, H = 64, 48
+    tree = synth.make_tree(depth_limit=5, basis_dim=9, seed=8)
+    shuffled = synth.shuffle_nodes(tree, seed=2)
+    p0, p1 = str(tmp_path / "ordered.npz"), str(tmp_path / "shuffled.npz")
+    tree.save_quant_npz(p0, n_retain=2)
+    # the stand-in quantiser ranks slots by luminance: the same slots get the same codes in either storage order
+    shuffled.save_quant_npz(p1, n_retain=2)
+    cams = _cams(W, H, 2)
+    opt = R.RenderOptions(spp=6, denoise=False)
+    ref = R.RenderContext(W, H, frames=2)
+    R.launch_renderer_batch(R.N3Tree(p0), cams, opt, ref)
+    for direct in (False, True):
+        ctx = R.RenderContext(W, H, frames=2)
+        R.launch_renderer_batch(R.N3Tree(p1, quant_direct=direct), cams, opt, ctx)
+        for f in range(2):
+            ref.select_frame(f)
+            ctx.select_frame(f)
+            assert_bits_equal(ctx.download_aux(), ref.download_aux(), "direct %s frame %d" % (direct, f))

@@ -30,4 +30,4 @@ for C in $CFGS; do
   RTO_FRAMES_PER_LAUNCH=32 python3 tools/pmc_summarize.py $O/${TAG}_${C}_pmc_summary.json $O/${TAG}_${C}_pmc_1 $O/${TAG}_${C}_pmc_2 $O/${TAG}_${C}_pmc_3 $O/${TAG}_${C}_pmc_4 $O/${TAG}_${C}_pmc_5 $O/${TAG}_${C}_pmc_6 > /dev/null
   rm -rf $O/${TAG}_${C}_trace $O/${TAG}_${C}_pmc_[1-6] $O/${TAG}_${C}_pmc_[1-6].err
 done
-python3 tools/pmc_traffic.py $O/${TAG}_pmc_traffic.json $O/r2_probe_ceiling.json $(for C in $CFGS; do echo $C=$O/${TAG}_${C}_pmc_summary.json; done)
+python3 tools/pmc_traffic.py $O/${TAG}_pmc_traffic.json profiles/r2_probe_ceiling.json $(for C in $CFGS; do echo $C=$O/${TAG}_${C}_pmc_summary.json; done)

@@ -392,10 +392,12 @@ RTO_DEV bool block_tile(const TileMap& tm, int b, int& tx, int& ty) {
 //   planar      [SPP][H*W]:  i * SIZE + p   (a wave's 64 hit stores go to 64 different lines once its lanes hold
 //                                            unrelated pixels)
 //   pixel-major [H*W][SPP]:  p * SPP + i   (a pixel's thresholds / hit list are one contiguous run: 24 B at SPP 6)
-#ifdef RTO_HITS_PLANAR
-constexpr bool kHitsPixelMajor = false;
-#else
+// (measured, 32 frames of 800x800 SPP 6: pixel-major traversal 2.98 ms, planar 2.81 ms; shading 0.78 vs 0.80 ms --
+// planar stays)
+#ifdef RTO_HITS_PIXEL_MAJOR
 constexpr bool kHitsPixelMajor = true;
+#else
+constexpr bool kHitsPixelMajor = false;
 #endif
 template <int SPP>
 RTO_DEV uint32_t hit_index(uint32_t pixel, uint32_t i, uint32_t SIZE) {
@@ -663,11 +665,7 @@ struct RayState {
     int prev_lvl;   // level of the node about to be visited
     uint32_t hoff;  // index of this pixel's first hit entry in the hand-off buffer
     uint32_t node;  // node about to be visited; kGridNext = the top grid is visited next
-    // header traversal (TRAV == 1): header of `node` and what the next iteration must load first
-    uint32_t hx, hy;  // {first internal child, internal mask | non-zero-sigma mask << 8}
-    uint32_t need;    // what the next iteration does first: load (kNeedGrid / kNeedHdr / kNeedSig) or step (kNeedStep)
 };
-constexpr uint32_t kNeedGrid = 1u, kNeedHdr = 2u, kNeedSig = 3u, kNeedStep = 4u, kNeedClassify = 5u;
 constexpr uint32_t kGridNext = 0xffffffffu;
 
 // position p of a ray queue -> (frame, x, y).  The queue holds `qtiles` tiles per frame, frame after
@@ -734,23 +732,18 @@ __global__ void __launch_bounds__(256) sample_kernel(const FrameBatch fb, const 
 // at a leaf, takes its march step and picks the restart node of the next one -- instead of a nested
 // "descend until leaf" loop whose trip count is the maximum over the wave (measured: 1.4 loads per
 // lane-step on average, but ~4 per wave-step for the slowest lane).
-// TRAV: 0 = the 4-byte-per-slot traversal image (nodew), one word per visit; 1 = the header image (TreeDev::trav2):
-// an 8-byte header per node held in registers, children by popcount, sigma fetched only for non-zero leaves --
-// a step into a sibling leaf needs no load, the data is 4x denser in the caches, and every load of the loop is
-// the same 8-byte instruction.  Same visits, same arithmetic per step: bit-identical results.
-template <int SPP, int REFILL, int WPS, int TRAV>
+template <int SPP, int REFILL, int WPS>
 __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, const OptDev opt, const FrameBatch fb,
                                                        unsigned long long* __restrict__ queue,
                                                        uint32_t* __restrict__ hits, const uint32_t chunk) {
     // queue[8 + 8k]: next ray of queue k (zeroed on the stream before the launch)
-    // LDS: [(TRAV ? 3 : 1) * (max_depth+1-top_levels)][256] ancestor stack | [SPP+1][256] sorted thresholds | frame table
+    // LDS: [max_depth+1-top_levels][256] ancestor stack | [SPP+1][256] sorted thresholds | frame table
     extern __shared__ uint32_t s_mem[];
     const int tid = threadIdx.x;
     uint32_t* stack = s_mem + tid;
     const int stack_levels = tree.max_depth + 1 - tree.top_levels;  // levels top_levels.. only
-    constexpr int kStackWords = TRAV ? 3 : 1;  // TRAV 1 keeps {node, header} per level
-    float* s_dst = reinterpret_cast<float*>(s_mem + (size_t)stack_levels * kStackWords * 256) + tid;
-    FrameDesc* s_frames = reinterpret_cast<FrameDesc*>(s_mem + (size_t)(stack_levels * kStackWords + SPP + 1) * 256);
+    float* s_dst = reinterpret_cast<float*>(s_mem + (size_t)stack_levels * 256) + tid;
+    FrameDesc* s_frames = reinterpret_cast<FrameDesc*>(s_mem + (size_t)(stack_levels + SPP + 1) * 256);
     __shared__ int s_qstart[kMaxQueues + 1];
 #pragma unroll
     for (int f = 0; f < kMaxBatch; ++f)  // static indices: the kernarg struct is never address-taken
@@ -783,12 +776,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     typedef const __attribute__((address_space(1))) u32x2* gptr2_t;
     const gptr2_t topgrid = (gptr2_t)topgrid_p;
     const int G = tree.top_levels;  // grid bits per axis; the LDS stack holds node levels G.. (entry 0 = level G)
-    if (TRAV == 0 && G == 0) stack[0] = 0u;  // no top grid: level 0 is the root
-    const uint2* trav2_p = tree.trav2;
-    uint32_t hdr_off = tree.hdr_off, sig_off = tree.sig_off;
-    asm volatile("" : "+s"(trav2_p), "+s"(hdr_off), "+s"(sig_off));
-    const gptr2_t trav2 = (gptr2_t)trav2_p;
-    const int plane = stack_levels * 256;  // TRAV 1: stack planes {node, hx, hy}
+    if (G == 0) stack[0] = 0u;      // no top grid: level 0 is the root
 
 #ifdef RTO_DBG_COUNTERS
     unsigned dbg_wave_steps = 0, dbg_lane_steps = 0, dbg_lane_loads = 0, dbg_lane_leafs = 0, dbg_refills = 0, dbg_refilled = 0;
@@ -884,8 +872,6 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                                 rs.piy = (uint32_t)(rs.pos[1] * 16777216.f);
                                 rs.piz = (uint32_t)(rs.pos[2] * 16777216.f);
                                 rs.node = G > 0 ? kGridNext : 0u;
-                                rs.need = G > 0 ? kNeedGrid : kNeedHdr;  // (TRAV 1; without a grid: the root's header)
-                                rs.hx = rs.hy = 0u;
                             }
                         }
                     }
@@ -901,120 +887,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
         ++dbg_wave_steps;
         dbg_lane_steps += (unsigned)__popcll(__ballot(active));
 #endif
-        if constexpr (TRAV == 1) {
-            // ---- header traversal.  rs.need says what this iteration does for the lane: load a grid entry / a node
-            // header / a sigma (one 8-byte load instruction for all three), or step straight away (a leaf of zero
-            // density under a header the lane already holds).  A lane that has just received a header, or has just
-            // stepped and holds the header of its restart node, classifies its next slot at the bottom of the SAME
-            // iteration, so the following iteration starts with the load (or the step) that slot needs.
-            if (active) {
-                const uint32_t sh = 23u - (uint32_t)rs.prev_lvl;
-                const uint32_t ci = (__builtin_amdgcn_ubfe(rs.pix, sh, 1u) << 2) |
-                                    (__builtin_amdgcn_ubfe(rs.piy, sh, 1u) << 1) | __builtin_amdgcn_ubfe(rs.piz, sh, 1u);
-                bool step_now = rs.need == kNeedStep;
-                uint32_t sig_bits = 0u, slot = (rs.node << 3) | ci;
-                if (rs.need <= kNeedSig) {
-                    const uint32_t gs = 24u - (uint32_t)G;
-                    const uint32_t key = (((rs.pix >> gs) << G | (rs.piy >> gs)) << G) | (rs.piz >> gs);
-                    const uint32_t idx = rs.need == kNeedGrid ? key : rs.need == kNeedHdr ? hdr_off + rs.node : sig_off + (slot >> 2);
-                    const u32x2 e = trav2[idx];
-                    if (rs.need == kNeedGrid) {
-                        rs.prev_lvl = (int)(e.x >> 27);
-                        if (e.y & 0x80000000u) {  // the cell lies in a leaf above node level G
-                            slot = e.x & 0x07ffffffu;
-                            sig_bits = e.y & 0xffffu;
-                            step_now = true;
-                        } else {  // the node of level G: its header next
-                            rs.node = e.x & 0x07ffffffu;
-                            rs.need = kNeedHdr;
-                        }
-                    } else if (rs.need == kNeedHdr) {
-                        rs.hx = e.x;
-                        rs.hy = e.y;
-                        rs.need = kNeedClassify;
-                        uint32_t* sp = stack + (rs.prev_lvl - G) * 256;
-                        sp[0] = rs.node;
-                        sp[plane] = e.x;
-                        sp[2 * plane] = e.y;
-                    } else {  // the leaf's sigma: half (slot & 3) of the 8 bytes
-                        const uint32_t v = (ci & 2u) ? e.y : e.x;
-                        sig_bits = (ci & 1u) ? (v >> 16) : (v & 0xffffu);
-                        step_now = true;
-                    }
-                }
-                if (step_now) {  // the march step (rt_core.cuh:241-270), as in the TRAV 0 branch below
-                    const int lvl = rs.prev_lvl;
-                    const float cube_sz = __uint_as_float((uint32_t)(128 + lvl) << 23);
-                    const float inv_cube = __uint_as_float((uint32_t)(126 - lvl) << 23);
-                    const float b0 = -__builtin_amdgcn_fractf(rs.pos[0] * cube_sz) * rs.invdir[0];
-                    const float b1 = -__builtin_amdgcn_fractf(rs.pos[1] * cube_sz) * rs.invdir[1];
-                    const float b2 = -__builtin_amdgcn_fractf(rs.pos[2] * cube_sz) * rs.invdir[2];
-                    const float a0 = __builtin_fmaxf(b0, b0 + rs.invdir[0]);
-                    const float a1 = __builtin_fmaxf(b1, b1 + rs.invdir[1]);
-                    const float a2 = __builtin_fmaxf(b2, b2 + rs.invdir[2]);
-                    const float tm = __builtin_fminf(1e4f, __builtin_fminf(__builtin_fminf(a0, a1), a2));
-                    const float delta_t = tm * inv_cube + step_size;
-                    const float sigma = half_bits_to_float((uint16_t)sig_bits);
-                    bool done = false;
-                    if (sigma > sigma_thresh) {
-                        const float delta = delta_t * rs.delta_scale * sigma;
-                        const float reach = rs.src + delta;
-                        if (reach >= rs.cur) {
-                            uint32_t cnt = 0;
-                            do {
-                                ++cnt;
-                                ++rs.spp;
-                                rs.cur = s_dst[rs.spp * 256];
-                            } while (reach >= rs.cur);
-                            hits[rs.hoff + rs.sh_nums * hstride] = hit_pack(slot, cnt);
-                            ++rs.sh_nums;
-                            done = rs.spp == (uint32_t)SPP;
-                        }
-                        rs.src = reach;
-                    }
-                    rs.t += delta_t;
-                    active = !done && rs.t < rs.tmax;
-                    if (active) {  // next position -> where the next visit starts
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) rs.pos[i] = clamp_unit(rs.cen[i] + rs.t * rs.dir[i]);
-                        const uint32_t ix = (uint32_t)(rs.pos[0] * 16777216.f);
-                        const uint32_t iy = (uint32_t)(rs.pos[1] * 16777216.f);
-                        const uint32_t iz = (uint32_t)(rs.pos[2] * 16777216.f);
-                        const uint32_t diff = (ix ^ rs.pix) | (iy ^ rs.piy) | (iz ^ rs.piz);
-                        int m = __clz((int)diff) - 8;
-                        m = m < lvl ? m : lvl;
-                        rs.pix = ix;
-                        rs.piy = iy;
-                        rs.piz = iz;
-                        if (m < G) {
-                            rs.need = kNeedGrid;
-                        } else {
-                            if (m < lvl) {  // an ancestor: its node and header from the stack
-                                const uint32_t* sp = stack + (m - G) * 256;
-                                rs.node = sp[0];
-                                rs.hx = sp[plane];
-                                rs.hy = sp[2 * plane];
-                                rs.prev_lvl = m;
-                            }  // else: another slot of the same node, whose header this lane still holds
-                            rs.need = kNeedClassify;
-                        }
-                    }
-                }
-                if (active && rs.need == kNeedClassify) {  // the header is here: what is the slot of the (new) position?
-                    const uint32_t sh2 = 23u - (uint32_t)rs.prev_lvl;
-                    const uint32_t c2 = (__builtin_amdgcn_ubfe(rs.pix, sh2, 1u) << 2) |
-                                        (__builtin_amdgcn_ubfe(rs.piy, sh2, 1u) << 1) | __builtin_amdgcn_ubfe(rs.piz, sh2, 1u);
-                    const uint32_t bit = 1u << c2;
-                    if (rs.hy & bit) {  // internal: one level down, that node's header next
-                        rs.node = rs.hx + (uint32_t)__builtin_popcount(rs.hy & (bit - 1u) & 0xffu);
-                        ++rs.prev_lvl;
-                        rs.need = kNeedHdr;
-                    } else {  // a leaf: its sigma next, or -- zero density -- nothing at all
-                        rs.need = (rs.hy & (bit << 8)) ? kNeedSig : kNeedStep;
-                    }
-                }
-            }
-        } else {
+        {
             // ---- one node visit for every active lane
             if (active) {
                 const bool grid = rs.node == kGridNext;
@@ -1057,23 +930,6 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     }
                 }
 #endif
-#ifdef RTO_UNI_LOAD
-                {  // ONE 8-byte load instruction for both kinds of visit: the grid entry, or the aligned pair of
-                   // traversal-image words holding this slot (one gather per iteration instead of two when a
-                   // wave's lanes are split between the kinds)
-                    const uint32_t pair = grid ? key : (slot >> 1);
-                    const gptr2_t base = grid ? topgrid : (gptr2_t)nodew_p;
-                    const u32x2 e = base[pair];
-                    if (grid) {
-                        slot = e.x & 0x07ffffffu;
-                        rs.prev_lvl = (int)(e.x >> 27);
-                        rs.node = slot >> 3;
-                        w = e.y;
-                    } else {
-                        w = (slot & 1u) ? e.y : e.x;
-                    }
-                }
-#else
                 if (grid) {  // the iteration's one load: 8 bytes of the top grid ...
                     const u32x2 e = topgrid[key];  // (through the L1 as well: non-temporal costs 15 %)
                     slot = e.x & 0x07ffffffu;
@@ -1083,7 +939,6 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                 } else {  // ... or 4 bytes of the traversal image
                     w = nodew[slot];  // (through the L1: a non-temporal load here costs 50 %)
                 }
-#endif
 #ifdef RTO_DBG_COUNTERS
                 ++dbg_lane_loads;
 #endif
@@ -1506,18 +1361,18 @@ hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev&
     }
 }
 
-template <int SPP, int REFILL, int WPS, int TRAV>
+template <int SPP, int REFILL, int WPS>
 static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                     const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
                                     int chunk_override, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
-    const size_t lds = (size_t)((tree.max_depth + 1 - tree.top_levels) * (TRAV ? 3 : 1) + SPP + 1) * 256 * sizeof(uint32_t) +
+    const size_t lds = (size_t)(tree.max_depth + 1 - tree.top_levels + SPP + 1) * 256 * sizeof(uint32_t) +
                        sizeof(FrameDesc) * kMaxBatch;
-    const void* fn = reinterpret_cast<const void*>(&render_persist<SPP, REFILL, WPS, TRAV>);
+    const void* fn = reinterpret_cast<const void*>(&render_persist<SPP, REFILL, WPS>);
     OccupancyCache local;
     if (!occ) occ = &local;
     if (occ->blocks_per_cu == 0 || occ->fn != fn || occ->lds != lds) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_persist<SPP, REFILL, WPS, TRAV>, 256, lds) != hipSuccess || nb < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_persist<SPP, REFILL, WPS>, 256, lds) != hipSuccess || nb < 1)
             nb = 2;
         occ->blocks_per_cu = nb > 8 ? 8 : nb;
         occ->fn = fn;
@@ -1540,7 +1395,7 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
     // this context ended
     if (hipMemsetAsync(queue, 0, kQueueWords * sizeof(unsigned long long), stream) != hipSuccess) return hipErrorLaunchFailure;
     if (ev) (void)hipEventRecord(ev[0], stream);
-    hipLaunchKernelGGL((render_persist<SPP, REFILL, WPS, TRAV>), dim3(grid), dim3(256), lds, stream, tree, opt, fb, queue, hits, chunk);
+    hipLaunchKernelGGL((render_persist<SPP, REFILL, WPS>), dim3(grid), dim3(256), lds, stream, tree, opt, fb, queue, hits, chunk);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
     if (ev) (void)hipEventRecord(ev[1], stream);
 #ifndef RTO_SHADE_P
@@ -1575,11 +1430,11 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
 template <int SPP>
 static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                    const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
-                                   int refill, int trav, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
+                                   int refill, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
     const int chunk_override = (refill / 1000) * 64;  // tuning: refill = 1000 * tiles_per_dequeue + threshold
     refill %= 1000;
     if (SPP == 6) {  // tuning instantiations only for the benchmark configuration
-#define RTO_F(R, O) return launch_batch_impl<SPP, R, O, 0>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, occ, ev, stream)
+#define RTO_F(R, O) return launch_batch_impl<SPP, R, O>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, occ, ev, stream)
         switch (refill) {  // A/B set kept for tools/ab_tuning.py: 100 * waves/SIMD + refill threshold
             case 808: RTO_F(8, 8);
             case 816: RTO_F(16, 8);
@@ -1595,23 +1450,21 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
     // (2.75 ms vs 2.92 for 16 idle lanes at 8 waves/SIMD; 4 to 8 waves/SIMD differ by < 2 % -- the
     // kernel is bound by the L1s, not by latency hiding -- and larger refill rounds waste fewer issue
     // slots on the partially filled ray set-up)
-    if (trav && tree.trav2)
-        return launch_batch_impl<SPP, 32, 6, 1>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, occ, ev, stream);
-    return launch_batch_impl<SPP, 32, 6, 0>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, occ, ev, stream);
+    return launch_batch_impl<SPP, 32, 6>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, occ, ev, stream);
 }
 
 hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
-                               int refill, int trav, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
+                               int refill, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
     switch (spp) {
-        case 1: return launch_batch_spp<1>(tree, opt, fb, jump, queue, hits, num_cus, refill, trav, occ, ev, stream);
-        case 2: return launch_batch_spp<2>(tree, opt, fb, jump, queue, hits, num_cus, refill, trav, occ, ev, stream);
-        case 3: return launch_batch_spp<3>(tree, opt, fb, jump, queue, hits, num_cus, refill, trav, occ, ev, stream);
-        case 4: return launch_batch_spp<4>(tree, opt, fb, jump, queue, hits, num_cus, refill, trav, occ, ev, stream);
-        case 6: return launch_batch_spp<6>(tree, opt, fb, jump, queue, hits, num_cus, refill, trav, occ, ev, stream);
-        case 8: return launch_batch_spp<8>(tree, opt, fb, jump, queue, hits, num_cus, refill, trav, occ, ev, stream);
-        case 16: return launch_batch_spp<16>(tree, opt, fb, jump, queue, hits, num_cus, refill, trav, occ, ev, stream);
-        case 32: return launch_batch_spp<32>(tree, opt, fb, jump, queue, hits, num_cus, refill, trav, occ, ev, stream);
+        case 1: return launch_batch_spp<1>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
+        case 2: return launch_batch_spp<2>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
+        case 3: return launch_batch_spp<3>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
+        case 4: return launch_batch_spp<4>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
+        case 6: return launch_batch_spp<6>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
+        case 8: return launch_batch_spp<8>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
+        case 16: return launch_batch_spp<16>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
+        case 32: return launch_batch_spp<32>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -77,7 +77,6 @@ struct rto_tree {
     void* d_child = nullptr;
     void* d_nodew = nullptr;
     void* d_topgrid = nullptr;
-    void* d_trav2 = nullptr;  // header traversal image: [top grid][node headers][sigma], one allocation
     void* d_qrec = nullptr;
     void* d_qcolors = nullptr;
     void* d_qsigma = nullptr;
@@ -115,7 +114,6 @@ struct rto_ctx {
     bool jump_valid = false;
     int kernel = RTO_KERNEL_AUTO;
     int strip_rows = 1;
-    int trav = 1;    // batched path: 1 = header traversal image when the tree has one, 0 = per-slot image
     int refill = 0;  // 0 = the default instantiation; 100 * waves/SIMD + idle-lane threshold picks an A/B one
     bool tile_order_on = true;
     bool stats_on = false;
@@ -169,8 +167,8 @@ int ensure_jump_table(rto_ctx* c, hipStream_t stream) {
 }
 
 // Breadth-first node order of a tree: order[new] = old.  Children are visited in slot order, so after the
-// renumbering (a) the internal children of every node are consecutive, in slot order, and (b) every level
-// is stored in Morton order of its cells -- whatever order the file used (svox appends the children of
+// renumbering the internal children of every node are consecutive, in slot order, and every level is stored
+// in Morton order of its cells -- whatever order the file used (svox appends the children of
 // whichever leaves a refinement step selected).  Nodes the root does not reach (spare capacity) keep their
 // relative order behind the reachable ones.
 std::vector<int64_t> bfs_order(const int32_t* child, int64_t capacity, int64_t N3) {
@@ -241,60 +239,6 @@ void relay_tree(const std::vector<int64_t>& order, const int32_t* child, const u
             std::memcpy(out.q_retained.data() + (size_t)j * ns * 3, plane.data(), ns * 3 * sizeof(uint16_t));
         }
     }
-}
-
-// Header traversal image of an N == 2 tree whose internal children are consecutive (bfs_order):
-//   grid  [2^(3G)]   per top-grid cell: {slot | level << 27, 0x80000000 | sigma} where the root path ends on a leaf
-//                    above node level G, else {node of level G | G << 27, 0}
-//   hdr   [capacity] {first internal child, internal mask | non-zero-sigma mask << 8}
-//   sig   [capacity] the 8 fp16 sigmas of the node (0 in internal slots), two u64 words
-// as u64 words in one buffer.  Returns false when some node's children are not consecutive (a DAG).
-bool build_trav2(const int32_t* child, const uint16_t* sigma_src, int sigma_stride, int64_t capacity, int G,
-                 std::vector<uint64_t>& out) {
-    const size_t g3 = G > 0 ? (size_t)1 << (3 * G) : 0;
-    out.assign(g3 + (size_t)capacity * 3, 0);
-    uint64_t* hdr = out.data() + g3;
-    uint16_t* sig = reinterpret_cast<uint16_t*>(out.data() + g3 + (size_t)capacity);
-    for (int64_t n = 0; n < capacity; ++n) {
-        uint32_t first = 0, mask = 0, nz = 0, cnt = 0;
-        for (int k = 0; k < 8; ++k) {
-            const int32_t c = child[n * 8 + k];
-            if (c) {
-                const uint32_t t = (uint32_t)(n + c);
-                if (!cnt) first = t;
-                if (t != first + cnt) return false;
-                ++cnt;
-                mask |= 1u << k;
-            } else {
-                const uint16_t sb = sigma_src[(size_t)(n * 8 + k) * (size_t)sigma_stride];
-                sig[n * 8 + k] = sb;
-                if (sb & 0x7fffu) nz |= 1u << k;
-            }
-        }
-        hdr[n] = (uint64_t)first | ((uint64_t)(mask | (nz << 8)) << 32);
-    }
-    for (size_t key = 0; key < g3; ++key) {
-        const uint32_t m = (1u << G) - 1u;
-        const uint32_t cx = (uint32_t)(key >> (2 * G)), cy = (uint32_t)(key >> G) & m, cz = (uint32_t)key & m;
-        uint32_t node = 0;
-        for (int lvl = 0;; ++lvl) {
-            const int sh = G - 1 - lvl;
-            const uint32_t ci = (((cx >> sh) & 1u) << 2) | (((cy >> sh) & 1u) << 1) | ((cz >> sh) & 1u);
-            const uint32_t slot = node * 8u + ci;
-            const int32_t c = child[slot];
-            if (c == 0) {
-                out[key] = (uint64_t)(slot | ((uint32_t)lvl << 27)) |
-                           ((uint64_t)(0x80000000u | sigma_src[(size_t)slot * (size_t)sigma_stride]) << 32);
-                break;
-            }
-            node += (uint32_t)c;
-            if (lvl == G - 1) {
-                out[key] = (uint64_t)(node | ((uint32_t)G << 27));
-                break;
-            }
-        }
-    }
-    return true;
 }
 
 int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, int N, int data_dim,
@@ -436,19 +380,6 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
         dev_bytes += gbytes;
     }
 
-    if (t->fast_ok && capacity < (int64_t(1) << 27)) {
-        // header traversal image (render_persist): 8 B per node + its sigmas, children addressed by popcount
-        std::vector<uint64_t> trav2;
-        const bool ok = quant ? build_trav2(child, quant->q_sigma, 1, capacity, top_levels, trav2)
-                              : build_trav2(child, data + (data_dim - 1), data_dim, capacity, top_levels, trav2);
-        if (ok) {
-            if (hipMalloc(&t->d_trav2, trav2.size() * 8) != hipSuccess ||
-                hipMemcpy(t->d_trav2, trav2.data(), trav2.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
-                return fail(RTO_E_HIP, "uploading the header traversal image failed");
-            dev_bytes += trav2.size() * 8;
-        }
-    }
-
     rto::TreeDev& d = t->dev;
     if (t->d_qsigma) {  // sigma now lives in the traversal image
         (void)hipFree(t->d_qsigma);
@@ -458,9 +389,6 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
     if (quant && !t->fast_ok) return fail(RTO_E_UNSUPPORTED, "direct rendering of quantised trees needs the N == 2 traversal image");
     d.topgrid = (const uint2*)t->d_topgrid;
     d.top_levels = top_levels;
-    d.trav2 = (const uint2*)t->d_trav2;
-    d.hdr_off = top_levels > 0 ? 1u << (3 * top_levels) : 0u;
-    d.sig_off = d.hdr_off + (uint32_t)capacity;
     d.qrec = (const uint16_t*)t->d_qrec;
     d.qcolors = (const uint2*)t->d_qcolors;
     d.q_retain = quant ? quant->n_retain : 0;
@@ -711,7 +639,6 @@ void rto_tree_free(rto_tree* t) {
     if (t->d_child) (void)hipFree(t->d_child);
     if (t->d_nodew) (void)hipFree(t->d_nodew);
     if (t->d_topgrid) (void)hipFree(t->d_topgrid);
-    if (t->d_trav2) (void)hipFree(t->d_trav2);
     for (void* p : {t->d_qrec, t->d_qcolors, t->d_qsigma})
         if (p) (void)hipFree(p);
     delete t;
@@ -929,8 +856,6 @@ int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value) {
         return build_tile_tables(c);
     } else if (k == "refill") {
         c->refill = value;
-    } else if (k == "trav") {
-        c->trav = value != 0;
     } else if (k == "strip_rows") {
         if (value < 1) return set_err(RTO_E_INVALID, "strip_rows must be >= 1");
         c->strip_rows = value;
@@ -1157,7 +1082,7 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     if (ctx->kt_on && ctx->kt_count < kKtRing) ev = &ctx->kt_ev[(size_t)ctx->kt_count++ * 3];
     hipError_t e = rto::launch_render_batch(o->spp, tree->dev, od, fb, ctx->jump, ctx->queue,
                                             ctx->hits + (size_t)slot0 * o->spp * px,  // = fb.f[0].hits: the kernel indexes frames from here
-                                            ctx->num_cus, ctx->refill, ctx->trav, &ctx->occ, ev, stream);
+                                            ctx->num_cus, ctx->refill, &ctx->occ, ev, stream);
     if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("batched render launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
 }

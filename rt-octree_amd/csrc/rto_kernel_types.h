@@ -31,18 +31,6 @@ struct TreeDev {
     // above level G costs this one 8-byte, L2-resident load.  nullptr / 0 when absent.
     const uint2* topgrid;
     int top_levels;
-    // Header traversal image (render_persist; built on the host from the breadth-first tree, rto_abi.cpp
-    // build_trav2), u64 words in one buffer so that every visit is the same 8-byte load:
-    //   [0, hdr_off)            top grid: {slot | level << 27, 0x80000000 | sigma} for a leaf above node level G,
-    //                                     {node of level G | G << 27, 0} otherwise
-    //   [hdr_off, sig_off)      per node {first internal child, internal mask | non-zero-sigma mask << 8}; the
-    //                           internal children of a node are consecutive in slot order: child k =
-    //                           first + popcount(internal mask below bit k)
-    //   [sig_off, +2*capacity)  per node its 8 fp16 sigmas
-    // 8 B + 16 B per node instead of 32 B, and a step into a sibling leaf of the node whose header a lane
-    // already holds needs no load at all unless that leaf's sigma is non-zero.  nullptr when absent.
-    const uint2* trav2;
-    uint32_t hdr_off, sig_off;
     // Quantised tree rendered WITHOUT expansion (the inputs of n3tree.cpp:279-340):
     // `data` is nullptr; per leaf slot one record of q_rec u16 values, `qrec[slot * q_rec + ...]`:
     //   [3 * q_retain] fp16 retained coefficients, (basis k, channel c) at k * 3 + c

@@ -28,12 +28,11 @@ struct OccupancyCache {
     int blocks_per_cu = 0;
 };
 
-// trav: 1 = traverse the header image (TreeDev::trav2) when the tree has one, 0 = the per-slot image (nodew)
 // persistent batched renderer (N == 2 trees): fb.n frames in one launch (traversal kernel, then the
 // shading kernel); `queue` = kQueueWords u64 (zeroed on the stream before every launch); ev = nullptr or 3 events recorded before / between / after
 hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
-                               int refill, int trav, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream);
+                               int refill, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream);
 
 // quant_map [nq][ns] + data_retained [nr][ns][3] -> slot-major records of `rec` u16 (TreeDev::qrec)
 hipError_t launch_pack_quant(const uint16_t* qmap, const uint16_t* retained, int64_t ns, int nr, int nq, int rec,

@@ -1,0 +1,81 @@
+"""BASELINE.json configs[3] at size: 1920x1080, SPP 6, SH25 tree, GuidanceNet + filter, batched -- the shape of
+the TanksAndTemple Truck run (T&T intrinsics fx = fy = 1160, a close orbit).  Full frames cannot go through the
+CPU oracle in test time, so: size-independent properties of every pixel, bit-exact oracle spot pixels, batched ==
+frame loop, the denoised image against the oracle filter on the same maps."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+import rt_octree_amd as R
+from helpers import assert_bits_equal
+from rt_octree_amd import denoiser, synth
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def test_c4_1080p_sh25_denoised_batch():
+    W, H, spp = 1920, 1080, 6
+    tree = synth.make_tree(depth_limit=8, basis_dim=25, seed=13, shell=2.0, radius=1.12)
+    dt = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+    ht = orc.HostTree(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+    poses = synth.orbit_poses(8, radius=2.6)
+    cams = []
+    for p in poses[:3]:
+        c = R.Camera(W, H, 1160.0, 1160.0)
+        c.set_c2w(p)
+        cams.append(c)
+    opt = R.RenderOptions(spp=spp, denoise=True)
+    ctx = R.RenderContext(W, H, frames=3)
+    jumps = [100, 101, 102]
+    R.launch_renderer_batch(dt, cams, opt, ctx, rng_jumps=jumps)
+    # ---- every pixel: estimator properties
+    for f in range(3):
+        ctx.select_frame(f)
+        aux = ctx.download_aux()
+        noisy = ctx.download_image(noisy=True)
+        a6 = aux[3] * spp
+        assert np.all(np.abs(a6 - np.round(a6)) < 1e-5) and aux[3].min() >= 0 and aux[3].max() <= 1
+        assert np.array_equal(aux[4:], aux[:4] * aux[:4])
+        assert np.all(noisy[..., 3] == 1.0) and np.all(noisy[..., :3][aux[3] == 0] == 1.0)
+        assert np.array_equal(noisy[..., :3], np.moveaxis(aux[:3], 0, -1))
+        assert (aux[3] > 0).mean() > 0.2  # the close orbit fills a good part of the frame
+        # ---- oracle spot pixels (bit-exact), spread over the frame incl. its corners
+        rs = np.random.RandomState(f)
+        idxs = list(rs.randint(0, W * H, 96)) + [0, W - 1, (H - 1) * W, H * W - 1, (H // 2) * W + W // 2]
+        ocam = orc.camera(W, H, 1160.0, 1160.0, cams[f].transform.reshape(-1))
+        oopt = orc.default_options(spp=spp)
+        base = orc.rng(frame=jumps[f])
+        for idx in idxs:
+            a8, rgba = (C.c_float * 8)(), (C.c_float * 4)()
+            assert orc.lib().orc_render_pixel(C.byref(ht.c), C.byref(ocam), C.byref(oopt), C.byref(base), int(idx), a8, rgba, None) == 0
+            y, x = divmod(int(idx), W)
+            assert_bits_equal(aux[:, y, x], np.array(a8[:], np.float32), "frame %d pixel %d" % (f, idx))
+    # ---- batched == the reference's frame loop (one launch per frame, rng.advance in between)
+    one = R.RenderContext(W, H)
+    one.rng_seed()
+    one.rng_advance(jumps[1] << 32)
+    R.launch_renderer(dt, cams[1], opt, one)
+    ctx.select_frame(1)
+    assert_bits_equal(one.download_aux(), ctx.download_aux(), "frame loop vs batch")
+    # ---- denoise: fused GuidanceNet -> exact filter == the oracle filter on the same maps; factorised within 1e-5
+    torch.manual_seed(0)
+    net = denoiser.FusedGuidanceNet(denoiser.GuidanceNetCompact.from_full(denoiser.GuidanceNet(8, 32, 5, 2, 4)).eval())
+    aux_t = torch.as_tensor(ctx.batch_views()[0], device="cuda:0")
+    wm, gm = net(aux_t[:3])
+    ctx.select_frame(0)
+    R.filtering(None, wm, gm, ctx.noisy_ptr, ctx.image_ptr)  # all three frames, one launch
+    torch.cuda.synchronize()
+    ctx.select_frame(2)
+    exact = ctx.download_image()
+    ref = orc.filter_levels(wm[2].cpu().numpy(), gm[2].cpu().numpy(), ctx.download_image(noisy=True))
+    assert_bits_equal(exact, ref, "exact filter vs oracle at 1080p")
+    ctx.select_frame(0)
+    R.filtering(None, wm, gm, ctx.noisy_ptr, ctx.image_ptr, mode=R.FILTER_FAST)
+    torch.cuda.synchronize()
+    ctx.select_frame(2)
+    fast = ctx.download_image()
+    assert np.allclose(fast[..., :3], exact[..., :3], rtol=2e-5, atol=2e-6)
+    assert np.all((exact[..., :3] >= -1e-6) & (exact[..., :3] <= 1 + 1e-5))

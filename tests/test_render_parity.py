@@ -101,10 +101,8 @@ def test_node_order_never_changes_pixels(small_tree_sh9):
         assert_bits_equal(aux_h, aux_o, "aux")
         assert_bits_equal(rgba_h, rgba_o, "rgba")
     ctx = R.RenderContext(72, 64, frames=1)
-    for trav in (1, 0):
-        ctx.set_tuning("trav", trav)
-        R.launch_renderer_batch(dts, [cam], R.RenderOptions(spp=6, denoise=False), ctx)
-        assert_bits_equal(ctx.download_aux(), aux_o, "batched aux, trav %d" % trav)
+    R.launch_renderer_batch(dts, [cam], R.RenderOptions(spp=6, denoise=False), ctx)
+    assert_bits_equal(ctx.download_aux(), aux_o, "batched aux")
 
 
 def test_batched_launch_on_a_tree_without_traversal_image():
@@ -136,21 +134,19 @@ def test_batched_launch_on_a_tree_without_traversal_image():
 
 
 @pytest.mark.parametrize("depth,basis", [(1, 4), (2, 4), (3, 9), (8, 9)])
-def test_header_traversal_on_shallow_and_deep_trees(depth, basis):
-    """the header image without a top grid (depth < 3), with a shallow grid, and on a deeper tree; SPP 1 and 32;
-    a negative sigma_thresh makes even zero-density leaves candidates for a hit"""
+def test_batched_path_on_shallow_and_deep_trees(depth, basis):
+    """no top grid (depth < 3), a shallow grid, a deeper tree; SPP 1 and 32; a negative sigma_thresh makes even
+    zero-density leaves candidates for a hit"""
     tree = synth.make_tree(depth_limit=depth, basis_dim=basis, seed=depth)
     ht, dt = make_pair(tree)
     ocam, cam = cameras(56, 40, POSES[3])
     ctx = R.RenderContext(56, 40, frames=2)
     for spp, kw in ((1, {}), (32, {}), (4, {"sigma_thresh": -1.0})):
         want = oracle_frame(ht, ocam, spp, frame=1, **kw)[0]
-        for trav in (1, 0):
-            ctx.set_tuning("trav", trav)
-            ctx.rng_seed()
-            R.launch_renderer_batch(dt, [cam, cam], R.RenderOptions(spp=spp, denoise=False, **kw), ctx, rng_jumps=[4, 1])
-            ctx.select_frame(1)
-            assert_bits_equal(ctx.download_aux(), want, "depth %d spp %d trav %d" % (depth, spp, trav))
+        ctx.rng_seed()
+        R.launch_renderer_batch(dt, [cam, cam], R.RenderOptions(spp=spp, denoise=False, **kw), ctx, rng_jumps=[4, 1])
+        ctx.select_frame(1)
+        assert_bits_equal(ctx.download_aux(), want, "depth %d spp %d" % (depth, spp))
 
 
 def test_camera_inside_box_and_miss(small_tree_sh9):
@@ -336,8 +332,8 @@ def test_batched_kernel_full_size_matches_fast(small_tree_sh9):
 
 def test_queue_tuning_never_changes_results(small_tree_sh16):
     """rto_ctx_set_tuning: single queue / one queue per XCD, frame- / tile-major order, row-major /
-    centre-out / wedge tile tables of any block size, refill thresholds, per-slot or header traversal image
-    -- which wave renders which ray when, and from which derived image of the tree, is free; the pixels are not."""
+    centre-out / wedge tile tables of any block size, refill thresholds -- which wave renders which ray
+    when is free, the pixels are not."""
     ht, dt = make_pair(small_tree_sh16)
     W, H = 132, 76  # ragged vs the 8x8 ray tiles and vs the 4x4-tile blocks
     cams, want = [], []
@@ -348,8 +344,7 @@ def test_queue_tuning_never_changes_results(small_tree_sh16):
     ctx = R.RenderContext(W, H, frames=3)
     settings = [{"xcd_queues": 0, "tile_order": 0}, {"xcd_queues": 0, "tile_order": 1, "tile_major": 0},
                 {"xcd_queues": 1, "tile_major": 1, "tile_block": 1}, {"tile_block": 3}, {"tile_block": 64},
-                {"tile_block": 4, "refill": 808}, {"refill": 816}, {"refill": 432}, {"refill": 0},
-                {"trav": 0}, {"trav": 1, "xcd_queues": 0}, {"trav": 1, "xcd_queues": 1}]
+                {"tile_block": 4, "refill": 808}, {"refill": 816}, {"refill": 432}, {"refill": 0}]
     for kv in settings:
         for k, v in kv.items():
             ctx.set_tuning(k, v)

@@ -315,7 +315,7 @@ def main():
             ev[1].record(lstream)
         if denoise:
             with torch.no_grad(), torch.cuda.stream(lstream):
-                wm, gm = lnet(laux[:n], stream=lstream) if not args.torch_net else lnet(laux[:n])
+                wm, gm = lnet(laux[:n], stream=lstream, squares_implied=True) if not args.torch_net else lnet(laux[:n])
             if ev:
                 ev[2].record(lstream)
             lctx.select_frame(0)
@@ -388,7 +388,7 @@ def main():
             evs[1].record(stream)
             if denoise:
                 with torch.no_grad():
-                    wm, gm = net(one_aux[:1], stream=stream) if not args.torch_net else net(one_aux[:1])
+                    wm, gm = net(one_aux[:1], stream=stream, squares_implied=True) if not args.torch_net else net(one_aux[:1])
                 evs[2].record(stream)
                 one.select_frame(0)
                 R.filtering(stream, wm, gm, one.noisy_ptr, one.image_ptr, mode=filter_mode)

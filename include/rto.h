@@ -261,6 +261,12 @@ int rto_guidance_net_create(const float* w1, const float* b1, const float* w2, c
 /* aux: device [n][8][H][W] fp32; outputs: device [n][levels][H][W] fp32 (weight_map, guidance_map) */
 int rto_guidance_net_forward(const rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W,
                              float* weight_map, float* guidance_map);
+/* flags: RTO_NET_AUX_SQUARES_IMPLIED -- the caller guarantees that aux planes 4..7 are the fp32 squares of planes
+ * 0..3, which is how the renderer fills them (volrend.cu:195-202); the kernel then reads planes 0..3 only and
+ * squares them itself: the same values from half the bytes.  Results are bit-identical to flags = 0 on such input. */
+#define RTO_NET_AUX_SQUARES_IMPLIED 1
+int rto_guidance_net_forward_ex(const rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W,
+                                float* weight_map, float* guidance_map, int flags);
 void rto_guidance_net_free(rto_guidance_net* net);
 
 /* ---- profiling aid ---- */

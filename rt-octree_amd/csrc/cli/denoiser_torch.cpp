@@ -135,8 +135,9 @@ void TorchDenoiser::forward(float* aux, int n, int H, int W, const float** weigh
             impl_->weight = torch::empty({n, L, H, W}, options);
             impl_->guidance = torch::empty({n, L, H, W}, options);
         }
-        if (rto_guidance_net_forward(impl_->fused, nullptr, aux, n, H, W, impl_->weight.data_ptr<float>(),
-                                     impl_->guidance.data_ptr<float>()) != RTO_OK)
+        // aux is the renderer's buffer: planes 4..7 are the squares of planes 0..3
+        if (rto_guidance_net_forward_ex(impl_->fused, nullptr, aux, n, H, W, impl_->weight.data_ptr<float>(),
+                                        impl_->guidance.data_ptr<float>(), RTO_NET_AUX_SQUARES_IMPLIED) != RTO_OK)
             throw std::runtime_error(std::string("fused GuidanceNet failed: ") + rto_last_error());
         *weight = impl_->weight.data_ptr<float>();
         *guidance = impl_->guidance.data_ptr<float>();

@@ -366,6 +366,18 @@ __global__ void __launch_bounds__(256, 3) filter_fast(const float* __restrict__ 
     const int lx = tid & (kFastW - 1), ry = tid / kFastW;  // column, row group
     const int px = blockIdx.x * kFastW + lx, py0 = blockIdx.y * kFastH + ry * kFastRows;
     const int base = (ry * kFastRows + L) * SW + lx + L;     // staged index of this thread's first output
+    // every level's guidance values of this thread's staged elements and its outputs' weights, requested up
+    // front: one exposed memory latency per tile instead of one per level
+    float gv_all[L][PER];
+    float wl_all[L][kFastRows];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) gv_all[l][i] = gidx[i] >= 0 ? guidance[l * HW + gidx[i]] : 0.f;
+#pragma unroll
+        for (int r = 0; r < kFastRows; ++r)
+            wl_all[l][r] = (px < W && py0 + r < H) ? weight[l * HW + (int64_t)(py0 + r) * W + px] : 0.f;
+    }
     float o[kFastRows][3];
 #pragma unroll
     for (int r = 0; r < kFastRows; ++r) o[r][0] = o[r][1] = o[r][2] = 0.f;
@@ -373,11 +385,10 @@ __global__ void __launch_bounds__(256, 3) filter_fast(const float* __restrict__ 
     auto level = [&](auto l_tag) {
         constexpr int l = decltype(l_tag)::value;
         // ---- tile maximum / minimum of g_l over the image pixels of the staged tile
-        float gv[PER];
         float mx = -3.402823466e+38f, mn = 3.402823466e+38f;
+        const float(&gv)[PER] = gv_all[l];
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            gv[i] = gidx[i] >= 0 ? guidance[l * HW + gidx[i]] : 0.f;
             if (gidx[i] >= 0) {
                 mx = fmaxf(mx, gv[i]);
                 mn = fminf(mn, gv[i]);
@@ -408,10 +419,7 @@ __global__ void __launch_bounds__(256, 3) filter_fast(const float* __restrict__ 
             }
         }
         __syncthreads();  // P_l complete (and s_red may be rewritten)
-        float wl[kFastRows];
-#pragma unroll
-        for (int r = 0; r < kFastRows; ++r)
-            wl[r] = (px < W && py0 + r < H) ? weight[l * HW + (int64_t)(py0 + r) * W + px] : 0.f;
+        const float(&wl)[kFastRows] = wl_all[l];
         if (!wide) {
             float4 acc[kFastRows];
             box_rows<l + 1, SW>(s_p, base, acc);  // support S = l + 1

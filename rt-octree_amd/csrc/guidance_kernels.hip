@@ -41,7 +41,10 @@ constexpr int kCIn = 8;           // aux channels (render_context.hpp:23)
 __device__ __forceinline__ float relu6(float x) { return fminf(fmaxf(x, 0.f), 6.f); }
 
 // C1 = mid channels (multiple of 16, <= 64), L = kernel levels (2L <= 16)
-template <int C1, int L>
+// SQ: the aux planes 4..7 are the squares of planes 0..3 (what the renderer writes, volrend.cu:195-202:
+// a[4 + c] = out[c] * out[c], one fp32 multiply): read only planes 0..3 and square them here -- the same fp32
+// product, so the same fp16 inputs, from half the bytes.
+template <int C1, int L, bool SQ>
 __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ aux,    // [n][8][H][W]
                                                        const _Float16* __restrict__ w1,  // [C1][96]   k = tap*8 + ci
                                                        const float* __restrict__ b1,     // [C1]
@@ -99,9 +102,13 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
             const bool in = e < NPIX && gx >= 0 && gx < W && gy >= 0 && gy < H;
             const int64_t gi = in ? (int64_t)gy * W + gx : 0;
 #pragma unroll
-            for (int c = 0; c < kCIn; ++c) {
+            for (int c = 0; c < (SQ ? kCIn / 2 : kCIn); ++c) {
                 const float t = aux[c * HW + gi];
                 v[it][c] = in ? t : 0.f;
+            }
+            if (SQ) {
+#pragma unroll
+                for (int c = 0; c < kCIn / 2; ++c) v[it][kCIn / 2 + c] = v[it][c] * v[it][c];
             }
         }
 #pragma unroll
@@ -211,11 +218,15 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
 
 hipError_t launch_guidance_net(const float* aux, const void* w1, const float* b1, const void* w2, const float* b2, int c1,
                                int levels, int n, int H, int W, float* weight_out, float* guidance_out,
-                               hipStream_t stream) {
+                               bool squares_implied, hipStream_t stream) {
     if (c1 != 32 || levels != 4) return hipErrorInvalidValue;  // the reference configuration (blender.txt:21-25)
     const dim3 grid((W + kGW - 1) / kGW, (H + kGH - 1) / kGH, n), block(256);
-    hipLaunchKernelGGL((guidance_fused<32, 4>), grid, block, 0, stream, aux, (const _Float16*)w1, b1, (const _Float16*)w2, b2,
-                       weight_out, guidance_out, H, W);
+    if (squares_implied)
+        hipLaunchKernelGGL((guidance_fused<32, 4, true>), grid, block, 0, stream, aux, (const _Float16*)w1, b1,
+                           (const _Float16*)w2, b2, weight_out, guidance_out, H, W);
+    else
+        hipLaunchKernelGGL((guidance_fused<32, 4, false>), grid, block, 0, stream, aux, (const _Float16*)w1, b1,
+                           (const _Float16*)w2, b2, weight_out, guidance_out, H, W);
     return hipGetLastError();
 }
 

@@ -83,11 +83,17 @@ int rto_guidance_net_create(const float* w1, const float* b1, const float* w2, c
 
 int rto_guidance_net_forward(const rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W,
                              float* weight_map, float* guidance_map) {
+    return rto_guidance_net_forward_ex(net, stream, aux, n, H, W, weight_map, guidance_map, 0);
+}
+
+int rto_guidance_net_forward_ex(const rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W,
+                                float* weight_map, float* guidance_map, int flags) {
     if (!net || !aux || !weight_map || !guidance_map || n < 1 || H < 1 || W < 1)
         return fail(RTO_E_INVALID, "rto_guidance_net_forward: bad argument");
     DeviceScope scope(net->device);
     const hipError_t e = rto::launch_guidance_net(aux, net->w1, net->b1, net->w2, net->b2, net->c1, net->levels, n, H, W,
-                                                  weight_map, guidance_map, (hipStream_t)stream);
+                                                  weight_map, guidance_map, (flags & RTO_NET_AUX_SQUARES_IMPLIED) != 0,
+                                                  (hipStream_t)stream);
     if (e != hipSuccess) return fail(RTO_E_HIP, std::string("GuidanceNet launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
 }

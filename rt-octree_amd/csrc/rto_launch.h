@@ -62,6 +62,6 @@ hipError_t launch_filter_backward(const float* grad_out, const float* img_in, co
 // fused compact GuidanceNet (guidance_kernels.hip): w1 fp16 [c1][96], w2 fp16 [16][9*c1], b2 [16]
 hipError_t launch_guidance_net(const float* aux, const void* w1, const float* b1, const void* w2, const float* b2, int c1,
                                int levels, int n, int H, int W, float* weight_out, float* guidance_out,
-                               hipStream_t stream);
+                               bool squares_implied, hipStream_t stream);
 
 }  // namespace rto

@@ -190,7 +190,9 @@ class FusedGuidanceNet:
         self._h = h
         self._out = {}
 
-    def __call__(self, aux, stream=None):
+    def __call__(self, aux, stream=None, squares_implied=False):
+        """squares_implied: aux planes 4..7 are the fp32 squares of planes 0..3 (the renderer's aux buffer): the
+        kernel reads half the bytes, results are bit-identical"""
         from ._lib import check, lib
         n, c, H, W = aux.shape
         assert c == 8 and aux.dtype == torch.float32 and aux.is_contiguous()
@@ -200,7 +202,8 @@ class FusedGuidanceNet:
                               torch.empty((n, self.levels, H, W), device=self.device))
         wm, gm = self._out[key]
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
-        check(lib().rto_guidance_net_forward(self._h, V._stream_ptr(s), aux.data_ptr(), n, H, W, wm.data_ptr(), gm.data_ptr()))
+        check(lib().rto_guidance_net_forward_ex(self._h, V._stream_ptr(s), aux.data_ptr(), n, H, W, wm.data_ptr(), gm.data_ptr(),
+                                                1 if squares_implied else 0))
         return wm, gm
 
     def __del__(self):

@@ -74,3 +74,21 @@ def test_denoised_image_psnr():
         outs.append(out.cpu().numpy())
     mse = np.mean((outs[0][..., :3].astype(np.float64) - outs[1][..., :3]) ** 2)
     assert -10 * np.log10(mse) > 50.0
+
+
+@pytest.mark.parametrize("shape", [(2, 37, 53), (1, 64, 96)])
+def test_squares_implied_reads_half_the_input_bit_identically(shape):
+    """RTO_NET_AUX_SQUARES_IMPLIED: the renderer's aux planes 4..7 are the fp32 squares of planes 0..3; the kernel
+    may square them itself instead of reading them -- same fp32 products, same fp16 inputs, same maps."""
+    n, H, W = shape
+    _, fused = _nets(3)
+    torch.manual_seed(4)
+    aux = torch.rand(n, 8, H, W)
+    aux[:, 4:] = aux[:, :4] * aux[:, :4]
+    dev_aux = aux.cuda().contiguous()
+    w0, g0 = (t.clone() for t in fused(dev_aux))
+    poisoned = dev_aux.clone()
+    poisoned[:, 4:] = 123.0  # must not be read in the implied mode
+    w1, g1 = fused(poisoned, squares_implied=True)
+    torch.cuda.synchronize()
+    assert torch.equal(w0, w1) and torch.equal(g0, g1)

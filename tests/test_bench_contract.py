@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_line_has_the_contract_fields():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--batch", "4", "--size", "160",
-           "--depth", "6", "--cpu-frames", "1", "--psnr-frames", "2"]
+           "--depth", "6", "--cpu-frames", "1", "--psnr-frames", "2", "--ref-loop-frames", "4"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -30,8 +30,34 @@ def test_bench_line_has_the_contract_fields():
         assert k in rf, k
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
-    assert rf["traffic"] is None  # counter passes exist for the default workload only
+    assert rf["traffic"] is None and "ALGORITHMIC" in rf["basis"]  # counter passes exist for the BASELINE workloads only
+    for k in ("algorithmic_gbps", "algorithmic_frac", "avg_launch_ms", "frames_per_launch", "tcp"):
+        assert k in rf, k
+    assert d["config"]["frames_per_launch"] == rf["frames_per_launch"] == 3.0  # 6 steps in groups of <= 4: the actual value
+    rl = d["reference_loop"]
+    assert rl["batch"] == 1 and rl["fps"] > 0 and rl["render_ms"] > 0 and rl["fps"] < d["reference_timer"]["fps"] * 1.5
+    assert d["psnr"]["factorised_vs_exact_filter_db"] > 100.0
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+
+
+def test_counter_based_roofline_for_the_baseline_workloads():
+    """profiles/pmc_traffic.json (what bench.py reads for `roofline.achieved`): counter passes for c2 / c5 / c4 and the
+    gather ceilings; the counter-based HBM fraction of the default workload is far below the algorithmic one."""
+    doc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert set(doc["workloads"]) >= {"c2", "c5", "c4"}
+    for w in doc["workloads"].values():
+        for k in ("frames_per_launch", "fetch_bytes", "write_bytes", "tcp_line_accesses", "tcp_tcc_read_req", "tcc_hit",
+                  "tcc_miss", "kernel_clocks"):
+            assert w[k] > 0, k
+    ce = doc["ceilings"]
+    assert 0 < ce["mall_lines_per_clk"] < ce["l2_lines_per_clk"] < ce["l1_hit_lines_per_clk"] < 4
+    sys.path.insert(0, ROOT)
+    import bench
+    args = bench.parse_args([])
+    assert bench.workload_id(args, 800, 800) == "c2"
+    assert bench.workload_id(bench.parse_args(["--spp", "1", "--no-denoise"]), 800, 800) == "c5"
+    assert bench.workload_id(bench.parse_args(["--c4"]), 1920, 1080) == "c4"
+    assert bench.workload_id(bench.parse_args(["--shuffle-nodes", "1"]), 800, 800) is None

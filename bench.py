@@ -92,6 +92,9 @@ def parse_args(argv=None):
     ap.add_argument("--plan-only", action="store_true",
                     help="no GPU work: join the process group (gloo), print every rank's frame plan as JSON and exit -- "
                          "pins the rank / scene / pose / RNG-jump bookkeeping of a multi-GPU run on a CPU box")
+    ap.add_argument("--fp32-maps", action="store_true",
+                    help="hand the GuidanceNet maps to the factorised filter as fp32 planes (the reference's tensors) instead "
+                         "of the packed fp16 values the network actually produces: same pixels, twice the bytes")
     ap.add_argument("--exact-filter", action="store_true",
                     help="run the bit-exact guided filter (164 exps per pixel) instead of the factorised one")
     args = ap.parse_args(argv)
@@ -295,6 +298,8 @@ def main():
         lanes.append((c2, torch.cuda.Stream(dev), n2, torch.as_tensor(c2.batch_views()[0], device=dev)))
 
     filter_mode = R.FILTER_EXACT if args.exact_filter else R.FILTER_FAST
+    # fused GuidanceNet + factorised filter: keep the maps in fp16 between the two kernels (same pixels, half the bytes)
+    packed_route = denoise and not args.torch_net and not args.exact_filter and not args.fp32_maps
 
     def frame_of(step, scene_map):  # (scene, pose) of this rank's `step`-th frame
         return pose_schedule(step, rank, world, len(poses), n_scenes, scene_map)
@@ -314,12 +319,18 @@ def main():
         if ev:
             ev[1].record(lstream)
         if denoise:
-            with torch.no_grad(), torch.cuda.stream(lstream):
-                wm, gm = lnet(laux[:n], stream=lstream, squares_implied=True) if not args.torch_net else lnet(laux[:n])
-            if ev:
-                ev[2].record(lstream)
             lctx.select_frame(0)
-            R.filtering(lstream, wm, gm, lctx.noisy_ptr, lctx.image_ptr, mode=filter_mode)
+            if packed_route:  # GuidanceNet -> fp16 maps in the handle's scratch -> factorised filter
+                lnet.forward_packed(laux[:n], stream=lstream, squares_implied=True)
+                if ev:
+                    ev[2].record(lstream)
+                lnet.filter_packed(lctx.noisy_ptr, lctx.image_ptr, stream=lstream)
+            else:
+                with torch.no_grad(), torch.cuda.stream(lstream):
+                    wm, gm = lnet(laux[:n], stream=lstream, squares_implied=True) if not args.torch_net else lnet(laux[:n])
+                if ev:
+                    ev[2].record(lstream)
+                R.filtering(lstream, wm, gm, lctx.noisy_ptr, lctx.image_ptr, mode=filter_mode)
             if ev:
                 ev[3].record(lstream)
 
@@ -387,11 +398,16 @@ def main():
             R.launch_renderer(trees[sc], cams[i], opt, one, stream)
             evs[1].record(stream)
             if denoise:
-                with torch.no_grad():
-                    wm, gm = net(one_aux[:1], stream=stream, squares_implied=True) if not args.torch_net else net(one_aux[:1])
-                evs[2].record(stream)
                 one.select_frame(0)
-                R.filtering(stream, wm, gm, one.noisy_ptr, one.image_ptr, mode=filter_mode)
+                if packed_route:
+                    net.forward_packed(one_aux[:1], stream=stream, squares_implied=True)
+                    evs[2].record(stream)
+                    net.filter_packed(one.noisy_ptr, one.image_ptr, stream=stream)
+                else:
+                    with torch.no_grad():
+                        wm, gm = net(one_aux[:1], stream=stream, squares_implied=True) if not args.torch_net else net(one_aux[:1])
+                    evs[2].record(stream)
+                    R.filtering(stream, wm, gm, one.noisy_ptr, one.image_ptr, mode=filter_mode)
                 evs[3].record(stream)
             (evs[3] if denoise else evs[1]).synchronize()  # Timer::record: the host waits for every frame
             if k >= 0:
@@ -615,7 +631,7 @@ def main():
                            "scene s -> rank s mod N" if (maps[0] == "scene" and n_scenes > 1) else "frame g -> rank g mod N"),
             "tree_nodes": int(tree.capacity), "tree_device_mb": tree.device_bytes / 1e6,
             "frames_per_launch": frames_per_launch, "frames_per_launch_cap": B, "streams": len(lanes),
-            "scenes": n_scenes, "scene_map": maps[0], "filter": "exact" if args.exact_filter else "factorised",
+            "scenes": n_scenes, "scene_map": maps[0], "filter": "exact" if args.exact_filter else "factorised", "maps": "fp16 packed" if packed_route else "fp32 planes",
             "parallelism": "frames x%d" % world,
         },
         "reference_timer": {  # Timer::report formula (render_context.hpp:190-206), rank 0, per frame

@@ -267,6 +267,15 @@ int rto_guidance_net_forward(const rto_guidance_net* net, void* stream, const fl
 #define RTO_NET_AUX_SQUARES_IMPLIED 1
 int rto_guidance_net_forward_ex(const rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W,
                                 float* weight_map, float* guidance_map, int flags);
+/* The denoise stage (Denoiser::denoise, denoiser.cpp:31-61) as two launches that keep the maps in their native
+ * precision: _forward_packed runs the network and leaves its 8 output channels as fp16 (4 softmax logits + 4
+ * guidance values per pixel, [n][H][W][8], in a scratch buffer the handle owns) -- the reference's `.float()` only
+ * widens those values; rto_filtering_packed then runs the factorised filter (RTO_FILTER_FACTORISED) on them, taking
+ * the softmax itself: img_in / img_out [n][H][W][4] fp32.  Output = rto_guidance_net_forward_ex +
+ * rto_filtering_batch_mode(FACTORISED) bit for bit, from half the map bytes.  Same stream for both calls; one
+ * handle per stream at a time. */
+int rto_guidance_net_forward_packed(rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W, int flags);
+int rto_filtering_packed(const rto_guidance_net* net, void* stream, const float* img_in, float* img_out);
 void rto_guidance_net_free(rto_guidance_net* net);
 
 /* ---- profiling aid ---- */

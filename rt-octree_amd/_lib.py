@@ -97,6 +97,8 @@ SYMBOLS = {
     "rto_guidance_net_create": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "rto_guidance_net_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rto_guidance_net_forward_ex": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int]),
+    "rto_guidance_net_forward_packed": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rto_filtering_packed": (C.c_int, [_P, _P, _P, _P]),
     "rto_guidance_net_free": (None, [_P]),
     "rto_probe_gather": (C.c_int, [C.c_uint64, C.c_int]),
     "rto_probe_gather_sweep": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

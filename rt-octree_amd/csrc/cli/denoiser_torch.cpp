@@ -125,6 +125,7 @@ TorchDenoiser::~TorchDenoiser() {
 }
 
 bool TorchDenoiser::fused() const { return impl_->fused != nullptr; }
+rto_guidance_net* TorchDenoiser::fused_handle() const { return impl_->fused; }
 
 void TorchDenoiser::forward(float* aux, int n, int H, int W, const float** weight, const float** guidance, int* levels) {
     torch::NoGradGuard no_grad;

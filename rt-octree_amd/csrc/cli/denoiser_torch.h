@@ -6,6 +6,8 @@
 #include <memory>
 #include <string>
 
+struct rto_guidance_net;
+
 namespace rto {
 
 class TorchDenoiser {
@@ -19,6 +21,8 @@ public:
     TorchDenoiser(const std::string& ts_module_path, int device, bool use_fused = true);
     ~TorchDenoiser();
     bool fused() const;
+    // the fused kernel's handle (include/rto.h rto_guidance_net_*), or nullptr on the libtorch path
+    rto_guidance_net* fused_handle() const;
 
     // aux: device pointer to [n,8,H,W] fp32 (zero-copy from_blob).  On return *weight / *guidance point
     // at contiguous device tensors [n,L,H,W] that stay alive until the next call.

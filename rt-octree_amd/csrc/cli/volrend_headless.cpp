@@ -250,17 +250,28 @@ int main(int argc, char** argv) {
     cam.fy = fy;
     void* stream = nullptr;  // the default stream: libtorch's current stream in this process
 
-    auto denoise = [&]() -> int {  // Denoiser::denoise denoiser.cpp:31-61
+    // Denoiser::denoise (denoiser.cpp:31-61) for the n frames in context slots 0..n-1 (the selected slot must be 0 for
+    // n > 1).  Fused network + --fast_filter: the maps stay packed fp16 between the two kernels (same pixels as fp32 maps).
+    auto denoise_n = [&](int n, bool timed) -> int {
         const float *w = nullptr, *g = nullptr;
         int L = 0;
-        rto_timer_start(ctx, RTO_T_TORCH);
-        denoiser->forward(rto_ctx_aux(ctx), 1, height, width, &w, &g, &L);
-        rto_timer_stop(ctx, RTO_T_TORCH);
-        rto_timer_start(ctx, RTO_T_FILTER);
-        const int rc = rto_filtering_batch_mode(stream, w, g, L, height, width, 1, rto_ctx_noisy(ctx), rto_ctx_image(ctx), filter_mode);
-        rto_timer_stop(ctx, RTO_T_FILTER);
+        int rc = RTO_OK;
+        if (timed) rto_timer_start(ctx, RTO_T_TORCH);
+        const bool packed = denoiser->fused() && filter_mode == RTO_FILTER_FACTORISED;
+        if (packed)
+            rc = rto_guidance_net_forward_packed(denoiser->fused_handle(), stream, rto_ctx_aux(ctx), n, height, width,
+                                                 RTO_NET_AUX_SQUARES_IMPLIED);
+        else
+            denoiser->forward(rto_ctx_aux(ctx), n, height, width, &w, &g, &L);
+        if (timed) rto_timer_stop(ctx, RTO_T_TORCH);
+        if (rc != RTO_OK) return rc;
+        if (timed) rto_timer_start(ctx, RTO_T_FILTER);
+        rc = packed ? rto_filtering_packed(denoiser->fused_handle(), stream, rto_ctx_noisy(ctx), rto_ctx_image(ctx))
+                    : rto_filtering_batch_mode(stream, w, g, L, height, width, n, rto_ctx_noisy(ctx), rto_ctx_image(ctx), filter_mode);
+        if (timed) rto_timer_stop(ctx, RTO_T_FILTER);
         return rc;
     };
+    auto denoise = [&]() -> int { return denoise_n(1, true); };
 
     // Warm up (main_headless.cpp:469-479): pose 0, every iteration advances the RNG
     rto_timer_reset(ctx, stream);
@@ -278,12 +289,7 @@ int main(int argc, char** argv) {
         const int shapes[2] = {(int)std::min<size_t>((size_t)batch, n_mine), (int)(n_mine % (size_t)batch)};
         for (int n : shapes) {
             if (n < 1) continue;
-            for (int rep = 0; rep < 3; ++rep) {
-                const float *w = nullptr, *g = nullptr;
-                int L = 0;
-                denoiser->forward(rto_ctx_aux(ctx), n, height, width, &w, &g, &L);
-                CHECK_RTO(rto_filtering_batch_mode(stream, w, g, L, height, width, n, rto_ctx_noisy(ctx), rto_ctx_image(ctx), filter_mode));
-            }
+            for (int rep = 0; rep < 3; ++rep) CHECK_RTO(denoise_n(n, false));
         }
     }
     rto_timer_reset(ctx, stream);
@@ -314,16 +320,7 @@ int main(int argc, char** argv) {
             rto_timer_start(ctx, RTO_T_RENDER);
             CHECK_RTO(rto_launch_renderer_batch(tree, cams.data(), jumps.data(), n, &options, ctx, stream));
             rto_timer_stop(ctx, RTO_T_RENDER);
-            if (options.denoise) {
-                const float *w = nullptr, *gd = nullptr;
-                int L = 0;
-                rto_timer_start(ctx, RTO_T_TORCH);
-                denoiser->forward(rto_ctx_aux(ctx), n, height, width, &w, &gd, &L);
-                rto_timer_stop(ctx, RTO_T_TORCH);
-                rto_timer_start(ctx, RTO_T_FILTER);
-                CHECK_RTO(rto_filtering_batch_mode(stream, w, gd, L, height, width, n, rto_ctx_noisy(ctx), rto_ctx_image(ctx), filter_mode));
-                rto_timer_stop(ctx, RTO_T_FILTER);
-            }
+            if (options.denoise) CHECK_RTO(denoise_n(n, true));
             CHECK_RTO(rto_timer_record(ctx, options.denoise));
             rendered += (size_t)n;
             if (out_dir.empty()) continue;

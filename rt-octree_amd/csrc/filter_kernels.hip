@@ -303,14 +303,18 @@ RTO_DEV void box_rows(const float4* __restrict__ s_p, int base, float4 (&acc)[kF
 
 // a level of filter_fast for a tile whose guidance range would underflow the factorised exponentials:
 // per-pixel maximum as in the exact form, taps from global memory (rare, slow, correct)
-__device__ __noinline__ float4 filter_level_wide(const float* __restrict__ g, const float4* __restrict__ img_in, int S, int H,
-                                                 int W, int px, int py, float w) {
+// (half_stride != 0: g points at fp16 values half_stride halves apart -- the packed maps)
+__device__ __noinline__ float4 filter_level_wide(const float* __restrict__ g_, const float4* __restrict__ img_in, int S, int H,
+                                                 int W, int px, int py, float w, int half_stride) {
     if (px >= W || py >= H) return make_float4(0.f, 0.f, 0.f, 0.f);
+    auto g = [&](int64_t i) -> float {
+        return half_stride ? (float)reinterpret_cast<const _Float16*>(g_)[i * half_stride] : g_[i];
+    };
     float m = -3.402823466e+38f;
     for (int dy = -S; dy <= S; ++dy)
         for (int dx = -S; dx <= S; ++dx) {
             const int qx = px + dx, qy = py + dy;
-            if (qx >= 0 && qx < W && qy >= 0 && qy < H) m = fmaxf(m, g[(int64_t)qy * W + qx]);
+            if (qx >= 0 && qx < W && qy >= 0 && qy < H) m = fmaxf(m, g((int64_t)qy * W + qx));
         }
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, ks = 0.f;
     for (int dy = -S; dy <= S; ++dy)
@@ -318,7 +322,7 @@ __device__ __noinline__ float4 filter_level_wide(const float* __restrict__ g, co
             const int qx = px + dx, qy = py + dy;
             if (qx >= 0 && qx < W && qy >= 0 && qy < H) {
                 const int64_t qi = (int64_t)qy * W + qx;
-                const float k = __builtin_amdgcn_exp2f((g[qi] - m) * 1.44269504088896340736f);
+                const float k = __builtin_amdgcn_exp2f((g(qi) - m) * 1.44269504088896340736f);
                 const float4 t = img_in[qi];
                 a0 += k * t.x;
                 a1 += k * t.y;
@@ -330,7 +334,11 @@ __device__ __noinline__ float4 filter_level_wide(const float* __restrict__ g, co
     return make_float4(a0 * ww, a1 * ww, a2 * ww, 0.f);
 }
 
-template <int L>
+// PACKED (L = 4): the maps arrive as the GuidanceNet kernel's packed output, fp16 [n][H][W][8] = 4 softmax logits + 4
+// guidance values per pixel (`weight` points at it, `guidance` is unused): one 16-byte load per staged pixel
+// instead of 4 strided dword loads, the weights by softmax_weights4 on the logits -- the same values as the fp32
+// maps hold, so the same output bit for bit.
+template <int L, bool PACKED>
 __global__ void __launch_bounds__(256, 3) filter_fast(const float* __restrict__ weight,    // [n][L][H][W]
                                                      const float* __restrict__ guidance,  // [n][L][H][W]
                                                      const float4* __restrict__ img_in,   // [n][H][W]
@@ -346,10 +354,13 @@ __global__ void __launch_bounds__(256, 3) filter_fast(const float* __restrict__ 
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * kFastW - L, y0 = blockIdx.y * kFastH - L;
     const int64_t HW = (int64_t)H * W;
-    weight += (int64_t)blockIdx.z * L * HW;
+    weight += (int64_t)blockIdx.z * L * HW;  // (PACKED: 8 halves = 4 floats per pixel = L * HW floats per image as well)
     guidance += (int64_t)blockIdx.z * L * HW;
     img_in += (int64_t)blockIdx.z * HW;
     img_out += (int64_t)blockIdx.z * HW;
+    typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+    const _Float16* packed = reinterpret_cast<const _Float16*>(weight);
 
     // staged element e of this thread -> global index (or -1 outside the image)
     int gidx[PER];  // (a frame has < 2^31 pixels: rto_ctx_create refuses more)
@@ -370,13 +381,36 @@ __global__ void __launch_bounds__(256, 3) filter_fast(const float* __restrict__ 
     // front: one exposed memory latency per tile instead of one per level
     float gv_all[L][PER];
     float wl_all[L][kFastRows];
+    if constexpr (PACKED) {
+        static_assert(!PACKED || L == 4, "packed maps hold 4 levels");
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
+        for (int i = 0; i < PER; ++i) {
+            half8_t h = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (gidx[i] >= 0) h = *reinterpret_cast<const half8_t*>(packed + (int64_t)gidx[i] * 8);
 #pragma unroll
-        for (int i = 0; i < PER; ++i) gv_all[l][i] = gidx[i] >= 0 ? guidance[l * HW + gidx[i]] : 0.f;
+            for (int l = 0; l < L; ++l) gv_all[l][i] = (float)h[4 + l];
+        }
 #pragma unroll
-        for (int r = 0; r < kFastRows; ++r)
-            wl_all[l][r] = (px < W && py0 + r < H) ? weight[l * HW + (int64_t)(py0 + r) * W + px] : 0.f;
+        for (int r = 0; r < kFastRows; ++r) {
+            float logit[4] = {0.f, 0.f, 0.f, 0.f}, wgt[4];
+            if (px < W && py0 + r < H) {
+                const half4_t h = *reinterpret_cast<const half4_t*>(packed + ((int64_t)(py0 + r) * W + px) * 8);
+#pragma unroll
+                for (int l = 0; l < 4; ++l) logit[l] = (float)h[l];
+            }
+            softmax_weights4(logit, wgt);
+#pragma unroll
+            for (int l = 0; l < L; ++l) wl_all[l][r] = (px < W && py0 + r < H) ? wgt[l] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) gv_all[l][i] = gidx[i] >= 0 ? guidance[l * HW + gidx[i]] : 0.f;
+#pragma unroll
+            for (int r = 0; r < kFastRows; ++r)
+                wl_all[l][r] = (px < W && py0 + r < H) ? weight[l * HW + (int64_t)(py0 + r) * W + px] : 0.f;
+        }
     }
     float o[kFastRows][3];
 #pragma unroll
@@ -433,7 +467,9 @@ __global__ void __launch_bounds__(256, 3) filter_fast(const float* __restrict__ 
         } else {  // per-pixel maximum, taps from global memory
 #pragma unroll
             for (int r = 0; r < kFastRows; ++r) {
-                const float4 c4 = filter_level_wide(guidance + l * HW, img_in, l + 1, H, W, px, py0 + r, wl[r]);
+                const float4 c4 = PACKED ? filter_level_wide(reinterpret_cast<const float*>(packed + 4 + l), img_in, l + 1, H, W, px,
+                                                             py0 + r, wl[r], 8)
+                                         : filter_level_wide(guidance + l * HW, img_in, l + 1, H, W, px, py0 + r, wl[r], 0);
                 o[r][0] += c4.x;
                 o[r][1] += c4.y;
                 o[r][2] += c4.z;
@@ -451,6 +487,15 @@ __global__ void __launch_bounds__(256, 3) filter_fast(const float* __restrict__ 
         if (px < W && py0 + r < H) img_out[(int64_t)(py0 + r) * W + px] = make_float4(o[r][0], o[r][1], o[r][2], 1.0f);
 }
 
+hipError_t launch_filter_fast_packed(const void* packed_maps, int H, int W, int n, const float* img_in, float* img_out,
+                                     hipStream_t stream) {
+    const dim3 grid((W + kFastW - 1) / kFastW, (H + kFastH - 1) / kFastH, n), block(256);
+    const size_t lds = (size_t)2 * (kFastW + 8) * (kFastH + 8) * sizeof(float4);
+    hipLaunchKernelGGL((filter_fast<4, true>), grid, block, lds, stream, reinterpret_cast<const float*>(packed_maps),
+                       (const float*)nullptr, reinterpret_cast<const float4*>(img_in), reinterpret_cast<float4*>(img_out), H, W);
+    return hipGetLastError();
+}
+
 hipError_t launch_filter_fast(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
                               float* img_out, hipStream_t stream) {
     const dim3 grid((W + kFastW - 1) / kFastW, (H + kFastH - 1) / kFastH, n), block(256);
@@ -459,7 +504,7 @@ hipError_t launch_filter_fast(const float* weight, const float* guidance, int L,
 #define RTO_FFAST(LL)                                                                                              \
     case LL: {                                                                                                     \
         const size_t lds = (size_t)2 * (kFastW + 2 * LL) * (kFastH + 2 * LL) * sizeof(float4);                     \
-        hipLaunchKernelGGL(filter_fast<LL>, grid, block, lds, stream, weight, guidance, in4, out4, H, W);          \
+        hipLaunchKernelGGL((filter_fast<LL, false>), grid, block, lds, stream, weight, guidance, in4, out4, H, W);          \
     } break;
     switch (L) {
         RTO_FFAST(1) RTO_FFAST(2) RTO_FFAST(3) RTO_FFAST(4) RTO_FFAST(5) RTO_FFAST(6)

@@ -44,7 +44,11 @@ __device__ __forceinline__ float relu6(float x) { return fminf(fmaxf(x, 0.f), 6.
 // SQ: the aux planes 4..7 are the squares of planes 0..3 (what the renderer writes, volrend.cu:195-202:
 // a[4 + c] = out[c] * out[c], one fp32 multiply): read only planes 0..3 and square them here -- the same fp32
 // product, so the same fp16 inputs, from half the bytes.
-template <int C1, int L, bool SQ>
+// PACK: write the network's 8 output channels as they leave the last ReLU6 -- fp16 values, [n][H][W][8]: the 4
+// softmax logits, then the 4 guidance values -- instead of fp32 weight_map / guidance_map planes.  16 B per pixel
+// instead of 32, nothing lost: the reference's `.float()` (network.py:112) only widens those fp16 values, and the
+// consumer (filter_fast<L, true>) applies softmax_weights() below to the logits itself.
+template <int C1, int L, bool SQ, bool PACK>
 __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ aux,    // [n][8][H][W]
                                                        const _Float16* __restrict__ w1,  // [C1][96]   k = tap*8 + ci
                                                        const float* __restrict__ b1,     // [C1]
@@ -71,7 +75,7 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
     const int x0 = blockIdx.x * kGW, y0 = blockIdx.y * kGH;
     const int64_t HW = (int64_t)H * W;
     aux += (int64_t)blockIdx.z * kCIn * HW;
-    weight_out += (int64_t)blockIdx.z * L * HW;
+    weight_out += (int64_t)blockIdx.z * L * HW;  // (PACK: [H][W][8] fp16 = 4 floats per pixel = L * HW floats per image too)
     guidance_out += (int64_t)blockIdx.z * L * HW;
 
     const int col = lane & 15, kg = lane >> 4;  // MFMA lane roles: pixel (B/C column), k-group / row block
@@ -192,18 +196,17 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = (float)(_Float16)relu6(acc[i] + bias[i]);  // fp16 activations, then .float()
                 const int64_t pix = (int64_t)gy * W + gx;
-                if (L == 4) {
+                if (PACK) {  // (weight_out = the packed buffer of image blockIdx.z; kg 0: logits, kg 1: guidance)
+                    half4 h;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) h[i] = (_Float16)v[i];
+                    *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(weight_out) + pix * 8 + kg * 4) = h;
+                } else if (L == 4) {
                     if (kg == 0) {  // channels 0..3: softmax -> weight_map (network.py:113-114)
-                        const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                        float e[4], s = 0.f;
+                        float wgt[4];
+                        softmax_weights4(v, wgt);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            e[i] = __expf(v[i] - m);
-                            s += e[i];
-                        }
-                        const float inv = 1.f / s;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) weight_out[i * HW + pix] = e[i] * inv;
+                        for (int i = 0; i < 4; ++i) weight_out[i * HW + pix] = wgt[i];
                     } else {  // channels 4..7: guidance_map (:116)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) guidance_out[i * HW + pix] = v[i];
@@ -221,12 +224,16 @@ hipError_t launch_guidance_net(const float* aux, const void* w1, const float* b1
                                bool squares_implied, hipStream_t stream) {
     if (c1 != 32 || levels != 4) return hipErrorInvalidValue;  // the reference configuration (blender.txt:21-25)
     const dim3 grid((W + kGW - 1) / kGW, (H + kGH - 1) / kGH, n), block(256);
-    if (squares_implied)
-        hipLaunchKernelGGL((guidance_fused<32, 4, true>), grid, block, 0, stream, aux, (const _Float16*)w1, b1,
-                           (const _Float16*)w2, b2, weight_out, guidance_out, H, W);
-    else
-        hipLaunchKernelGGL((guidance_fused<32, 4, false>), grid, block, 0, stream, aux, (const _Float16*)w1, b1,
-                           (const _Float16*)w2, b2, weight_out, guidance_out, H, W);
+    const bool pack = guidance_out == nullptr;  // weight_out is then the packed fp16 buffer [n][H][W][8]
+#define RTO_NET(SQ, PK)                                                                                                   \
+    hipLaunchKernelGGL((guidance_fused<32, 4, SQ, PK>), grid, block, 0, stream, aux, (const _Float16*)w1, b1, (const _Float16*)w2, \
+                       b2, weight_out, guidance_out, H, W)
+    if (pack) {
+        if (squares_implied) RTO_NET(true, true); else RTO_NET(false, true);
+    } else {
+        if (squares_implied) RTO_NET(true, false); else RTO_NET(false, false);
+    }
+#undef RTO_NET
     return hipGetLastError();
 }
 

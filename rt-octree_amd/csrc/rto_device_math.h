@@ -204,6 +204,21 @@ RTO_DEV float2v fexp_f32_le88_x2(float2v x) {
     return p * sc;
 }
 
+// weight = softmax(x[:, :4]) (network.py:113-114) in fp32 over the four fp16-valued logits; one definition for
+// the GuidanceNet kernel's epilogue and for the filter that consumes packed logits, so both give the same bits
+RTO_DEV void softmax_weights4(const float* v, float* out) {
+    const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+    float e[4], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        e[i] = __expf(v[i] - m);
+        s += e[i];
+    }
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = e[i] * inv;
+}
+
 RTO_DEV float f_min(float a, float b) { return a < b ? a : b; }
 RTO_DEV float f_max(float a, float b) { return a > b ? a : b; }
 

@@ -15,6 +15,9 @@ struct rto_guidance_net {
     void* w2 = nullptr;   // fp16 [16][9*c1]
     float* b1 = nullptr;  // [c1]
     float* b2 = nullptr;  // [16]
+    void* packed = nullptr;      // scratch of the packed route: fp16 [n][H][W][8]
+    size_t packed_bytes = 0;
+    int packed_n = 0, packed_h = 0, packed_w = 0;  // what the scratch currently holds
 };
 
 namespace {
@@ -98,9 +101,43 @@ int rto_guidance_net_forward_ex(const rto_guidance_net* net, void* stream, const
     return RTO_OK;
 }
 
+int rto_guidance_net_forward_packed(rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W, int flags) {
+    if (!net || !aux || n < 1 || H < 1 || W < 1) return fail(RTO_E_INVALID, "rto_guidance_net_forward_packed: bad argument");
+    DeviceScope scope(net->device);
+    const size_t need = (size_t)n * H * W * 16;
+    if (need > net->packed_bytes) {  // grow the scratch (first use or a larger batch); earlier work may still read it
+        if (net->packed) {
+            if (hipDeviceSynchronize() != hipSuccess || hipFree(net->packed) != hipSuccess) return fail(RTO_E_HIP, "hipFree failed");
+            net->packed = nullptr;
+            net->packed_bytes = 0;
+        }
+        if (hipMalloc(&net->packed, need) != hipSuccess) return fail(RTO_E_HIP, "hipMalloc(packed maps) failed");
+        net->packed_bytes = need;
+    }
+    const hipError_t e = rto::launch_guidance_net(aux, net->w1, net->b1, net->w2, net->b2, net->c1, net->levels, n, H, W,
+                                                  (float*)net->packed, nullptr, (flags & RTO_NET_AUX_SQUARES_IMPLIED) != 0,
+                                                  (hipStream_t)stream);
+    if (e != hipSuccess) return fail(RTO_E_HIP, std::string("GuidanceNet launch failed: ") + hipGetErrorString(e));
+    net->packed_n = n;
+    net->packed_h = H;
+    net->packed_w = W;
+    return RTO_OK;
+}
+
+int rto_filtering_packed(const rto_guidance_net* net, void* stream, const float* img_in, float* img_out) {
+    if (!net || !img_in || !img_out || img_in == img_out) return fail(RTO_E_INVALID, "rto_filtering_packed: bad argument");
+    if (!net->packed || net->packed_n < 1) return fail(RTO_E_INVALID, "rto_filtering_packed: no packed maps (call rto_guidance_net_forward_packed first)");
+    DeviceScope scope(net->device);
+    const hipError_t e = rto::launch_filter_fast_packed(net->packed, net->packed_h, net->packed_w, net->packed_n, img_in, img_out,
+                                                        (hipStream_t)stream);
+    if (e != hipSuccess) return fail(RTO_E_HIP, std::string("filter launch failed: ") + hipGetErrorString(e));
+    return RTO_OK;
+}
+
 void rto_guidance_net_free(rto_guidance_net* net) {
     if (!net) return;
     DeviceScope scope(net->device);
+    if (net->packed) (void)hipFree(net->packed);
     if (net->w1) (void)hipFree(net->w1);
     if (net->w2) (void)hipFree(net->w2);
     if (net->b1) (void)hipFree(net->b1);

@@ -50,6 +50,10 @@ hipError_t launch_filter(const float* weight, const float* guidance, int L, int 
 hipError_t launch_filter_fast(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
                               float* img_out, hipStream_t stream);
 
+// ... on the GuidanceNet kernel's packed fp16 maps [n][H][W][8] (4 logits + 4 guidance values), L = 4
+hipError_t launch_filter_fast_packed(const void* packed_maps, int H, int W, int n, const float* img_in, float* img_out,
+                                     hipStream_t stream);
+
 // training side: forward that also saves rgb_filtered [n][L][H][W][4], max_map / inv_kernel_sum
 // [n][L][H][W] (filtering.cu:205-216), and the backward (filtering.cu:230-301) in gather form
 hipError_t launch_filter_train(const float* weight, const float* guidance, int L, int H, int W, int n,
@@ -59,7 +63,8 @@ hipError_t launch_filter_backward(const float* grad_out, const float* img_in, co
                                   const float* rgb_filtered, const float* max_map, const float* inv_kernel_sum, int L,
                                   int H, int W, int n, float* grad_weight, float* grad_guidance, hipStream_t stream);
 
-// fused compact GuidanceNet (guidance_kernels.hip): w1 fp16 [c1][96], w2 fp16 [16][9*c1], b2 [16]
+// fused compact GuidanceNet (guidance_kernels.hip): w1 fp16 [c1][96], w2 fp16 [16][9*c1], b2 [16];
+// guidance_out == nullptr: weight_out receives the packed fp16 maps [n][H][W][8] instead
 hipError_t launch_guidance_net(const float* aux, const void* w1, const float* b1, const void* w2, const float* b2, int c1,
                                int levels, int n, int H, int W, float* weight_out, float* guidance_out,
                                bool squares_implied, hipStream_t stream);

@@ -61,3 +61,17 @@ def test_counter_based_roofline_for_the_baseline_workloads():
     assert bench.workload_id(bench.parse_args(["--spp", "1", "--no-denoise"]), 800, 800) == "c5"
     assert bench.workload_id(bench.parse_args(["--c4"]), 1920, 1080) == "c4"
     assert bench.workload_id(bench.parse_args(["--shuffle-nodes", "1"]), 800, 800) is None
+
+
+@pytest.mark.gpu
+def test_bench_scenes_mode_reports_both_mappings():
+    """config C3 shape on a tiny workload: 2 scenes, both rank mappings timed, groups never mix scenes"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "2", "--batch", "4", "--size", "128",
+           "--depth", "5", "--cpu-frames", "0", "--psnr-frames", "0", "--ref-loop-frames", "0", "--scenes", "2",
+           "--scene-map", "both"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["scenes"] == 2 and d["config"]["scene_map"] == "pose" and d["value"] > 0
+    assert d["alt_scene_map"]["scene_map"] == "scene" and d["alt_scene_map"]["value"] > 0
+    assert "2 scenes" in d["config"]["workload"]

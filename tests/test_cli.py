@@ -163,6 +163,29 @@ def test_cli_reference_format_ts_takes_the_fused_kernel(tmp_path):
     assert fused.c1 == 32 and fused.levels == 4
 
 
+@pytest.mark.gpu
+def test_cli_fast_filter_route(tmp_path):
+    """--fast_filter: fused GuidanceNet -> packed fp16 maps -> factorised filter.  PNG bytes within 1 LSB of the
+    default (bit-exact filter) route -- the (uint8)(f * 255) truncation turns a 1e-6 difference into a step at most --
+    and identical between --batch 1 and the batched loop."""
+    from PIL import Image
+    tree, tp, poses, pp = _scene(tmp_path, n=3)
+    tsp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ts_ref_format.ts")
+    op = synth.write_opt_json(str(tmp_path / "opt.json"))
+    outs = {}
+    for name, extra in (("exact", []), ("fast", ["--fast_filter"]), ("fast1", ["--fast_filter", "--batch", "1"])):
+        out = str(tmp_path / name)
+        r = _run([tp, pp, "--options", op, "--ts_module", tsp, "-w", "96", "-h", "72", "-o", out, "--warmup", "1"] + extra)
+        assert r.returncode == 0, r.stderr
+        outs[name] = [np.array(Image.open(os.path.join(out, "r_%d.png" % i))).astype(int) for i in range(3)]
+    changed = 0
+    for i in range(3):
+        assert np.abs(outs["fast"][i] - outs["exact"][i]).max() <= 1, i
+        assert np.array_equal(outs["fast"][i], outs["fast1"][i]), i
+        changed += int((outs["fast"][i] != outs["exact"][i]).sum())
+    assert changed < 0.002 * 3 * 96 * 72 * 4  # a handful of LSB flips at most
+
+
 def _parse_poses(out):
     lines = [l for l in out.splitlines() if l and not l.startswith("INFO")]
     head = lines[0].split()

@@ -92,3 +92,25 @@ def test_squares_implied_reads_half_the_input_bit_identically(shape):
     w1, g1 = fused(poisoned, squares_implied=True)
     torch.cuda.synchronize()
     assert torch.equal(w0, w1) and torch.equal(g0, g1)
+
+
+@pytest.mark.parametrize("shape", [(2, 37, 53), (1, 64, 96), (3, 100, 41)])
+def test_packed_denoise_route_equals_the_fp32_maps_route(shape):
+    """rto_guidance_net_forward_packed + rto_filtering_packed (fp16 logits + guidance, 16 B per pixel, softmax taken
+    by the filter) == rto_guidance_net_forward + the factorised filter on fp32 maps, bit for bit."""
+    n, H, W = shape
+    _, fused = _nets(5)
+    torch.manual_seed(6)
+    aux = torch.rand(n, 8, H, W)
+    aux[:, 4:] = aux[:, :4] * aux[:, :4]
+    dev = torch.device("cuda:0")
+    aux_d = aux.to(dev).contiguous()
+    noisy = torch.rand(n, H, W, 4, device=dev)
+    w, g = fused(aux_d, squares_implied=True)
+    ref = torch.empty_like(noisy)
+    R.filtering(None, w, g, noisy, ref, mode=R.FILTER_FAST)
+    out = torch.full_like(noisy, -3.0)
+    fused.forward_packed(aux_d, squares_implied=True)
+    fused.filter_packed(noisy, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)

@@ -36,6 +36,10 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
 constexpr int kGW = 32, kGH = 8;  // output tile
+#ifndef RTO_NET_STRIP
+#define RTO_NET_STRIP 1
+#endif
+constexpr int kStrip = RTO_NET_STRIP;  // tiles per workgroup, along x
 constexpr int kCIn = 8;           // aux channels (render_context.hpp:23)
 
 __device__ __forceinline__ float relu6(float x) { return fminf(fmaxf(x, 0.f), 6.f); }
@@ -72,7 +76,13 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
     __shared__ __attribute__((aligned(16))) _Float16 s_act[AH * AW * AS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int x0 = blockIdx.x * kGW, y0 = blockIdx.y * kGH;
+    // A workgroup can walk a strip of kStrip tiles along x with the input of tile t + 1 on its way into registers
+    // while layers 1 and 2 of tile t run.  Measured (16 frames of 800x800): strip 1 0.356 ms, 3 0.376-0.44, 5 0.39-0.44,
+    // 25 0.47 -- with 4 workgroups per CU the other workgroups already cover a tile's load phase, and longer strips
+    // only leave fewer workgroups to balance; the default stays 1.
+    const int tiles_x = (W + kGW - 1) / kGW;
+    const int tx_first = blockIdx.x * kStrip;
+    const int y0 = blockIdx.y * kGH;
     const int64_t HW = (int64_t)H * W;
     aux += (int64_t)blockIdx.z * kCIn * HW;
     weight_out += (int64_t)blockIdx.z * L * HW;  // (PACK: [H][W][8] fp16 = 4 floats per pixel = L * HW floats per image too)
@@ -92,12 +102,22 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
     for (int ks = 0; ks < KS2; ++ks)
         wb[ks] = *reinterpret_cast<const half8*>(w2 + (size_t)col * (9 * C1) + ks * 32 + kg * 8);
 
-    // ---- stage A: input tile, planar fp32 -> HWC fp16.  One thread = one tile pixel: its 8 channel
-    // loads are independent (all in flight at once; a per-element loop waited for each load in turn
-    // and was the whole kernel's critical path) and become one 16-byte LDS store.
-    {
-        constexpr int NPIX = IH * IW, NIT = (NPIX + 255) / 256;
-        float v[NIT][kCIn];
+    // biases once per workgroup, before the strip loop: a global load inside stages B / C would make their
+    // s_waitcnt drain the prefetch of the next tile as well (vmcnt retires in issue order)
+    float bias1[NT1][4], bias2[4];
+#pragma unroll
+    for (int t = 0; t < NT1; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias1[t][i] = b1[t * 16 + kg * 4 + i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bias2[i] = b2[kg * 4 + i];
+
+    // ---- stage A: input tile, planar fp32 -> HWC fp16.  One thread = one tile pixel: its channel loads are
+    // independent (all in flight at once) and become one 16-byte LDS store.
+    constexpr int NPIX = IH * IW, NIT = (NPIX + 255) / 256;
+    constexpr int NLD = SQ ? kCIn / 2 : kCIn;  // planes actually read
+    float v[NIT][NLD];
+    auto fetch = [&](int x0) {  // issue the loads of the tile whose first output column is x0
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int e = tid + it * 256;
@@ -106,90 +126,130 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
             const bool in = e < NPIX && gx >= 0 && gx < W && gy >= 0 && gy < H;
             const int64_t gi = in ? (int64_t)gy * W + gx : 0;
 #pragma unroll
-            for (int c = 0; c < (SQ ? kCIn / 2 : kCIn); ++c) {
+            for (int c = 0; c < NLD; ++c) {
                 const float t = aux[c * HW + gi];
                 v[it][c] = in ? t : 0.f;
             }
+        }
+    };
+#ifdef RTO_NET_DBG_STAMP
+    unsigned long long st[8];
+    st[0] = __builtin_amdgcn_s_memtime();
+#endif
+    fetch(tx_first * kGW);
+
+    for (int ts = 0; ts < kStrip; ++ts) {
+    const int tile_x = tx_first + ts;
+    if (tile_x >= tiles_x) break;  // workgroup-uniform
+    const int x0 = tile_x * kGW;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int e = tid + it * 256;
+        if (e < NPIX) {
+            half8 h;
+#pragma unroll
+            for (int c = 0; c < NLD; ++c) h[c] = (_Float16)v[it][c];
             if (SQ) {
 #pragma unroll
-                for (int c = 0; c < kCIn / 2; ++c) v[it][kCIn / 2 + c] = v[it][c] * v[it][c];
+                for (int c = 0; c < kCIn / 2; ++c) h[kCIn / 2 + c] = (_Float16)(v[it][c] * v[it][c]);
             }
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int e = tid + it * 256;
-            if (e < NPIX) {
-                half8 h;
-#pragma unroll
-                for (int c = 0; c < kCIn; ++c) h[c] = (_Float16)v[it][c];
-                *reinterpret_cast<half8*>(s_in + (size_t)e * kCIn) = h;
-            }
+            *reinterpret_cast<half8*>(s_in + (size_t)e * kCIn) = h;
         }
     }
-    __syncthreads();
+#ifdef RTO_NET_DBG_STAMP
+    if (ts == 0) st[1] = __builtin_amdgcn_s_memtime();
+#endif
+    __syncthreads();  // s_in complete; every wave is also done with stage C of the previous tile (s_act is free)
+#ifdef RTO_NET_DBG_STAMP
+    if (ts == 0) st[2] = __builtin_amdgcn_s_memtime();
+#endif
+    if (ts + 1 < kStrip && tile_x + 1 < tiles_x) fetch(x0 + kGW);  // next tile's input: in flight during stages B and C
 
 
     // ---- stage B: layer 1 on the AH x AW region
     {
-        float bias[NT1][4];
-#pragma unroll
-        for (int t = 0; t < NT1; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bias[t][i] = b1[t * 16 + kg * 4 + i];
-
+        const float(&bias)[NT1][4] = bias1;
         constexpr int NG1 = (AH * AW + 15) / 16;
+#ifndef RTO_NET_DBG_BREP
+#define RTO_NET_DBG_BREP 1
+#endif
+        for (int rep = 0; rep < RTO_NET_DBG_BREP; ++rep)
         for (int g = wave; g < NG1; g += 4) {
+            if (RTO_NET_DBG_BREP > 1) asm volatile("" ::: "memory");
+            // (the index arithmetic of this loop is what the kernel's VALU time went into: 24-bit multiplies and
+            // a reciprocal multiply instead of 32-bit mul_lo / mul_hi -- all operands are far below 2^24)
             const int p = g * 16 + col;
             const bool valid = p < AH * AW;
-            const int ry = valid ? p / AW : 0, rx = valid ? p - (p / AW) * AW : 0;
+            static_assert(AH * AW < 2048, "reciprocal division below assumes a small tile");
+            const int q = (int)(__umul24((unsigned)p, (65536u + AW - 1) / AW) >> 16);  // p / AW for p < 2048
+            const int ry = valid ? q : 0, rx = valid ? p - (int)__umul24((unsigned)q, AW) : 0;
             float4v acc[NT1];
 #pragma unroll
             for (int t = 0; t < NT1; ++t) acc[t] = (float4v){0.f, 0.f, 0.f, 0.f};
+            half8 bf1[3];
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) {
                 const int tap = ks * 4 + kg;
-                half8 bfrag = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+                bf1[ks] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
                 if (tap < 9) {
                     const int ky = tap / 3, kx = tap - ky * 3;
-                    bfrag = *reinterpret_cast<const half8*>(s_in + ((ry + ky) * IW + rx + kx) * kCIn);
+                    bf1[ks] = *reinterpret_cast<const half8*>(s_in + (__umul24((unsigned)(ry + ky), IW) + rx + kx) * kCIn);
                 }
-#pragma unroll
-                for (int t = 0; t < NT1; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][ks], bfrag, acc[t], 0, 0, 0);
             }
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+                for (int t = 0; t < NT1; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][ks], bf1[ks], acc[t], 0, 0, 0);
             if (valid) {
                 const int gx = x0 - 1 + rx, gy = y0 - 1 + ry;
-                const bool inside = gx >= 0 && gx < W && gy >= 0 && gy < H;
+                // outside the image the activation is the second convolution's zero padding: scale by 0 (branch-free;
+                // relu6(...) is finite and >= 0, so x * 1 = x and x * 0 = +0 exactly)
+                const float inside = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? 1.f : 0.f;
 #pragma unroll
                 for (int t = 0; t < NT1; ++t) {
                     half4 o;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = inside ? (_Float16)relu6(acc[t][i] + bias[t][i]) : (_Float16)0.f;
-                    *reinterpret_cast<half4*>(s_act + (size_t)p * AS + t * 16 + kg * 4) = o;
+                    for (int i = 0; i < 4; ++i) o[i] = (_Float16)(relu6(acc[t][i] + bias[t][i]) * inside);
+                    *reinterpret_cast<half4*>(s_act + __umul24((unsigned)p, AS) + t * 16 + kg * 4) = o;
                 }
             }
         }
     }
+#ifdef RTO_NET_DBG_STAMP
+    if (ts == 0) st[3] = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
+#ifdef RTO_NET_DBG_STAMP
+    if (ts == 0) st[4] = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- stage C: layer 2 on the kGH x kGW tile, softmax, stores
     {
-        float bias[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bias[i] = b2[kg * 4 + i];
-
+        const float(&bias)[4] = bias2;
         constexpr int NG2 = kGH * kGW / 16;
+#ifndef RTO_NET_DBG_CREP
+#define RTO_NET_DBG_CREP 1
+#endif
+        for (int rep = 0; rep < RTO_NET_DBG_CREP; ++rep)
         for (int g = wave; g < NG2; g += 4) {
+            if (RTO_NET_DBG_CREP > 1) asm volatile("" ::: "memory");
             const int p = g * 16 + col;
             const int oy = p / kGW, ox = p - oy * kGW;
             float4v acc = (float4v){0.f, 0.f, 0.f, 0.f};
+            // all of the group's B fragments first, each into registers of its own, then the MFMA chain: with one
+            // fragment register set the compiler serialises read -> wait -> MFMA nine times and the group costs nine
+            // LDS latencies (measured: 1.5 k clocks per group at 4 waves per SIMD)
+            half8 bf[KS2];
 #pragma unroll
             for (int ks = 0; ks < KS2; ++ks) {
                 const int k0 = ks * 32 + kg * 8;  // k = tap*C1 + ci
                 const int tap = k0 / C1, ci = k0 - tap * C1;
                 const int ky = tap / 3, kx = tap - ky * 3;
-                const half8 bfrag = *reinterpret_cast<const half8*>(s_act + (size_t)((oy + ky) * AW + ox + kx) * AS + ci);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ks], bfrag, acc, 0, 0, 0);
+                bf[ks] = *reinterpret_cast<const half8*>(s_act + __umul24(__umul24((unsigned)(oy + ky), AW) + ox + kx, AS) + ci);
             }
+            __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks the reads back between the MFMAs)
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ks], bf[ks], acc, 0, 0, 0);
             const int gx = x0 + ox, gy = y0 + oy;
             if (gx < W && gy < H && kg * 4 < 2 * L) {
                 float v[4];
@@ -215,6 +275,15 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
             }
         }
     }
+#ifdef RTO_NET_DBG_STAMP
+    if (ts == 0) {
+        st[5] = __builtin_amdgcn_s_memtime();
+        if ((blockIdx.x == 3 || blockIdx.x == 11) && (blockIdx.y == 40 || blockIdx.y == 41) && blockIdx.z == 2 && lane == 0)
+            printf("blk %d,%d wave %d: fetch+wait+cvt %llu | sync %llu | B %llu | sync %llu | C %llu | start %llu\n", blockIdx.x, blockIdx.y, wave,
+                   st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[0]);
+    }
+#endif
+    }  // strip
 }
 
 }  // namespace
@@ -223,7 +292,8 @@ hipError_t launch_guidance_net(const float* aux, const void* w1, const float* b1
                                int levels, int n, int H, int W, float* weight_out, float* guidance_out,
                                bool squares_implied, hipStream_t stream) {
     if (c1 != 32 || levels != 4) return hipErrorInvalidValue;  // the reference configuration (blender.txt:21-25)
-    const dim3 grid((W + kGW - 1) / kGW, (H + kGH - 1) / kGH, n), block(256);
+    const int tiles_x = (W + kGW - 1) / kGW;
+    const dim3 grid((tiles_x + kStrip - 1) / kStrip, (H + kGH - 1) / kGH, n), block(256);
     const bool pack = guidance_out == nullptr;  // weight_out is then the packed fp16 buffer [n][H][W][8]
 #define RTO_NET(SQ, PK)                                                                                                   \
     hipLaunchKernelGGL((guidance_fused<32, 4, SQ, PK>), grid, block, 0, stream, aux, (const _Float16*)w1, b1, (const _Float16*)w2, \

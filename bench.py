@@ -474,12 +474,20 @@ def main():
                     l2_miss = l1_miss * pj["tcc_miss"] / max(pj["tcc_hit"] + pj["tcc_miss"], 1)
                     model_clk = ((lines - l1_miss) / ce["l1_hit_lines_per_clk"] + (l1_miss - l2_miss) / ce["l2_lines_per_clk"]
                                  + l2_miss / ce["mall_lines_per_clk"])
+                    ci = ce.get("independent")
+                    lower = None
+                    if ci:
+                        lower = ((lines - l1_miss) / ci["l1_hit_lines_per_clk"] + (l1_miss - l2_miss) / ci["l2_lines_per_clk"]
+                                 + l2_miss / ci["mall_lines_per_clk"]) / clk
                     tcp = {"line_accesses_per_clk_per_cu": lines / clk, "l1_hit_rate": 1.0 - l1_miss / lines,
                            "l2_hit_rate": 1.0 - l2_miss / max(l1_miss, 1.0),
-                           "ceilings_lines_per_clk_per_cu": ce, "frac": model_clk / clk,
+                           "ceilings_lines_per_clk_per_cu": ce, "frac": model_clk / clk, "frac_lower": lower,
                            "note": "frac = (L1-hit lines / ceiling + L2-served lines / ceiling + lines from beyond L2 / ceiling) / "
-                                   "kernel clocks: the share of the kernel the L1s need for its gathers at the rates "
-                                   "tools/probe_ceiling.py measured for scattered dword loads (profiles/r2_probe_ceiling.json)"}
+                                   "kernel clocks: the share of the kernel its L1s need for the gathers at the rates "
+                                   "tools/probe_ceiling.py measured for DEPENDENT scattered dword loads, the traversal's shape "
+                                   "(profiles/r2_probe_ceiling.json); the three classes overlap a little in the real kernel, so "
+                                   "values around 1 mean: at that ceiling.  frac_lower prices the same lines at the rates of "
+                                   "four independent gathers in flight per wave -- rates no dependent walk can reach."}
         except Exception as e:  # a malformed profile must not break the bench line
             print("[bench] ignoring %s: %r" % (pmc_path, e), file=sys.stderr)
             traffic = tcp = None

@@ -6,9 +6,9 @@ import os
 import sys
 
 
-def ceiling(probe, table_prefix):
+def ceiling(probe, table_prefix, dependent=1):
     for g in probe["gather"]:
-        if g["table"].startswith(table_prefix) and g["dependent"] == 1 and g["blocked"] == 0 and g["lines_per_gather"] == 21 \
+        if g["table"].startswith(table_prefix) and g["dependent"] == dependent and g["blocked"] == 0 and g["lines_per_gather"] == 21 \
                 and g["waves_per_simd"] == 6:
             return g["line_accesses_per_clk_per_cu"]
     raise KeyError(table_prefix)
@@ -22,6 +22,10 @@ def main():
         doc["ceilings"] = {
             "l1_hit_lines_per_clk": ceiling(probe, "16 KiB"), "l2_lines_per_clk": ceiling(probe, "2 MiB"),
             "mall_lines_per_clk": ceiling(probe, "64 MiB"),
+            # the same with FOUR independent gathers in flight per wave: what the L1 sustains when nothing waits on a
+            # previous load -- an upper bound on its rates, hence a lower bound on the share of the kernel it needs
+            "independent": {"l1_hit_lines_per_clk": ceiling(probe, "16 KiB", 0), "l2_lines_per_clk": ceiling(probe, "2 MiB", 0),
+                            "mall_lines_per_clk": ceiling(probe, "64 MiB", 0)},
             "source": "tools/probe_ceiling.py (%s): one dependent dword gather per wave touching 21 distinct 64-B lines, "
                       "6 waves per SIMD, table resident in L1 / L2 / beyond L2" % os.path.basename(probe_path)}
     for spec in sys.argv[3:]:

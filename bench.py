@@ -3,13 +3,14 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one frame of config C2: batched-regular-tracking render (800x800, SPP 6) + GuidanceNet
-(the compact network as one fused MFMA kernel; --torch-net runs it through PyTorch-ROCm/MIOpen) +
-guided filter, i.e. what one iteration of the reference's timed loop does
-(main_headless.cpp:485-543).  Frames are issued in groups of --batch poses (default 32): one launch
-of the persistent ray-queue traversal kernel + one shading launch, one batched GuidanceNet forward,
-one batched filter launch per group -- a frame alone cannot fill 256 CUs (DESIGN.md "Batching").
-Every image is bit-identical to rendering the poses one by one (tests/test_render_parity.py).
+A "step" is one pass of the hot path over one BATCH of synthetic input: --batch poses (default 100 = half of the
+reference's 200-pose test loop) of config C2 -- batched-regular-tracking render (800x800, SPP 6) + GuidanceNet (the
+compact network as one fused MFMA kernel; --torch-net runs it through PyTorch-ROCm/MIOpen) + guided filter, i.e. what
+--batch iterations of the reference's timed loop do (main_headless.cpp:485-543) -- issued as one launch of the
+persistent ray-queue traversal kernel + one shading launch, one batched GuidanceNet forward and one batched filter
+launch: a frame alone cannot fill 256 CUs (DESIGN.md "Batching").  `value` is FRAMES per second whatever the step
+size (frames = steps x batch x ranks); `reference_loop` reports the reference's own one-frame-per-launch loop shape
+beside it.  Every image is bit-identical to rendering the poses one by one (tests/test_render_parity.py).
 
 Inputs are synthetic (no dataset exists on either machine): a seeded lego-like SH16 PlenOctree of
 ~2.1 M nodes, a 200-pose blender orbit, the GuidanceNet trained by tools/train_guidance.py.
@@ -54,9 +55,9 @@ WARM_FRAMES_REF = 100  # main_headless.cpp:469-479: 100 warm-up frames each adva
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--batch", type=int, default=32, help="frames per launch group (1..32)")
+    ap.add_argument("--steps", type=int, default=8, help="timed steps; one step = one batch of --batch frames")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed warm-up steps (batches)")
+    ap.add_argument("--batch", type=int, default=100, help="frames per step = per launch group (1..128)")
     ap.add_argument("--size", type=int, default=800, help="square image size (config C2/C5)")
     ap.add_argument("--width", type=int, default=0, help="with --height: non-square frames (config C4: 1920x1080)")
     ap.add_argument("--height", type=int, default=0)
@@ -175,10 +176,10 @@ def plan_only(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    B = max(1, min(32, args.batch))
+    B = max(1, min(128, args.batch))
     n_scenes = 1 if args.tree else max(1, min(8, args.scenes))
     maps = ["pose", "scene"] if n_scenes > 1 else ["pose"]
-    mine = {m: plan_groups(args.steps, B, rank, world, 200, n_scenes, m) for m in maps}
+    mine = {m: plan_groups(args.steps * B, B, rank, world, 200, n_scenes, m) for m in maps}
     plans = [mine]
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -188,7 +189,7 @@ def plan_only(args):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"world": world, "steps": args.steps, "batch": B, "scenes": n_scenes,
+        print(json.dumps({"world": world, "steps": args.steps, "batch": B, "frames_per_rank": args.steps * B, "scenes": n_scenes,
                           "plans": {m: [plans[r][m] for r in range(world)] for m in maps},
                           "rng_jump_of_pose": "%d + pose" % WARM_FRAMES_REF}))
 
@@ -231,7 +232,7 @@ def main():
     W = H = args.size
     if args.width > 0 and args.height > 0:
         W, H = args.width, args.height
-    B = max(1, min(32, args.batch))
+    B = max(1, min(128, args.batch))
     n_scenes = 1 if args.tree else max(1, min(8, args.scenes))
     maps = ["pose", "scene"] if (args.scene_map == "both" and n_scenes > 1) else [args.scene_map if args.scene_map != "both" else "pose"]
     tree_host = None
@@ -298,6 +299,7 @@ def main():
         lanes.append((c2, torch.cuda.Stream(dev), n2, torch.as_tensor(c2.batch_views()[0], device=dev)))
 
     filter_mode = R.FILTER_EXACT if args.exact_filter else R.FILTER_FAST
+    n_frames = args.steps * B  # timed frames of this rank: one step = one batch
     # fused GuidanceNet + factorised filter: keep the maps in fp16 between the two kernels (same pixels, half the bytes)
     packed_route = denoise and not args.torch_net and not args.exact_filter and not args.fp32_maps
 
@@ -338,8 +340,14 @@ def main():
         return plan_groups(n_frames, B, rank, world, len(poses), n_scenes, scene_map)
 
     def timed(scene_map):
-        warm, work = plan(args.warmup, scene_map), plan(args.steps, scene_map)
+        warm, work = plan(args.warmup * B, scene_map), plan(n_frames, scene_map)
         events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in work]
+        if work:  # allocation pass (untimed, whatever --warmup is): every lane sees the largest group once, so no
+            # buffer of the library or of torch's allocator is created inside the timed region
+            big = max(work, key=lambda g: len(g[1]))
+            for ln in range(len(lanes)):
+                group(big[0], big[1], None, ln)
+            torch.cuda.synchronize(dev)
         for g, (sc, idx) in enumerate(warm):
             group(sc, idx, None, g % len(lanes))
         torch.cuda.synchronize(dev)
@@ -365,19 +373,19 @@ def main():
               "traverse_ms": sum(k["traverse_ms"] * k["launches"] for k in kts) / n_launch,
               "shade_ms": sum(k["shade_ms"] * k["launches"] for k in kts) / n_launch}
         # Timer::report formula (render_context.hpp:190-206), per frame, from the per-group event pairs
-        render_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
-        torch_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps if denoise else 0.0
-        filter_ms = sum(e[2].elapsed_time(e[3]) for e in events) / args.steps if denoise else 0.0
+        render_ms = sum(e[0].elapsed_time(e[1]) for e in events) / n_frames
+        torch_ms = sum(e[1].elapsed_time(e[2]) for e in events) / n_frames if denoise else 0.0
+        filter_ms = sum(e[2].elapsed_time(e[3]) for e in events) / n_frames if denoise else 0.0
         all_ms = render_ms + torch_ms + filter_ms
         return elapsed, kt, {"render_ms": render_ms, "torch_ms": torch_ms, "filter_ms": filter_ms,
-                             "fps": 1000.0 / all_ms if all_ms > 0 else 0.0, "frames": args.steps}
+                             "fps": 1000.0 / all_ms if all_ms > 0 else 0.0, "frames": n_frames}
 
     # ---------------- warm-up + timed region(s) ----------------
     elapsed, kt, tstats = timed(maps[0])
     alt = None
     if len(maps) > 1:
         e2, _, t2 = timed(maps[1])
-        alt = {"scene_map": maps[1], "value": args.steps * world / e2, "ms_per_step": e2 / args.steps * 1e3,
+        alt = {"scene_map": maps[1], "value": n_frames * world / e2, "ms_per_step": e2 / args.steps * 1e3,
                "reference_timer_fps": t2["fps"]}
 
     # ---------------- untimed: the reference's loop shape (one frame per launch, sync per frame) ----------------
@@ -430,7 +438,7 @@ def main():
     ctx.enable_stats(True)
     ctx.get_stats(reset=True)
     opt_nd = R.RenderOptions(spp=args.spp, denoise=False)
-    count_steps = min(args.steps, 64)  # per-frame means need no more
+    count_steps = min(n_frames, 64)  # per-frame means need no more
     for s in range(count_steps):  # same poses, same RNG bases as the timed frames
         sc, i = frame_of(s, maps[0])
         # the counting kernel shades from dense records: a codebook-direct tree is counted on its
@@ -447,7 +455,7 @@ def main():
     px = W * H
     alg_bytes_frame = (4 * units["levels"] + 2 * units["steps"] + 2 * (tree.data_dim - 1) * units["hit_leaves"]
                        + 48 * px * count_steps) / count_steps
-    frames_per_launch = args.steps / max(kt["launches"], 1)
+    frames_per_launch = n_frames / max(kt["launches"], 1)
     alg_bytes_launch = alg_bytes_frame * frames_per_launch
     t_launch = kt["traverse_ms"] * 1e-3
     alg_gbps = alg_bytes_launch / t_launch / 1e9 if t_launch > 0 else 0.0
@@ -596,7 +604,7 @@ def main():
                                      "(tests/), whose estimator semantics are pinned by tests/test_expectation.py; NOT a "
                                      "comparison with frames of the CUDA reference (none exist offline)")
 
-    total_frames = args.steps * world
+    total_frames = n_frames * world
     use = achieved if achieved is not None else alg_gbps
     roof = {
         "kernel": "render_persist<%d>" % args.spp, "bound": "hbm",
@@ -631,14 +639,14 @@ def main():
         "dtype": "f32" if not denoise else "f32 (traversal, filter) + f16 x f16 -> f32 (GuidanceNet conv, %s)" % ("MIOpen" if args.torch_net else "fused MFMA kernel"),
         "data": "synthetic",
         "config": {
-            "workload": "configs[%s]: %slego-like synthetic PlenOctree %s (%d nodes, depth %d), %dx%d SPP=%d%s, 1 frame per step issued in groups of <= %d, frames sharded %s"
+            "workload": "configs[%s]: %slego-like synthetic PlenOctree %s (%d nodes, depth %d), %dx%d SPP=%d%s, 1 step = 1 batch of %d frames (one launch group), frames sharded %s"
                         % ({"c2": "1", "c4": "3 stand-in", "c5": "4"}.get(wid, "2" if n_scenes > 1 else "1-like"),
                            ("%d scenes, " % n_scenes) if n_scenes > 1 else "",
                            tree.data_format, tree.capacity, tree.max_depth, W, H, args.spp,
                            " + GuidanceNet(8,32,5,2,4) denoise" if denoise else " raw (no denoise)", B,
                            "scene s -> rank s mod N" if (maps[0] == "scene" and n_scenes > 1) else "frame g -> rank g mod N"),
             "tree_nodes": int(tree.capacity), "tree_device_mb": tree.device_bytes / 1e6,
-            "frames_per_launch": frames_per_launch, "frames_per_launch_cap": B, "streams": len(lanes),
+            "frames_per_step": B, "frames_timed": total_frames, "frames_per_launch": frames_per_launch, "streams": len(lanes),
             "scenes": n_scenes, "scene_map": maps[0], "filter": "exact" if args.exact_filter else "factorised", "maps": "fp16 packed" if packed_route else "fp32 planes",
             "parallelism": "frames x%d" % world,
         },

@@ -143,7 +143,7 @@ void rto_tree_free(rto_tree* t);
 /* RenderContext::update (render_context.hpp:70-91): aux [8][H][W] f32, noisy and final images
  * [H][W][4] f32, rng = pcg32(20230418) (:16).  offscreen is always true (headless path). */
 int rto_ctx_create(int width, int height, int device, rto_ctx** out);
-/* The same with `frames` (1..32) frame slots: aux [frames][8][H][W], noisy / image [frames][H][W][4],
+/* The same with `frames` (1..128) frame slots: aux [frames][8][H][W], noisy / image [frames][H][W][4],
  * contiguous.  Single-frame entry points and accessors act on the slot chosen with
  * rto_ctx_select_frame (default 0); rto_launch_renderer_batch fills slots 0..n-1. */
 int rto_ctx_create_batch(int width, int height, int frames, int device, rto_ctx** out);
@@ -189,7 +189,7 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
                         rto_ctx* ctx, void* stream);
 
 /* Throughput form of the operator: n frames (poses of the same tree) in ONE launch of the
- * persistent ray-queue kernel.  Frame f is rendered with cams[f] into frame slot f with the RNG
+ * persistent ray-queue kernel (n <= 128).  Frame f is rendered with cams[f] into frame slot f with the RNG
  * ctx.rng advanced by rng_jumps[f] * 2^32 (NULL: f jumps) -- bit-identical to n sequential
  * rto_launch_renderer calls separated by rto_ctx_rng_advance(ctx, 1<<32), the reference's frame
  * loop (main_headless.cpp:485-506).  ctx.rng itself is not modified.  Needs an N == 2 tree. */

@@ -8,7 +8,7 @@
 //   * `--ts_module` is only required when the options say denoise = true (the reference constructs
 //     the Denoiser unconditionally and aborts without it, main_headless.cpp:455-456);
 //   * TanksAndTemple pose files are read in sorted order (the reference uses directory order);
-//   * `--batch B` (1..32, default 32) renders B poses per launch of the persistent ray-queue kernel and
+//   * `--batch B` (1..128, default 100: the reference's 200-pose test loop in two launches) renders B poses per launch of the persistent ray-queue kernel and
 //     denoises them as one batch; images are identical to B = 1 (one launch per frame, the reference's loop), the report is still per frame;
 //   * extra flags `--shard i/N` (render poses i, i+N, ...: frame sharding across GPUs, one process
 //     per GPU) and `--warmup K` (default 100 like the reference).
@@ -108,7 +108,7 @@ void usage() {
         "  -o,--write_images DIR   write r_<i>.png (or buf_<name>.bin with --write_buffer)\n"
         "  --write_buffer  --max_imgs N  --scale S  -i intrin  -r,--reverse_yz\n"
         "  --shard i/N        render poses i, i+N, ... only     --warmup K (100)\n"
-        "  --batch B          poses per launch (1..32, default 32; 1 = one launch per frame like the reference's loop)\n"
+        "  --batch B          poses per launch (1..128, default 100; 1 = one launch per frame like the reference's loop)\n"
         "  --torch_net        run the TorchScript GuidanceNet through libtorch even when it is the compact two-layer\n"
         "                     network the fused HIP kernel implements (default: fused)\n"
         "  --fast_filter      guided filter with factorised exponentials (4 exps per pixel instead of 164; agrees with\n"
@@ -219,7 +219,7 @@ int main(int argc, char** argv) {
         options.sigma_thresh = (float)std::atof(args.get("sigma_thresh", "1e-2").c_str());
     }
 
-    int batch = std::max(1, std::min(32, std::atoi(args.get("batch", "32").c_str())));
+    int batch = std::max(1, std::min(128, std::atoi(args.get("batch", "100").c_str())));
     const int filter_mode = args.has("fast_filter") ? RTO_FILTER_FACTORISED : RTO_FILTER_EXACT;
     {  // no more frame slots than this process has poses to render
         const size_t n_mine = (ps.trans.size() + (size_t)shard_n - 1 - (size_t)shard_i) / (size_t)shard_n;

@@ -745,9 +745,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     float* s_dst = reinterpret_cast<float*>(s_mem + (size_t)stack_levels * 256) + tid;
     FrameDesc* s_frames = reinterpret_cast<FrameDesc*>(s_mem + (size_t)(stack_levels + SPP + 1) * 256);
     __shared__ int s_qstart[kMaxQueues + 1];
-#pragma unroll
-    for (int f = 0; f < kMaxBatch; ++f)  // static indices: the kernarg struct is never address-taken
-        if (tid == f) s_frames[f] = fb.f[f];
+    if (tid < fb.n) s_frames[tid] = fb.f[tid];  // the batch's frame table: device memory -> LDS
 #pragma unroll
     for (int k = 0; k <= kMaxQueues; ++k)
         if (tid == 64 + k) s_qstart[k] = fb.qstart[k];
@@ -1139,7 +1137,7 @@ __global__ void __launch_bounds__(256) shade_kernel(const TreeDev tree, const Op
     const uint32_t pblock = (q / (uint32_t)fb.n) * 8u + (bid & 7u);
     const int64_t wave_px0 = ((int64_t)pblock * 4 + wv) * (64 * P);
     if (wave_px0 >= SIZE) return;  // wave-uniform
-    const FrameDesc& fd = fb.f[frame];  // block-uniform index: scalar loads from the kernarg
+    const FrameDesc& fd = fb.f[frame];  // block-uniform index: scalar loads
 
     // ---- each lane: the hit lists of its P pixels (pixel p*64 + lane of the wave: coalesced)
     uint32_t h[P][SPP];
@@ -1276,6 +1274,15 @@ __global__ void __launch_bounds__(256) shade_kernel(const TreeDev tree, const Op
         }
         write_pixel(fo, SIZE, (int)idx, opt.background_brightness, out[p]);
     }
+}
+
+// ------------------------------------------------------------------ frame table
+// The frame descriptors of a batch reach the device as kernel arguments of this one-wave kernel, at most kFrameChunk
+// per launch (a kernarg segment holds 4 KB; 64 descriptors are 6 KB), and are written to the context's table on the
+// launch stream: no host staging buffer whose lifetime would have to outlast an asynchronous copy.
+__global__ void write_frames_kernel(const FrameChunk c, FrameDesc* __restrict__ dst, int n) {
+    const int i = threadIdx.x;
+    if (i < n) dst[i] = c.f[i];
 }
 
 // ------------------------------------------------------------------ u8 conversion
@@ -1467,6 +1474,16 @@ hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, 
         case 32: return launch_batch_spp<32>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
         default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_write_frames(const FrameDesc* host, int n, FrameDesc* dev_table, hipStream_t stream) {
+    for (int f0 = 0; f0 < n; f0 += kFrameChunk) {
+        FrameChunk c;
+        const int m = n - f0 < kFrameChunk ? n - f0 : kFrameChunk;
+        for (int i = 0; i < m; ++i) c.f[i] = host[f0 + i];
+        hipLaunchKernelGGL(write_frames_kernel, dim3(1), dim3(64), 0, stream, c, dev_table + f0, m);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_rgba8(const float* rgba, uint8_t* out, int64_t n_pixels, hipStream_t stream) {

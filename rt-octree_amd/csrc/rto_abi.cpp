@@ -91,6 +91,7 @@ struct rto_ctx {
     int sel = 0;     // slot the single-frame entry points and accessors refer to
     int num_cus = 256;
     unsigned long long* queue = nullptr;  // persistent-kernel ray queues (kQueueWords u64)
+    rto::FrameDesc* d_frames = nullptr;   // frame table of the batch in flight (kMaxBatch descriptors)
     rto::OccupancyCache occ;              // of the persistent kernel instantiation last launched
     uint32_t* tile_order = nullptr;       // centre-out order of the 8x8 ray tiles (persistent kernel)
     uint32_t* wedge_order = nullptr;      // the same tiles grouped into 8 angular wedges (one ray queue per XCD)
@@ -747,6 +748,7 @@ int rto_ctx_create_batch(int width, int height, int frames, int device, rto_ctx*
         hipMalloc((void**)&c->image, px * 4 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&c->rgba8, px * 4) != hipSuccess ||
         hipMalloc((void**)&c->queue, rto::kQueueWords * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void**)&c->d_frames, rto::kMaxBatch * sizeof(rto::FrameDesc)) != hipSuccess ||
         hipMemset(c->queue, 0, rto::kQueueWords * sizeof(unsigned long long)) != hipSuccess) {
         rto_ctx_free(c);
         return set_err(RTO_E_HIP, "hipMalloc(ctx buffers) failed");
@@ -781,6 +783,7 @@ void rto_ctx_free(rto_ctx* c) {
     if (c->rgba8) (void)hipFree(c->rgba8);
     if (c->jump) (void)hipFree(c->jump);
     if (c->queue) (void)hipFree(c->queue);
+    if (c->d_frames) (void)hipFree(c->d_frames);
     if (c->hits) (void)hipFree(c->hits);
     if (c->tile_order) (void)hipFree(c->tile_order);
     if (c->wedge_order) (void)hipFree(c->wedge_order);
@@ -1055,11 +1058,13 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
         }
     }
     const size_t px = frame_px(ctx);
+    rto::FrameDesc frames[rto::kMaxBatch];
+    fb.f = ctx->d_frames;
     for (int f = 0; f < n; ++f) {
         if (cams[f].width != ctx->width || cams[f].height != ctx->height)
             return set_err(RTO_E_INVALID, "camera size does not match the render context");
         if (!(cams[f].fx != 0.f) || !(cams[f].fy != 0.f)) return set_err(RTO_E_INVALID, "camera focal length is zero");
-        rto::FrameDesc& d = fb.f[f];
+        rto::FrameDesc& d = frames[f];
         d.fx = cams[f].fx;
         d.fy = cams[f].fy;
         std::memcpy(d.transform, cams[f].transform, sizeof(d.transform));
@@ -1078,6 +1083,7 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     int rc = ensure_jump_table(ctx, stream);
     if (rc != RTO_OK) return rc;
     const rto::OptDev od = make_opt_dev(o);
+    HIP_TRY(rto::launch_write_frames(frames, n, ctx->d_frames, stream));
     hipEvent_t* ev = nullptr;
     if (ctx->kt_on && ctx->kt_count < kKtRing) ev = &ctx->kt_ev[(size_t)ctx->kt_count++ * 3];
     hipError_t e = rto::launch_render_batch(o->spp, tree->dev, od, fb, ctx->jump, ctx->queue,

@@ -73,7 +73,8 @@ struct TileMap {
 
 // One frame of a batched launch (render_persist): its camera, its RNG base state and where its
 // pixels go.  width/height are shared by the batch.
-constexpr int kMaxBatch = 32;
+constexpr int kMaxBatch = 128;
+constexpr int kFrameChunk = 32;  // frame descriptors that travel in one kernarg (a kernarg segment holds 4 KB)
 struct FrameDesc {
     float fx, fy;
     float transform[12];
@@ -96,7 +97,10 @@ struct FrameBatch {
     // the others once that is empty.  n_queues = 1: a single queue over whole frames.
     int n_queues;
     int qstart[kMaxQueues + 1];
-    FrameDesc f[kMaxBatch];
+    const FrameDesc* f;  // [n] in device memory (the context's table, written on the launch stream by write_frames_kernel)
+};
+struct FrameChunk {
+    FrameDesc f[kFrameChunk];
 };
 
 struct FrameOut {

@@ -20,6 +20,9 @@ TileMap make_tile_map(int width, int height, int strip_rows);
 hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev& cam, const OptDev& opt,
                          const Pcg32& rng, const PcgJumpEntry* jump, const FrameOut& fo, int strip_rows, hipStream_t stream);
 
+// writes n frame descriptors (host memory, read before the call returns) into a device table on `stream`
+hipError_t launch_write_frames(const FrameDesc* host, int n, FrameDesc* dev_table, hipStream_t stream);
+
 // occupancy of the persistent kernel, cached per render context (which is per device and per thread): the
 // answer depends on the instantiation and on its dynamic LDS size (deeper trees need more)
 struct OccupancyCache {

@@ -23,7 +23,8 @@ def test_bench_line_has_the_contract_fields():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["value"] > 0
-    assert abs(d["ms_per_step"] * d["value"] - 1000.0) < 1.0  # value = frames / elapsed, ms_per_step = elapsed / frames
+    # value = frames / elapsed, ms_per_step = elapsed / steps, one step = one batch of 4 frames
+    assert abs(d["ms_per_step"] * d["value"] - 4000.0) < 4.0 and d["config"]["frames_per_step"] == 4 and d["config"]["frames_timed"] == 24
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -33,7 +34,7 @@ def test_bench_line_has_the_contract_fields():
     assert rf["traffic"] is None and "ALGORITHMIC" in rf["basis"]  # counter passes exist for the BASELINE workloads only
     for k in ("algorithmic_gbps", "algorithmic_frac", "avg_launch_ms", "frames_per_launch", "tcp"):
         assert k in rf, k
-    assert d["config"]["frames_per_launch"] == rf["frames_per_launch"] == 3.0  # 6 steps in groups of <= 4: the actual value
+    assert d["config"]["frames_per_launch"] == rf["frames_per_launch"] == 4.0  # the actual value
     rl = d["reference_loop"]
     assert rl["batch"] == 1 and rl["fps"] > 0 and rl["render_ms"] > 0 and rl["fps"] < d["reference_timer"]["fps"] * 1.5
     assert d["psnr"]["factorised_vs_exact_filter_db"] > 100.0

@@ -121,8 +121,8 @@ def test_bench_plan_two_ranks_over_gloo(tmp_path):
     import subprocess
     root = os.path.dirname(HERE)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "96", "--warmup", "0",
-           "--scenes", "2", "--plan-only"]
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--batch", "32",
+           "--warmup", "0", "--scenes", "2", "--plan-only"]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-2000:]

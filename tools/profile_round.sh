@@ -8,11 +8,11 @@ O=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 for C in $CFGS; do
   case $C in
-    c2) A="" ; STEPS=96 ;;
-    c5) A="--spp 1 --no-denoise" ; STEPS=96 ;;
-    c4) A="--c4" ; STEPS=64 ;;
+    c2) A="" ; STEPS=2 ;;
+    c5) A="--spp 1 --no-denoise" ; STEPS=2 ;;
+    c4) A="--c4" ; STEPS=2 ;;
   esac
-  B="bench.py $A --cpu-frames 0 --psnr-frames 0 --ref-loop-frames 0 --steps $STEPS --warmup 32"
+  B="bench.py $A --cpu-frames 0 --psnr-frames 0 --ref-loop-frames 0 --steps $STEPS --warmup 1"
   # the plain bench line of the configuration (C2: the full default line with CPU baseline and PSNR)
   if [ $C = c2 ]; then python3 bench.py > $O/${TAG}_bench_c2.json 2> $O/${TAG}_bench_c2.err
   else python3 bench.py $A --cpu-frames 0 --psnr-frames 16 > $O/${TAG}_bench_$C.json 2> $O/${TAG}_bench_$C.err; fi
@@ -27,7 +27,7 @@ for C in $CFGS; do
     i=$((i+1))
     rocprofv3 --pmc $SET --output-format csv -d $O/${TAG}_${C}_pmc_$i -- python3 $B > /dev/null 2> $O/${TAG}_${C}_pmc_$i.err || tail -2 $O/${TAG}_${C}_pmc_$i.err
   done
-  RTO_FRAMES_PER_LAUNCH=32 python3 tools/pmc_summarize.py $O/${TAG}_${C}_pmc_summary.json $O/${TAG}_${C}_pmc_1 $O/${TAG}_${C}_pmc_2 $O/${TAG}_${C}_pmc_3 $O/${TAG}_${C}_pmc_4 $O/${TAG}_${C}_pmc_5 $O/${TAG}_${C}_pmc_6 > /dev/null
+  python3 tools/pmc_summarize.py $O/${TAG}_${C}_pmc_summary.json $O/${TAG}_${C}_pmc_1 $O/${TAG}_${C}_pmc_2 $O/${TAG}_${C}_pmc_3 $O/${TAG}_${C}_pmc_4 $O/${TAG}_${C}_pmc_5 $O/${TAG}_${C}_pmc_6 > /dev/null
   rm -rf $O/${TAG}_${C}_trace $O/${TAG}_${C}_pmc_[1-6] $O/${TAG}_${C}_pmc_[1-6].err
 done
-python3 tools/pmc_traffic.py $O/${TAG}_pmc_traffic.json profiles/r2_probe_ceiling.json $(for C in $CFGS; do echo $C=$O/${TAG}_${C}_pmc_summary.json; done)
+RTO_FRAMES_PER_LAUNCH=100 python3 tools/pmc_traffic.py $O/${TAG}_pmc_traffic.json profiles/r2_probe_ceiling.json $(for C in $CFGS; do echo $C=$O/${TAG}_${C}_pmc_summary.json; done)

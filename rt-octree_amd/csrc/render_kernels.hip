@@ -16,7 +16,7 @@
 //                        ancestor stack in LDS), 8x8-pixel wave tiles in an XCD-interleaved strip
 //                        order, register-resident thresholds/hit lists with static indexing only,
 //                        table-driven RNG jump.
-//   render_persist<SPP>  N == 2, up to 32 frames per launch (the throughput path): persistent waves,
+//   render_persist<SPP>  N == 2, up to 128 frames per launch (the throughput path): persistent waves,
 //                        ray compaction, one ray queue per XCD; sample_kernel before it (thresholds)
 //                        and shade_kernel after it (SH colour + pixel epilogue).
 //

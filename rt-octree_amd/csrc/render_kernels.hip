@@ -354,7 +354,7 @@ __global__ void build_nodew_kernel(const int32_t* __restrict__ child, const uint
 }
 
 // Top-of-tree shortcut (TreeDev::topgrid): one thread per cell of the 2^G-per-axis grid walks its
-// root path over node levels 0..G-1 and records where it ends: {slot | level << 27, nodew[slot]}.
+// root path over node levels 0..G-1 and records where it ends: {slot | level << kGridSlotBits, nodew[slot]}.
 __global__ void build_topgrid_kernel(const uint32_t* __restrict__ nodew, int G, uint2* __restrict__ grid) {
     const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= (1u << (3 * G))) return;
@@ -371,7 +371,7 @@ __global__ void build_topgrid_kernel(const uint32_t* __restrict__ nodew, int G, 
         node += w;
         ++lvl;
     }
-    grid[key] = make_uint2(slot | ((uint32_t)lvl << 27), w);
+    grid[key] = make_uint2(slot | ((uint32_t)lvl << kGridSlotBits), w);
 }
 
 // ------------------------------------------------------------------ fast kernel (N == 2)
@@ -404,8 +404,13 @@ RTO_DEV uint32_t hit_index(uint32_t pixel, uint32_t i, uint32_t SIZE) {
     return kHitsPixelMajor ? pixel * (uint32_t)SPP + i : i * SIZE + pixel;
 }
 
-// Hit list entry: leaf slot in the low 27 bits, (count - 1) in the top 5.
-RTO_DEV uint32_t hit_pack(uint32_t slot, uint32_t cnt) { return slot | ((cnt - 1u) << 27); }
+// Hit list entry: leaf slot in the low hit_slot_bits(SPP) bits, (count - 1) above (rto_kernel_types.h).
+template <int SPP>
+RTO_DEV uint32_t hit_pack(uint32_t slot, uint32_t cnt) { return slot | ((cnt - 1u) << hit_slot_bits(SPP)); }
+template <int SPP>
+RTO_DEV uint32_t hit_slot(uint32_t h) { return h & ((1u << hit_slot_bits(SPP)) - 1u); }
+template <int SPP>
+RTO_DEV uint32_t hit_count(uint32_t h) { return (h >> hit_slot_bits(SPP)) + 1u; }
 
 // Loads the `DD` fp16 values of one leaf record with aligned dword loads and shades it.
 // DD = data_dim (28 for SH9, 49 for SH16); the record starts at a 2-byte aligned address.
@@ -532,8 +537,8 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
                 const uint32_t gs = 24u - (uint32_t)G;
                 const uint32_t key = (((ix >> gs) << G | (iy >> gs)) << G) | (iz >> gs);
                 const uint2 e = tree.topgrid[key];
-                slot = e.x & 0x07ffffffu;
-                lvl = (int)(e.x >> 27);
+                slot = e.x & kGridSlotMask;
+                lvl = (int)(e.x >> kGridSlotBits);
                 node = slot >> 3;
                 w = e.y;
                 have_w = true;
@@ -585,7 +590,7 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
 #pragma unroll
                         for (int i = 0; i < SPP; ++i) dst[i] = dst[i + 1];
                     } while (src + delta >= dst[0]);
-                    const uint32_t h = hit_pack(slot, cnt);
+                    const uint32_t h = hit_pack<SPP>(slot, cnt);
 #pragma unroll
                     for (int i = 0; i < SPP; ++i) hits[i] = (i == (int)sh_nums) ? h : hits[i];
                     ++sh_nums;
@@ -603,8 +608,8 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
 #pragma unroll
             for (int i = 0; i < SPP; ++i) {
                 if (i < (int)sh_nums) {
-                    const uint32_t slot = hits[i] & 0x07ffffffu;
-                    const float cnt = (float)((hits[i] >> 27) + 1u);
+                    const uint32_t slot = hit_slot<SPP>(hits[i]);
+                    const float cnt = (float)hit_count<SPP>(hits[i]);
                     if (tree.format == 1 && tree.data_dim == 28)
                         shade_leaf_packed<28>(tree, slot, basis_fn, cnt, out);
                     else if (tree.format == 1 && tree.data_dim == 49)
@@ -930,8 +935,8 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
 #endif
                 if (grid) {  // the iteration's one load: 8 bytes of the top grid ...
                     const u32x2 e = topgrid[key];  // (through the L1 as well: non-temporal costs 15 %)
-                    slot = e.x & 0x07ffffffu;
-                    rs.prev_lvl = (int)(e.x >> 27);
+                    slot = e.x & kGridSlotMask;
+                    rs.prev_lvl = (int)(e.x >> kGridSlotBits);
                     rs.node = slot >> 3;
                     w = e.y;
                 } else {  // ... or 4 bytes of the traversal image
@@ -971,7 +976,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                                 ++rs.spp;
                                 rs.cur = s_dst[rs.spp * 256];
                             } while (reach >= rs.cur);
-                            hits[rs.hoff + rs.sh_nums * hstride] = hit_pack(slot, cnt);
+                            hits[rs.hoff + rs.sh_nums * hstride] = hit_pack<SPP>(slot, cnt);
                             ++rs.sh_nums;
                             done = rs.spp == (uint32_t)SPP;
                         }
@@ -1231,7 +1236,7 @@ __global__ void __launch_bounds__(256) shade_kernel(const TreeDev tree, const Op
             float basis_fn[RTO_BASIS_MAX_DEV];
             ray_basis(tree, opt, vdir, basis_fn);
             float o[4];
-            leaf_contrib<MODE>(tree, he & 0x07ffffffu, basis_fn, (float)((he >> 27) + 1u), o);
+            leaf_contrib<MODE>(tree, hit_slot<SPP>(he), basis_fn, (float)hit_count<SPP>(he), o);
             s_c[wv][j] = o[0];
             s_c[wv][kShadeCap + j] = o[1];
             s_c[wv][2 * kShadeCap + j] = o[2];
@@ -1249,7 +1254,7 @@ __global__ void __launch_bounds__(256) shade_kernel(const TreeDev tree, const Op
                     out[p][0] += s_c[wv][pos];
                     out[p][1] += s_c[wv][kShadeCap + pos];
                     out[p][2] += s_c[wv][2 * kShadeCap + pos];
-                    out[p][3] += (float)((h[p][i] >> 27) + 1u);
+                    out[p][3] += (float)hit_count<SPP>(h[p][i]);
                 }
             }
         }

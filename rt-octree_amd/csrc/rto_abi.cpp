@@ -63,6 +63,10 @@ int device_of(const void* p) {
     return a.device;
 }
 
+// a hit-list entry packs {slot, count - 1}: at this SPP the tree's leaf slots must fit hit_slot_bits(spp) bits
+// (strictly: the all-ones entry terminates a list)
+bool slots_fit_spp(int64_t n_slots, int spp) { return n_slots < (int64_t(1) << rto::hit_slot_bits(spp)); }
+
 bool spp_supported(int spp) {  // volrend.cu:266-278
     return spp == 1 || spp == 2 || spp == 3 || spp == 4 || spp == 6 || spp == 8 || spp == 16 || spp == 32;
 }
@@ -344,9 +348,9 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
             return fail(RTO_E_HIP, "tree upload failed");
         dev_bytes += data_bytes + 16;
     }
-    // traversal image for the fast kernel: N == 2, depth within the 24 fixed-point bits, slot index
-    // within the 27 bits of a hit-list entry
-    if (N == 2 && max_depth <= 24 && n_slots < (int64_t(1) << 27)) {
+    // traversal image for the fast kernel: N == 2, depth within the 24 fixed-point bits, slot index within the 29
+    // bits of a top-grid entry (the hit-list budget depends on the SPP and is checked per launch: slots_fit_spp)
+    if (N == 2 && max_depth <= 24 && n_slots < (int64_t(1) << rto::kGridSlotBits)) {
         int* d_bad = nullptr;
         if (hipMalloc(&t->d_nodew, (size_t)n_slots * 4) != hipSuccess || hipMalloc((void**)&d_bad, 4) != hipSuccess ||
             hipMemset(d_bad, 0, 4) != hipSuccess)
@@ -944,9 +948,11 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
     if (!(cam->fx != 0.f) || !(cam->fy != 0.f)) return set_err(RTO_E_INVALID, "camera focal length is zero");
 
     int kernel = ctx->kernel;
-    if (kernel == RTO_KERNEL_AUTO) kernel = tree->fast_ok ? RTO_KERNEL_FAST : RTO_KERNEL_GENERIC;
-    if (kernel == RTO_KERNEL_FAST && !tree->fast_ok)
-        return set_err(RTO_E_UNSUPPORTED, "fast kernel needs an N == 2 tree of depth <= 24 and <= 2^27 slots");
+    const bool fast_here = tree->fast_ok && slots_fit_spp(tree->info.capacity * tree->dev.N3, o->spp);
+    if (kernel == RTO_KERNEL_AUTO) kernel = fast_here ? RTO_KERNEL_FAST : RTO_KERNEL_GENERIC;
+    if (kernel == RTO_KERNEL_FAST && !fast_here)
+        return set_err(RTO_E_UNSUPPORTED, "fast kernel needs an N == 2 tree of depth <= 24 whose leaf slots fit 32 - ceil(log2 spp) bits "
+                                          "(2^29 slots at spp <= 8, 2^27 at spp 32)");
 
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");
@@ -996,9 +1002,11 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
         return set_err(RTO_E_UNSUPPORTED, "SG/ASG bases are untested upstream and not built");
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");
-    if (!tree->fast_ok) {
-        // No traversal image (N != 2, depth > 24 or >= 2^27 leaf slots): the same frames, one launch of
-        // the generic kernel each -- same images, without the batching gain.
+    if (!tree->fast_ok || !slots_fit_spp(tree->info.capacity * tree->dev.N3, o->spp)) {
+        // No traversal image (N != 2, depth > 24, >= 2^29 leaf slots) or more slots than a hit-list entry can name at
+        // this SPP: the same frames, one launch of the generic kernel each -- same images, without the batching gain.
+        if (tree->quant)
+            return set_err(RTO_E_UNSUPPORTED, "a quantised tree kept quantised has too many leaf slots for the batched kernels at this spp");
         const rto::OptDev od = make_opt_dev(o);
         const size_t px = frame_px(ctx);
         for (int f = 0; f < n; ++f) {

@@ -13,6 +13,17 @@ namespace rto {
 //   internal slot: the reference's child[] value (relative node offset, |v| < 2^30)
 //   leaf slot:     0x80000000 | fp16 bits of the slot's sigma  -> top two bits are 0b10
 constexpr uint32_t kLeafTag = 0x80000000u;
+
+// Bit budgets of the packed words.  A top-grid entry is {slot | level << kGridSlotBits, word}: the level is < 8 (the
+// grid spans at most 6 node levels), which leaves 29 bits for the slot.  A hit-list entry is {slot | (count - 1) <<
+// hit_slot_bits(SPP)}: count <= SPP, so the slot gets 32 - ceil(log2 SPP) bits -- 29 at SPP <= 8, 27 at SPP 32.  A tree
+// renders through the fast / batched kernels at a given SPP while its leaf slots fit BOTH budgets (strictly: an
+// all-ones entry is the list terminator), i.e. up to 2^29 - 1 slots = 67 M nodes at the benchmark's SPP 6.
+constexpr int kGridSlotBits = 29;
+constexpr uint32_t kGridSlotMask = (1u << kGridSlotBits) - 1u;
+__host__ __device__ constexpr int hit_slot_bits(int spp) {
+    return spp <= 1 ? 31 : spp <= 2 ? 31 : spp <= 4 ? 30 : spp <= 8 ? 29 : spp <= 16 ? 28 : 27;
+}
 __host__ __device__ inline bool nodew_is_leaf(uint32_t w) { return (w >> 30) == 2u; }
 
 struct TreeDev {
@@ -26,7 +37,7 @@ struct TreeDev {
     float ndc_width, ndc_height, ndc_focal;  // ndc_width <= 0: off (data_spec.hpp:49)
     int max_depth;                            // levels of child[] visited to reach the deepest leaf
     // Dense shortcut over the top of the tree (N == 2): G = top_levels bits per axis; entry
-    // [(x*2^G + y)*2^G + z] = {slot | level << 27, nodew[slot]} where the root-path walk of that cell
+    // [(x*2^G + y)*2^G + z] = {slot | level << kGridSlotBits, nodew[slot]} where the root-path walk of that cell
     // over node levels 0..G-1 ends (at a leaf, or at the level G-1 slot).  A march step that restarts
     // above level G costs this one 8-byte, L2-resident load.  nullptr / 0 when absent.
     const uint2* topgrid;

@@ -20,12 +20,12 @@ def main():
     W = H = 800
     fx = synth.blender_focal(W)
     cams = []
-    for p in synth.orbit_poses(200)[:96]:
+    for p in synth.orbit_poses(200)[:200]:
         c = R.Camera(W, H, fx, fx)
         c.set_c2w(p)
         cams.append(c)
     opt = R.RenderOptions(spp=6, denoise=False)
-    B = 32
+    B = 100
     ctx = R.RenderContext(W, H, frames=B)
     stream = torch.cuda.current_stream()
     ref = None

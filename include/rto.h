@@ -19,6 +19,10 @@
  * accessors are plain linear hipMalloc memory (the reference's cudaArray/surface/texture objects
  * are replaced by linear buffers with the same logical layout).
  *
+ * Threading: handles are thread-compatible, not thread-safe -- one rto_ctx (and one rto_guidance_net) per host thread
+ * and per stream at a time: a context owns the hand-off buffers, ray queues and frame table of the launch in flight,
+ * and two batched launches of one context on different streams would share them.
+ *
  * Error convention: every function returning int returns RTO_OK (0) or a negative RTO_E_* code;
  * rto_last_error() gives the message for the calling thread.  The library never calls exit()
  * (the reference does: src/cuda/common.cu:8-21) and never falls back to a CPU path: without a

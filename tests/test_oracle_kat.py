@@ -163,6 +163,10 @@ def test_sh_basis_vs_scipy():
 
 
 def test_frames_match_golden():
+    """SELF-REGRESSION pin: frames_golden.npz was produced by this repository's oracle (tests/golden/make_goldens.py),
+    not by the reference -- it guards the restatement against silent drift.  What ties the restatement to the
+    reference's behaviour: the file:line restatement itself, the reference-header pcg32 KAT, and the independent
+    rendering-equation model of tests/test_expectation.py."""
     g = np.load(os.path.join(HERE, "golden", "frames_golden.npz"))
     W, H, fx = g["size_fx"]
     W, H = int(W), int(H)
@@ -224,7 +228,8 @@ def test_unsupported_inputs():
 
 def test_oracle_reproduces_committed_kat_vectors():
     """tests/golden/kat_golden.npz: point queries, SH basis bit patterns, the
-    L = 4 filter with its saved tensors and gradients -- pins the oracle against silent drift."""
+    L = 4 filter with its saved tensors and gradients -- SELF-REGRESSION vectors (generated by this oracle): they pin the
+    oracle against silent drift, not against the reference."""
     import ctypes as C
     g = np.load(os.path.join(HERE, "golden", "kat_golden.npz"))
     ht = orc.HostTree(g["q.child"], g["q.data"], g["q.scale"], g["q.offset"], "SH4")

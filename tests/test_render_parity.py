@@ -221,7 +221,8 @@ def test_full_size_properties(small_tree_sh9):
 
 
 def test_hip_matches_committed_golden_frames():
-    """HIP path vs tests/golden/frames_golden.npz (aux fp32 bits + RGBA8 bytes)."""
+    """HIP path vs tests/golden/frames_golden.npz (aux fp32 bits + RGBA8 bytes) -- frames produced by this repository's
+    oracle (a self-regression pin, not reference output)."""
     import os
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frames_golden.npz"))
     W, H, fx = g["size_fx"]

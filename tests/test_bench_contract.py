@@ -76,3 +76,26 @@ def test_bench_scenes_mode_reports_both_mappings():
     assert d["config"]["scenes"] == 2 and d["config"]["scene_map"] == "pose" and d["value"] > 0
     assert d["alt_scene_map"]["scene_map"] == "scene" and d["alt_scene_map"]["value"] > 0
     assert "2 scenes" in d["config"]["workload"]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """the driver's torchrun line with two ranks (both on GPU 0, gloo instead of RCCL: RCCL refuses two ranks on one
+    device): rank / pose bookkeeping, the barrier + max-reduction of the elapsed time, one JSON line from rank 0 with
+    the whole-job frame count."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4",
+           "--size", "128", "--depth", "5", "--cpu-frames", "0", "--psnr-frames", "0", "--ref-loop-frames", "2"]
+    env = dict(os.environ, RTO_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["frames_timed"] == 24 and d["value"] > 0
+    assert d["cpu_baseline"] is None  # N == 1 only

@@ -127,6 +127,10 @@ int rto_tree_load_npz(const char* path, int device, rto_tree** out);
  * SH4/9/16/25 only; such a tree renders through the batched kernels (also for single frames).
  * Ignored for dense files. */
 #define RTO_TREE_QUANT_DIRECT 1
+/* RTO_TREE_COMPACT: do not build the aligned copy of the SH coefficients the shading kernels otherwise read (dense SH9 /
+ * SH16 trees: + 64 / 128 B per leaf slot, i.e. the device footprint roughly doubles, for ~11 % faster shading = ~2 % more
+ * frames/s on the benchmark scene).  Same pixels either way. */
+#define RTO_TREE_COMPACT 2
 int rto_tree_load_npz_ex(const char* path, int device, int flags, rto_tree** out);
 /* Same upload from host arrays: child int32 [capacity*N^3], data fp16 bits
  * [capacity*N^3*data_dim], data_format like "SH9"/"SH16"/"RGBA" (DataFormat::parse,

@@ -353,6 +353,17 @@ __global__ void build_nodew_kernel(const int32_t* __restrict__ child, const uint
     }
 }
 
+// Aligned copy of the SH coefficients for the shading kernels (TreeDev::shrec): per slot the 3 B coefficients of
+// data[] in the same order, zero-padded to shrec_halves(B).  Derived data: the same fp16 values.
+__global__ void build_shrec_kernel(const uint16_t* __restrict__ data, int64_t n_slots, int data_dim, int rec,
+                                   uint16_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per output half
+    if (i >= n_slots * rec) return;
+    const int64_t slot = i / rec;
+    const int k = (int)(i - slot * rec);
+    out[i] = k < data_dim - 1 ? data[slot * data_dim + k] : (uint16_t)0;
+}
+
 // Top-of-tree shortcut (TreeDev::topgrid): one thread per cell of the 2^G-per-axis grid walks its
 // root path over node levels 0..G-1 and records where it ends: {slot | level << kGridSlotBits, nodew[slot]}.
 __global__ void build_topgrid_kernel(const uint32_t* __restrict__ nodew, int G, uint2* __restrict__ grid) {
@@ -414,23 +425,44 @@ RTO_DEV uint32_t hit_count(uint32_t h) { return (h >> hit_slot_bits(SPP)) + 1u; 
 
 // Loads the `DD` fp16 values of one leaf record with aligned dword loads and shades it.
 // DD = data_dim (28 for SH9, 49 for SH16); the record starts at a 2-byte aligned address.
+// halves per record of the aligned SH-coefficient copy (TreeDev::shrec): the 3 B coefficients in a power-of-two stride,
+// so that a record lies in ONE 128-byte line -- SH9 64 B, SH16 128 B.  (Measured, 100 frames of the bench scene: SH16
+// shading 2.53 ms from data[], 2.36 with 96-byte records, 2.24 with 128-byte ones; SH25 records -- 150 B -- gain
+// nothing at 160 B and lose at 256 B, so SH25 trees are shaded from data[].)
+__host__ __device__ constexpr int shrec_halves(int basis_dim) { return 3 * basis_dim * 2 <= 64 ? 32 : 64; }
+
 template <int DD>
 RTO_DEV void shade_leaf_packed(const TreeDev& tree, uint32_t slot, const float* basis_fn, float cnt, float* out) {
     constexpr int B = (DD - 1) / 3;
-    constexpr int NDW = (DD + 2) / 2;  // dwords covering DD halves at either alignment
-    const uint64_t hoff = (uint64_t)slot * DD;  // in halves
-    const uint32_t odd = (uint32_t)hoff & 1u;
-    const uint32_t* __restrict__ p = reinterpret_cast<const uint32_t*>(tree.data + (hoff - odd));
-    uint32_t dw[NDW];
-#pragma unroll
-    for (int i = 0; i < NDW; ++i) dw[i] = p[i];
-    // bring half k of the record to packed position k: a funnel shift by 0 or 16 bits per dword
-    // (v_alignbit_b32) instead of extracting every coefficient at both alignments and selecting
     constexpr int NAL = (DD + 1) / 2;
-    const uint32_t sh = odd * 16u;
     uint32_t al[NAL];
+    if (B <= 16 && tree.shrec) {
+        // the aligned copy: 16-byte loads, every coefficient already at its packed position, one 128-byte line per
+        // record (a 98-byte record at a 2-byte aligned address straddles 1.76 lines on average)
+        constexpr int NQ = (3 * B * 2 + 15) / 16;  // 16-byte loads that hold coefficients
+        const uint4* __restrict__ q = reinterpret_cast<const uint4*>(tree.shrec + (uint64_t)slot * shrec_halves(B));
+        uint4 v[NQ];
 #pragma unroll
-    for (int i = 0; i < NAL; ++i) al[i] = __builtin_amdgcn_alignbit(i + 1 < NDW ? dw[i + 1] : 0u, dw[i], sh);
+        for (int i = 0; i < NQ; ++i) v[i] = q[i];
+#pragma unroll
+        for (int i = 0; i < NAL; ++i) {
+            const uint4& w = v[i >> 2];
+            al[i] = (i & 3) == 0 ? w.x : (i & 3) == 1 ? w.y : (i & 3) == 2 ? w.z : w.w;
+        }
+    } else {
+        constexpr int NDW = (DD + 2) / 2;  // dwords covering DD halves at either alignment
+        const uint64_t hoff = (uint64_t)slot * DD;  // in halves
+        const uint32_t odd = (uint32_t)hoff & 1u;
+        const uint32_t* __restrict__ p = reinterpret_cast<const uint32_t*>(tree.data + (hoff - odd));
+        uint32_t dw[NDW];
+#pragma unroll
+        for (int i = 0; i < NDW; ++i) dw[i] = p[i];
+        // bring half k of the record to packed position k: a funnel shift by 0 or 16 bits per dword
+        // (v_alignbit_b32) instead of extracting every coefficient at both alignments and selecting
+        const uint32_t sh = odd * 16u;
+#pragma unroll
+        for (int i = 0; i < NAL; ++i) al[i] = __builtin_amdgcn_alignbit(i + 1 < NDW ? dw[i + 1] : 0u, dw[i], sh);
+    }
     auto coef = [&](int k) -> float {
         return half_bits_to_float((uint16_t)((k & 1) ? (al[k >> 1] >> 16) : (al[k >> 1] & 0xffffu)));
     };
@@ -1318,6 +1350,12 @@ hipError_t launch_build_nodew(const int32_t* child, const uint16_t* data, int64_
     const int64_t blocks = (n_slots + threads - 1) / threads;
     hipLaunchKernelGGL(build_nodew_kernel, dim3((unsigned)blocks), dim3(threads), 0, stream, child, data, n_slots,
                        data_dim, nodew, bad_flag);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_shrec(const uint16_t* data, int64_t n_slots, int data_dim, int rec, uint16_t* out, hipStream_t stream) {
+    const int64_t n = n_slots * rec;
+    hipLaunchKernelGGL(build_shrec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data, n_slots, data_dim, rec, out);
     return hipGetLastError();
 }
 

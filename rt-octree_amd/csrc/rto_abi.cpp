@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -81,6 +82,7 @@ struct rto_tree {
     void* d_child = nullptr;
     void* d_nodew = nullptr;
     void* d_topgrid = nullptr;
+    void* d_shrec = nullptr;  // aligned copy of the SH coefficients (shading)
     void* d_qrec = nullptr;
     void* d_qcolors = nullptr;
     void* d_qsigma = nullptr;
@@ -248,7 +250,7 @@ void relay_tree(const std::vector<int64_t>& order, const int32_t* child, const u
 
 int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, int N, int data_dim,
                 const rto::DataFormat& fmt, const float scale[3], const float offset[3], int device,
-                rto_tree** out, const rto::HostTree* quant = nullptr) {
+                rto_tree** out, const rto::HostTree* quant = nullptr, int flags = 0) {
     if (!child || (!data && !quant) || capacity <= 0 || N < 1 || data_dim < 1 || !out)
         return set_err(RTO_E_INVALID, "rto_tree: null array or non-positive size");
     if (quant && (N != 2 || fmt.format != RTO_FMT_SH ||
@@ -385,6 +387,22 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
         dev_bytes += gbytes;
     }
 
+    if (t->fast_ok && !quant && fmt.format == RTO_FMT_SH && (fmt.basis_dim == 9 || fmt.basis_dim == 16) &&
+        !(flags & RTO_TREE_COMPACT) && !std::getenv("RTO_NO_SHREC")) {  // (the variable: tests)
+        // aligned copy of the SH coefficients for the shading kernels (+ 64 / 128 B per slot)
+        const int rec = 3 * fmt.basis_dim * 2 <= 64 ? 32 : 64;  // = shrec_halves()
+        const size_t rb = (size_t)n_slots * rec * 2;
+        if (hipMalloc(&t->d_shrec, rb) == hipSuccess) {
+            hipError_t e = rto::launch_build_shrec((const uint16_t*)t->d_data, n_slots, data_dim, rec, (uint16_t*)t->d_shrec, nullptr);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (e != hipSuccess) return fail(RTO_E_HIP, std::string("build_shrec failed: ") + hipGetErrorString(e));
+            dev_bytes += rb;
+        } else {  // not enough memory for the copy: shade from data[]
+            (void)hipGetLastError();
+            t->d_shrec = nullptr;
+        }
+    }
+
     rto::TreeDev& d = t->dev;
     if (t->d_qsigma) {  // sigma now lives in the traversal image
         (void)hipFree(t->d_qsigma);
@@ -394,6 +412,7 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
     if (quant && !t->fast_ok) return fail(RTO_E_UNSUPPORTED, "direct rendering of quantised trees needs the N == 2 traversal image");
     d.topgrid = (const uint2*)t->d_topgrid;
     d.top_levels = top_levels;
+    d.shrec = (const uint16_t*)t->d_shrec;
     d.qrec = (const uint16_t*)t->d_qrec;
     d.qcolors = (const uint2*)t->d_qcolors;
     d.q_retain = quant ? quant->n_retain : 0;
@@ -557,7 +576,7 @@ int rto_tree_load_npz_ex(const char* path, int device, int flags, rto_tree** out
     }
     std::fprintf(stdout, "INFO: Scale %f %f %f\n", h.scale[0], h.scale[1], h.scale[2]);  // n3tree.cpp:264
     int rc = upload_tree(h.child, h.data, h.capacity, h.N, h.data_dim, h.data_format, h.scale, h.offset, device, out,
-                         h.quantized ? &h : nullptr);
+                         h.quantized ? &h : nullptr, flags);
     if (rc != RTO_OK) return rc;
     if (h.use_ndc) rto_tree_set_ndc(*out, h.ndc_width, h.ndc_height, h.ndc_focal);
     return RTO_OK;
@@ -644,6 +663,7 @@ void rto_tree_free(rto_tree* t) {
     if (t->d_child) (void)hipFree(t->d_child);
     if (t->d_nodew) (void)hipFree(t->d_nodew);
     if (t->d_topgrid) (void)hipFree(t->d_topgrid);
+    if (t->d_shrec) (void)hipFree(t->d_shrec);
     for (void* p : {t->d_qrec, t->d_qcolors, t->d_qsigma})
         if (p) (void)hipFree(p);
     delete t;

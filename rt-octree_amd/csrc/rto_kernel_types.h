@@ -42,6 +42,10 @@ struct TreeDev {
     // above level G costs this one 8-byte, L2-resident load.  nullptr / 0 when absent.
     const uint2* topgrid;
     int top_levels;
+    // Aligned copy of the SH coefficients for shading (dense SH9 / SH16 / SH25 trees, N == 2): per slot the 3 B
+    // coefficients in data[]'s order, padded to a multiple of 32 B (64 / 96 / 160 B) so that a record is fetched by
+    // 16-byte loads from sectors of its own; nullptr when absent (shading then reads data[]).
+    const uint16_t* shrec;
     // Quantised tree rendered WITHOUT expansion (the inputs of n3tree.cpp:279-340):
     // `data` is nullptr; per leaf slot one record of q_rec u16 values, `qrec[slot * q_rec + ...]`:
     //   [3 * q_retain] fp16 retained coefficients, (basis k, channel c) at k * 3 + c

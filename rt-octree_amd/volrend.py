@@ -112,17 +112,18 @@ class N3Tree:
     """Device-resident PlenOctree.  `N3Tree(path)` = N3Tree::open + load_cuda
     (n3tree.cpp:111-154, n3tree.cu:9-41)."""
 
-    def __init__(self, path=None, device=0, quant_direct=False):
+    def __init__(self, path=None, device=0, quant_direct=False, compact=False):
         self._h = C.c_void_p(0)
         self.device = device
         self.quant_direct = bool(quant_direct)  # render a quantised tree from its codebooks (no expansion)
+        self.compact = bool(compact)            # RTO_TREE_COMPACT: no aligned copy of the SH coefficients for shading
         if path is not None:
             self.open(path)
 
     def open(self, path):
         self.free()
         h = C.c_void_p(0)
-        check(lib().rto_tree_load_npz_ex(os.fsencode(path), self.device, 1 if self.quant_direct else 0, C.byref(h)))
+        check(lib().rto_tree_load_npz_ex(os.fsencode(path), self.device, (1 if self.quant_direct else 0) | (2 if self.compact else 0), C.byref(h)))
         self._h = h
         self._refresh()
 

@@ -149,6 +149,27 @@ def test_batched_path_on_shallow_and_deep_trees(depth, basis):
         assert_bits_equal(ctx.download_aux(), want, "depth %d spp %d" % (depth, spp))
 
 
+@pytest.mark.parametrize("basis", [9, 16])
+def test_shading_from_the_aligned_copy_and_from_data_agree(basis, monkeypatch):
+    """dense SH9 / SH16 trees are shaded from an aligned copy of their coefficients (TreeDev::shrec); with the copy
+    switched off (RTO_NO_SHREC; RTO_TREE_COMPACT for files) the kernels read the 2-byte-aligned records of data[] --
+    same fp16 values, same pixels"""
+    tree = synth.make_tree(depth_limit=5, basis_dim=basis, seed=basis)
+    ht, dt = make_pair(tree)
+    assert dt.device_bytes > tree.data.nbytes * 1.9  # data + the padded copy
+    monkeypatch.setenv("RTO_NO_SHREC", "1")
+    _, dt_plain = make_pair(tree)
+    monkeypatch.delenv("RTO_NO_SHREC")
+    assert dt_plain.device_bytes < dt.device_bytes
+    ocam, cam = cameras(64, 48, POSES[1])
+    want = oracle_frame(ht, ocam, 6, frame=2)[0]
+    for t in (dt, dt_plain):
+        assert_bits_equal(hip_frame(t, cam, 6, frame=2, kernel=R.KERNEL_FAST)[0], want, "single frame")
+        ctx = R.RenderContext(64, 48, frames=1)
+        R.launch_renderer_batch(t, [cam], R.RenderOptions(spp=6, denoise=False), ctx, rng_jumps=[2])
+        assert_bits_equal(ctx.download_aux(), want, "batched")
+
+
 def test_camera_inside_box_and_miss(small_tree_sh9):
     """tmin clamps at 0 for a camera inside the volume; rays that miss return background
     (rt_core.cuh:219-222; SURVEY appendix B 3,4)."""
@@ -252,6 +273,17 @@ def test_work_counters_match_oracle(small_tree_sh16):
     ctx.enable_stats(False)
     aux_t, _, _ = hip_frame(dt, cam, 6, frame=1, kernel=R.KERNEL_FAST, ctx=ctx)
     assert_bits_equal(aux_s, aux_t, "counting instantiation renders the same frame")
+
+
+def test_compact_flag_skips_the_shading_copy(tmp_path, small_tree_sh16):
+    p = str(tmp_path / "t.npz")
+    small_tree_sh16.save_npz(p)
+    full, compact = R.N3Tree(p), R.N3Tree(p, compact=True)
+    assert compact.device_bytes < full.device_bytes
+    _, cam = cameras(48, 40, POSES[0])
+    a = hip_frame(full, cam, 6)[0]
+    b = hip_frame(compact, cam, 6)[0]
+    assert_bits_equal(a, b, "compact vs default")
 
 
 def test_tree_npz_roundtrip_on_device(tmp_path, small_tree_sh9):

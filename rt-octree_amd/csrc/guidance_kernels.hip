@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
     const int tile_x = tx_first + ts;
     if (tile_x >= tiles_x) break;  // workgroup-uniform
     const int x0 = tile_x * kGW;
+    const bool tile_interior = x0 >= 1 && x0 + kGW + 1 <= W && y0 >= 1 && y0 + kGH + 1 <= H;  // layer-1 region inside the image
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int e = tid + it * 256;
@@ -183,9 +184,11 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
             static_assert(AH * AW < 2048, "reciprocal division below assumes a small tile");
             const int q = (int)(__umul24((unsigned)p, (65536u + AW - 1) / AW) >> 16);  // p / AW for p < 2048
             const int ry = valid ? q : 0, rx = valid ? p - (int)__umul24((unsigned)q, AW) : 0;
+            // the accumulators start from the bias (lane element i of tile t is output channel t*16 + kg*4 + i): one
+            // operand of the first MFMA instead of eight additions per group
             float4v acc[NT1];
 #pragma unroll
-            for (int t = 0; t < NT1; ++t) acc[t] = (float4v){0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NT1; ++t) acc[t] = (float4v){bias[t][0], bias[t][1], bias[t][2], bias[t][3]};
             half8 bf1[3];
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) {
@@ -201,15 +204,22 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
 #pragma unroll
                 for (int t = 0; t < NT1; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][ks], bf1[ks], acc[t], 0, 0, 0);
             if (valid) {
-                const int gx = x0 - 1 + rx, gy = y0 - 1 + ry;
-                // outside the image the activation is the second convolution's zero padding: scale by 0 (branch-free;
-                // relu6(...) is finite and >= 0, so x * 1 = x and x * 0 = +0 exactly)
-                const float inside = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? 1.f : 0.f;
+                // outside the image the activation is the second convolution's zero padding.  Most tiles lie inside with
+                // their halo (workgroup-uniform test): no mask at all there; border tiles scale by 0 or 1 (relu6(...) is
+                // finite and >= 0, so x * 1 = x and x * 0 = +0 exactly)
+                float inside = 1.f;
+                if (!tile_interior) {
+                    const int gx = x0 - 1 + rx, gy = y0 - 1 + ry;
+                    inside = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? 1.f : 0.f;
+                }
 #pragma unroll
                 for (int t = 0; t < NT1; ++t) {
                     half4 o;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (_Float16)(relu6(acc[t][i] + bias[t][i]) * inside);
+                    for (int i = 0; i < 4; ++i) {
+                        const float r = __builtin_amdgcn_fmed3f(acc[t][i], 0.f, 6.f);  // ReLU6
+                        o[i] = (_Float16)(tile_interior ? r : r * inside);
+                    }
                     *reinterpret_cast<half4*>(s_act + __umul24((unsigned)p, AS) + t * 16 + kg * 4) = o;
                 }
             }
@@ -235,7 +245,7 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
             if (RTO_NET_DBG_CREP > 1) asm volatile("" ::: "memory");
             const int p = g * 16 + col;
             const int oy = p / kGW, ox = p - oy * kGW;
-            float4v acc = (float4v){0.f, 0.f, 0.f, 0.f};
+            float4v acc = (float4v){bias[0], bias[1], bias[2], bias[3]};  // the bias: the first MFMA's C operand
             // all of the group's B fragments first, each into registers of its own, then the MFMA chain: with one
             // fragment register set the compiler serialises read -> wait -> MFMA nine times and the group costs nine
             // LDS latencies (measured: 1.5 k clocks per group at 4 waves per SIMD)
@@ -254,7 +264,7 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
             if (gx < W && gy < H && kg * 4 < 2 * L) {
                 float v[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = (float)(_Float16)relu6(acc[i] + bias[i]);  // fp16 activations, then .float()
+                for (int i = 0; i < 4; ++i) v[i] = (float)(_Float16)__builtin_amdgcn_fmed3f(acc[i], 0.f, 6.f);  // ReLU6 -> fp16 activations, then .float()
                 const int64_t pix = (int64_t)gy * W + gx;
                 if (PACK) {  // (weight_out = the packed buffer of image blockIdx.z; kg 0: logits, kg 1: guidance)
                     half4 h;

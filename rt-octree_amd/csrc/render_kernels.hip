@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(256) render_generic(const TreeDev tree, const 
             // sample_dst rt_core.cuh:67-193
             float dst[SPP + 1];
             for (int n = 1; n <= SPP; ++n) {
-                const float tv = -det_logf(1.0f - pcg_next_float(rng));
+                const float tv = -det_log_one_minus(pcg_next_float(rng));
                 if (n == 1) {
                     dst[0] = tv;
                 } else if (tv <= dst[0]) {
@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
         float dst[SPP + 1];
 #pragma unroll
         for (int n = 0; n < SPP; ++n) {
-            float tv = -det_logf(1.0f - pcg_next_float(rng));
+            float tv = -det_log_one_minus(pcg_next_float(rng));
 #pragma unroll
             for (int i = 0; i < n; ++i) {  // static-index insertion: same sorted array
                 const float lo = f_min(dst[i], tv), hi = f_max(dst[i], tv);
@@ -751,7 +751,7 @@ __global__ void __launch_bounds__(256) sample_kernel(const FrameBatch fb, const 
     float dst[SPP];
 #pragma unroll
     for (int n = 0; n < SPP; ++n) {
-        float tv = -det_logf(1.0f - pcg_next_float(rng));
+        float tv = -det_log_one_minus(pcg_next_float(rng));
 #pragma unroll
         for (int i = 0; i < n; ++i) {  // static-index insertion: same sorted array
             const float lo = f_min(dst[i], tv), hi = f_max(dst[i], tv);

@@ -72,23 +72,8 @@ RTO_DEV float half_bits_to_float(uint16_t h) { return (float)__builtin_bit_cast(
 
 // ---- deterministic logf / expf: constants and operation order identical to
 //      oracle/rto_oracle.c orc_det_logf / orc_det_expf ----
-RTO_DEV float det_logf(float x) {
-    const uint32_t u = __float_as_uint(x);
-    if (x != x) return x;
-    if (u == 0x7f800000u) return x;
-    if ((u << 1) == 0) return -__builtin_inff();
-    if (u >> 31) return __builtin_nanf("");
-    int e = (int)(u >> 23) - 127;
-    uint32_t man = u & 0x7fffffu;
-    if ((u >> 23) == 0) {
-        int sh = 0;
-        while (!(man & 0x800000u)) {
-            man <<= 1;
-            ++sh;
-        }
-        man &= 0x7fffffu;
-        e = -126 - sh;
-    }
+// the reduction + series of det_logf for a POSITIVE NORMAL finite x (exponent e, mantissa bits man)
+RTO_DEV float det_logf_core(int e, uint32_t man) {
     double md = (double)__uint_as_float(man | 0x3f800000u);
     if (md > 1.4142135623730951) {
         md = md * 0.5;
@@ -107,6 +92,34 @@ RTO_DEV float det_logf(float x) {
     const double lm = 2.0 * s + (2.0 * s) * p;
     const double r = (double)e * 0.6931471805599453 + lm;
     return (float)r;
+}
+
+RTO_DEV float det_logf(float x) {
+    const uint32_t u = __float_as_uint(x);
+    if (x != x) return x;
+    if (u == 0x7f800000u) return x;
+    if ((u << 1) == 0) return -__builtin_inff();
+    if (u >> 31) return __builtin_nanf("");
+    int e = (int)(u >> 23) - 127;
+    uint32_t man = u & 0x7fffffu;
+    if ((u >> 23) == 0) {
+        int sh = 0;
+        while (!(man & 0x800000u)) {
+            man <<= 1;
+            ++sh;
+        }
+        man &= 0x7fffffu;
+        e = -126 - sh;
+    }
+    return det_logf_core(e, man);
+}
+
+// det_logf(1 - u) for u = pcg_next_float() in [0, 1 - 2^-23]: the argument is a positive normal number in
+// [2^-23, 1], so none of det_logf's special cases (NaN, infinity, zero, negative, subnormal) can occur and the same
+// value comes out of the core alone -- the threshold draws (6 per pixel) skip those tests and the subnormal loop.
+RTO_DEV float det_log_one_minus(float u01) {
+    const uint32_t u = __float_as_uint(1.0f - u01);
+    return det_logf_core((int)(u >> 23) - 127, u & 0x7fffffu);
 }
 
 RTO_DEV float det_expf(float x) {

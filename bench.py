@@ -85,6 +85,8 @@ def parse_args(argv=None):
                          "rank s mod N; 'both' = time both, headline the pose mapping")
     ap.add_argument("--quant-direct", action="store_true",
                     help="with --tree <quantised tree.npz>: render from the codebooks instead of the expanded fp16 tree")
+    ap.add_argument("--tuning", default="",
+                    help="development: rto_ctx_set_tuning keys for the batched path, e.g. cu_queues=32,queue_group=16")
     ap.add_argument("--streams", type=int, default=1,
                     help="groups alternate over this many HIP streams (each with its own context): the tail of one "
                          "group's kernels overlaps the next group's; per-kernel durations then include the sharing")
@@ -268,6 +270,8 @@ def main():
         c.set_c2w(p)
         cams.append(c)
     ctx = R.RenderContext(W, H, device=local_rank, frames=B)
+    for kv in filter(None, args.tuning.split(",")):
+        ctx.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
     denoise = not args.no_denoise
     opt = R.RenderOptions(spp=args.spp, denoise=denoise)
     net = full = compact = None

@@ -297,6 +297,8 @@ def main():
     lanes = [(ctx, stream, net, aux_t)]
     for _ in range(1, max(1, args.streams)):
         c2 = R.RenderContext(W, H, device=local_rank, frames=B)
+        for kv in filter(None, args.tuning.split(",")):
+            c2.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
         n2 = None
         if denoise:
             n2 = compact.half().to(dev) if args.torch_net else denoiser.FusedGuidanceNet(compact, device=local_rank)

@@ -415,13 +415,13 @@ RTO_DEV uint32_t hit_index(uint32_t pixel, uint32_t i, uint32_t SIZE) {
     return kHitsPixelMajor ? pixel * (uint32_t)SPP + i : i * SIZE + pixel;
 }
 
-// Hit list entry: leaf slot in the low hit_slot_bits(SPP) bits, (count - 1) above (rto_kernel_types.h).
+// Hit list entry: leaf slot in the low hit_slot_bits(SPP) bits, (count - 1) above, kHitValid on top (rto_kernel_types.h).
 template <int SPP>
-RTO_DEV uint32_t hit_pack(uint32_t slot, uint32_t cnt) { return slot | ((cnt - 1u) << hit_slot_bits(SPP)); }
+RTO_DEV uint32_t hit_pack(uint32_t slot, uint32_t cnt) { return kHitValid | slot | ((cnt - 1u) << hit_slot_bits(SPP)); }
 template <int SPP>
 RTO_DEV uint32_t hit_slot(uint32_t h) { return h & ((1u << hit_slot_bits(SPP)) - 1u); }
 template <int SPP>
-RTO_DEV uint32_t hit_count(uint32_t h) { return (h >> hit_slot_bits(SPP)) + 1u; }
+RTO_DEV uint32_t hit_count(uint32_t h) { return ((h & ~kHitValid) >> hit_slot_bits(SPP)) + 1u; }
 
 // Loads the `DD` fp16 values of one leaf record with aligned dword loads and shades it.
 // DD = data_dim (28 for SH9, 49 for SH16); the record starts at a 2-byte aligned address.
@@ -678,9 +678,8 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
 // (profiles/r1_a_*: mean residency 1.7 k of 8 k wave slots).  Here a fixed grid of persistent
 // waves pulls rays from queues that span every frame of the batch:
 //   * ray compaction: a lane whose ray ended (all SPP thresholds crossed, left the box, missed)
-//     idles only until the wave has REFILL such lanes; then the finished lanes terminate their hit
-//     lists and a ballot / mbcnt prefix sum hands each idle lane the next ray of the wave's
-//     reservoir (one atomicAdd per 64-256 rays);
+//     idles only until the wave has REFILL such lanes; then a ballot / mbcnt prefix sum hands each
+//     idle lane the next ray of the wave's reservoir (one atomicAdd per 64-256 rays);
 //   * rays are queued in 8x8-pixel tile order, so a wave's 64 rays stay spatially coherent; one
 //     queue per XCD over an image wedge each, tile-major across the frames (FrameBatch::qstart);
 //   * the end-of-queue drain happens once per batch instead of once per frame.
@@ -761,7 +760,9 @@ __global__ void __launch_bounds__(256) sample_kernel(const FrameBatch fb, const 
         dst[n] = tv;
     }
 #pragma unroll
-    for (int i = 0; i < SPP; ++i) fd.hits[hit_index<SPP>(idx, (uint32_t)i, SIZE)] = __float_as_uint(dst[i]);
+    // (-log(1 - 0) = -0.0: the thresholds are only ever compared, so +0.0 serves; its clear top bit is what the
+    //  shading kernel ends a hit list on)
+    for (int i = 0; i < SPP; ++i) fd.hits[hit_index<SPP>(idx, (uint32_t)i, SIZE)] = __float_as_uint(dst[i]) & ~kHitValid;
 }
 
 // REFILL = idle lanes that trigger a retire + refill round
@@ -818,7 +819,6 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
 #endif
     RayState rs;
     bool active = false;    // marching
-    bool pending = false;   // finished, hit list not yet terminated
     bool drained = false;   // queue exhausted (wave-uniform)
     const uint32_t kChunk = chunk;           // rays per global dequeue (a multiple of the 64-ray tile)
     uint32_t res_next = 0, res_end = 0;      // the wave's private reservoir (wave-uniform)
@@ -827,11 +827,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
         const unsigned long long act_mask = __ballot(active);
         if (64 - __popcll(act_mask) >= REFILL || act_mask == 0ULL) {
             for (;;) {
-                // ---- retire: terminate the hit list of every ray that has finished
-                if (pending && !active) {
-                    if (rs.sh_nums < (uint32_t)SPP) hits[rs.hoff + rs.sh_nums * hstride] = kNoHit;
-                    pending = false;
-                }
+                // (a finished ray needs no retiring: the stale threshold behind its last hit entry ends the list)
                 if (drained) break;
                 // ---- refill: hand the next queue entries to the idle lanes (ballot + prefix sum)
                 const unsigned long long need = __ballot(!active);
@@ -885,7 +881,6 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                         float tmin;
                         rs.hoff = (uint32_t)frame * (uint32_t)SPP * SIZE + hit_index<SPP>((uint32_t)(y * W + x), 0u, SIZE);
                         rs.sh_nums = 0;
-                        pending = true;  // a ray that misses the box just gets its list terminated
                         if (ray_enter(tree, opt, rs.dir, rs.cen, 1e9f, rs.invdir, rs.delta_scale, tmin, rs.tmax)) {
                             // sorted thresholds of this pixel (sample_kernel left them in the hand-off
                             // buffer, where the ray's hit list will overwrite them)
@@ -1130,7 +1125,7 @@ hipError_t launch_pack_quant(const uint16_t* qmap, const uint16_t* retained, int
 
 // ------------------------------------------------------------------ shading kernel
 // Second half of trace_ray (rt_core.cuh:272-331) + the pixel epilogue (volrend.cu:174-212) for the
-// batched path.  hits: packed entries per frame, kNoHit-terminated (layout: hit_index).
+// batched path.  hits: packed entries per frame, ended by the first word without kHitValid (layout: hit_index).
 //
 // Only about a quarter of the pixels hit anything and those that do hold 1..SPP leaves, so a
 // thread-per-pixel loop leaves most lanes idle while the gathers of a few run.  Instead each wave
@@ -1193,18 +1188,18 @@ __global__ void __launch_bounds__(256) shade_kernel(const TreeDev tree, const Op
                 for (int i = 0; i < SPP; ++i) raw[i] = hp[i];
 #pragma unroll
                 for (int i = 0; i < SPP; ++i) {
-                    open = open && raw[i] != kNoHit;
-                    h[p][i] = open ? raw[i] : kNoHit;
+                    open = open && (raw[i] & kHitValid) != 0u;
+                    h[p][i] = open ? raw[i] : 0u;
                     n[p] += open ? 1u : 0u;
                 }
             } else {
                 const uint32_t* hp = fd.hits + idx;
 #pragma unroll
                 for (int i = 0; i < SPP; ++i) {
-                    h[p][i] = kNoHit;
+                    h[p][i] = 0u;
                     if (open) {
                         h[p][i] = hp[(int64_t)i * SIZE];
-                        open = h[p][i] != kNoHit;
+                        open = (h[p][i] & kHitValid) != 0u;
                         n[p] += open ? 1u : 0u;
                     }
                 }

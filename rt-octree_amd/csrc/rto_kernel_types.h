@@ -15,14 +15,17 @@ namespace rto {
 constexpr uint32_t kLeafTag = 0x80000000u;
 
 // Bit budgets of the packed words.  A top-grid entry is {slot | level << kGridSlotBits, word}: the level is < 8 (the
-// grid spans at most 6 node levels), which leaves 29 bits for the slot.  A hit-list entry is {slot | (count - 1) <<
-// hit_slot_bits(SPP)}: count <= SPP, so the slot gets 32 - ceil(log2 SPP) bits -- 29 at SPP <= 8, 27 at SPP 32.  A tree
-// renders through the fast / batched kernels at a given SPP while its leaf slots fit BOTH budgets (strictly: an
-// all-ones entry is the list terminator), i.e. up to 2^29 - 1 slots = 67 M nodes at the benchmark's SPP 6.
+// grid spans at most 6 node levels), which leaves 29 bits for the slot.  A hit-list entry is {kHitValid | slot |
+// (count - 1) << hit_slot_bits(SPP)}: count <= SPP, so the slot gets 31 - ceil(log2 SPP) bits -- 28 at SPP <= 8, 26 at
+// SPP 32.  A tree renders through the fast / batched kernels at a given SPP while its leaf slots fit BOTH budgets,
+// i.e. up to 2^28 - 1 slots = 33 M nodes at the benchmark's SPP 6.
+// kHitValid: the hand-off buffer holds a pixel's sorted thresholds (non-negative floats: top bit clear) until the
+// traversal overwrites the first entries with its hit list, so the first word with a clear top bit ends the list --
+// no terminator is ever written (round 1 wrote one scattered dword per ray: most of the kernel's HBM writes).
 constexpr int kGridSlotBits = 29;
 constexpr uint32_t kGridSlotMask = (1u << kGridSlotBits) - 1u;
 __host__ __device__ constexpr int hit_slot_bits(int spp) {
-    return spp <= 1 ? 31 : spp <= 2 ? 31 : spp <= 4 ? 30 : spp <= 8 ? 29 : spp <= 16 ? 28 : 27;
+    return spp <= 1 ? 31 : spp <= 2 ? 30 : spp <= 4 ? 29 : spp <= 8 ? 28 : spp <= 16 ? 27 : 26;
 }
 __host__ __device__ inline bool nodew_is_leaf(uint32_t w) { return (w >> 30) == 2u; }
 
@@ -96,9 +99,9 @@ struct FrameDesc {
     uint64_t rng_state, rng_inc;
     float* aux;
     float* image;
-    uint32_t* hits;  // SPP * H*W packed hit entries, kNoHit-terminated per pixel (traversal -> shading; layout: hit_index)
+    uint32_t* hits;  // SPP * H*W words: thresholds, then packed hit entries (kHitValid) (traversal -> shading; layout: hit_index)
 };
-constexpr uint32_t kNoHit = 0xffffffffu;
+constexpr uint32_t kHitValid = 0x80000000u;
 constexpr int kMaxQueues = 8;  // XCDs of an MI355X
 // ctx queue memory (u64 words): [2..7] debug counters, [8 + 8k] next ray of queue k
 constexpr int kQueueWords = 8 + 8 * kMaxQueues;

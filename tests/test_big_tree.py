@@ -1,5 +1,5 @@
 """A tree with more than 2^27 leaf slots (a full octree of depth 9: 19.2 M nodes, 153 M slots): round 1 refused the
-fast / batched kernels above 2^27 slots; hit-list entries now carry 32 - ceil(log2 SPP) slot bits (29 at SPP <= 8) and
+fast / batched kernels above 2^27 slots; hit-list entries now carry 31 - ceil(log2 SPP) slot bits (28 at SPP <= 8) and
 top-grid entries 29, and a launch whose SPP leaves too few bits (SPP 32 here) falls back to the generic kernel."""
 import numpy as np
 import pytest
@@ -36,7 +36,7 @@ def test_tree_beyond_2_pow_27_slots():
     ht = orc.HostTree(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
     W, H = 40, 32
     ocam, cam = cameras(W, H, synth.orbit_poses(5)[2])
-    for spp in (6, 32):  # 6: fast and batched kernels (29 slot bits); 32: 27 bits are too few -> generic kernel
+    for spp in (6, 32):  # 6: fast and batched kernels (28 slot bits); 32: 26 bits are too few -> generic kernel
         want, rgba_o, st = orc.render_frame(ht, ocam, orc.default_options(spp=spp), orc.rng(frame=3))
         assert st["hit_rays"] > 100
         ctx = R.RenderContext(W, H, frames=2)

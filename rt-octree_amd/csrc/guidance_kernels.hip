@@ -15,8 +15,9 @@
 //            padded to 96; + bias, ReLU6, fp16, HWC in LDS (zero outside the image = the second
 //            convolution's "same" padding)
 //   stage C  layer 2 the same way: K = 9 taps x 32 channels = 9 MFMAs per 16 pixels, output
-//            channels padded 8 -> 16; + bias, ReLU6, fp16 rounding (the reference keeps fp16
-//            activations), then softmax over the L weight channels in fp32 and the stores
+//            channels padded 8 -> 16, each activation-row fragment shared by the three output rows
+//            it serves; + bias, ReLU6, fp16 rounding (the reference keeps fp16 activations), then
+//            softmax over the L weight channels in fp32 and the stores
 //
 // Accumulation is fp32 inside the MFMA like cuDNN/MIOpen fp16 convolutions; rounding points
 // (fp16 input, fp16 activations after each ReLU6) are the reference's.  Results agree with the fp32
@@ -24,6 +25,8 @@
 // cuDNN results are not pinned by the reference either.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+
+#include <type_traits>
 
 #include "rto_launch.h"
 
@@ -37,7 +40,7 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 
 constexpr int kGW = 32, kGH = 8;  // output tile
 #ifndef RTO_NET_STRIP
-#define RTO_NET_STRIP 1
+#define RTO_NET_STRIP 5
 #endif
 constexpr int kStrip = RTO_NET_STRIP;  // tiles per workgroup, along x
 constexpr int kCIn = 8;           // aux channels (render_context.hpp:23)
@@ -53,9 +56,8 @@ __device__ __forceinline__ float relu6(float x) { return fminf(fmaxf(x, 0.f), 6.
 // instead of 32, nothing lost: the reference's `.float()` (network.py:112) only widens those fp16 values, and the
 // consumer (filter_fast<L, true>) applies softmax_weights() below to the logits itself.
 template <int C1, int L, bool SQ, bool PACK>
-__global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ aux,    // [n][8][H][W]
-                                                       const _Float16* __restrict__ w1,  // [C1][96]   k = tap*8 + ci
-                                                       const float* __restrict__ b1,     // [C1]
+__global__ void __launch_bounds__(256, 4) guidance_fused(const float* __restrict__ aux,    // [n][8][H][W]
+                                                       const _Float16* __restrict__ w1,  // [C1][96]   k = tap*8 + ci; k = 72: bias
                                                        const _Float16* __restrict__ w2,  // [16][9*C1] k = tap*C1 + ci
                                                        const float* __restrict__ b2,     // [16]
                                                        float* __restrict__ weight_out,   // [n][L][H][W]
@@ -69,17 +71,24 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
     // 64-byte stride the 16 pixels a ds_read_b128 gathers start on only two distinct bank groups
     // (8-way conflict); at 80 B every bank is touched exactly twice, the minimum for 256 B
 #ifndef RTO_NET_PAD
-#define RTO_NET_PAD 0
+#define RTO_NET_PAD 8
 #endif
     constexpr int AS = C1 + RTO_NET_PAD;
     __shared__ __attribute__((aligned(16))) _Float16 s_in[IH * IW * kCIn];
     __shared__ __attribute__((aligned(16))) _Float16 s_act[AH * AW * AS];
+    __shared__ __attribute__((aligned(16))) _Float16 s_pad[16];  // B fragments of the padding taps: {1,0,..,0} (bias slot), {0,..,0}
+    __shared__ __attribute__((aligned(16))) float s_b2[16];      // layer-2 bias
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // A workgroup can walk a strip of kStrip tiles along x with the input of tile t + 1 on its way into registers
-    // while layers 1 and 2 of tile t run.  Measured (16 frames of 800x800): strip 1 0.356 ms, 3 0.376-0.44, 5 0.39-0.44,
-    // 25 0.47 -- with 4 workgroups per CU the other workgroups already cover a tile's load phase, and longer strips
-    // only leave fewer workgroups to balance; the default stays 1.
+    if (tid < 16) {  // (published by the barrier after stage A)
+        s_pad[tid] = (_Float16)(tid == 0 ? 1.f : 0.f);
+        s_b2[tid] = b2[tid];
+    }
+    // A workgroup walks a strip of kStrip tiles along x with the input of tile t + 1 on its way into registers while
+    // layers 1 and 2 of tile t run (a tile's input fetch is 37 % of its time when nothing hides it).  Measured per 50
+    // frames of 800x800 once the stages had been slimmed down to fit the prefetch registers without spills: strip 1
+    // 0.70 ms, 2 0.64, 5 0.60, 7..25 0.59-0.62.  (While stage B still spent ~75 VALU instructions per group the kernel
+    // was issue-bound and strips gained nothing.)
     const int tiles_x = (W + kGW - 1) / kGW;
     const int tx_first = blockIdx.x * kStrip;
     const int y0 = blockIdx.y * kGH;
@@ -102,15 +111,9 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
     for (int ks = 0; ks < KS2; ++ks)
         wb[ks] = *reinterpret_cast<const half8*>(w2 + (size_t)col * (9 * C1) + ks * 32 + kg * 8);
 
-    // biases once per workgroup, before the strip loop: a global load inside stages B / C would make their
-    // s_waitcnt drain the prefetch of the next tile as well (vmcnt retires in issue order)
-    float bias1[NT1][4], bias2[4];
-#pragma unroll
-    for (int t = 0; t < NT1; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bias1[t][i] = b1[t * 16 + kg * 4 + i];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bias2[i] = b2[kg * 4 + i];
+    // Biases cost no registers: layer 1's rides in the weights (k-slot 72, the first padding tap, whose B element is
+    // the constant 1 of s_pad; the packer rounds it to fp16 like the reference's `.half()` does), layer 2's is read from
+    // LDS once per tile.
 
     // ---- stage A: input tile, planar fp32 -> HWC fp16.  One thread = one tile pixel: its channel loads are
     // independent (all in flight at once) and become one 16-byte LDS store.
@@ -124,10 +127,10 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
             const int ty = e / IW, tx = e - ty * IW;
             const int gx = x0 - 2 + tx, gy = y0 - 2 + ty;
             const bool in = e < NPIX && gx >= 0 && gx < W && gy >= 0 && gy < H;
-            const int64_t gi = in ? (int64_t)gy * W + gx : 0;
+            const int gi = in ? gy * W + gx : 0;  // (8 * H * W < 2^31: rto_ctx_create's size check)
 #pragma unroll
             for (int c = 0; c < NLD; ++c) {
-                const float t = aux[c * HW + gi];
+                const float t = aux[c * (int)HW + gi];
                 v[it][c] = in ? t : 0.f;
             }
         }
@@ -138,6 +141,7 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
 #endif
     fetch(tx_first * kGW);
 
+#pragma nounroll
     for (int ts = 0; ts < kStrip; ++ts) {
     const int tile_x = tx_first + ts;
     if (tile_x >= tiles_x) break;  // workgroup-uniform
@@ -168,62 +172,79 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
 
 
     // ---- stage B: layer 1 on the AH x AW region
+    // The kernel is VALU-bound (stamps: stage B 38 % of a tile's time at ~75 VALU instructions per 16-pixel group
+    // around 6 MFMAs), so the loop carries its indices instead of recomputing them: group g + 4 of a wave is 64
+    // pixels = one row + 30 columns further on; a tap's LDS address is the group's base plus a per-lane constant; the
+    // three padding taps of the last k-step read a zeroed 16-byte slot; tiles whose activation region lies inside the
+    // image (all but the border ring) skip the zero-padding mask altogether.
     {
-        const float(&bias)[NT1][4] = bias1;
         constexpr int NG1 = (AH * AW + 15) / 16;
+        static_assert(AW > 30 && AW <= 64, "the row / column carry below assumes one wrap per 64 pixels");
 #ifndef RTO_NET_DBG_BREP
 #define RTO_NET_DBG_BREP 1
 #endif
-        for (int rep = 0; rep < RTO_NET_DBG_BREP; ++rep)
-        for (int g = wave; g < NG1; g += 4) {
-            if (RTO_NET_DBG_BREP > 1) asm volatile("" ::: "memory");
-            // (the index arithmetic of this loop is what the kernel's VALU time went into: 24-bit multiplies and
-            // a reciprocal multiply instead of 32-bit mul_lo / mul_hi -- all operands are far below 2^24)
-            const int p = g * 16 + col;
-            const bool valid = p < AH * AW;
-            static_assert(AH * AW < 2048, "reciprocal division below assumes a small tile");
-            const int q = (int)(__umul24((unsigned)p, (65536u + AW - 1) / AW) >> 16);  // p / AW for p < 2048
-            const int ry = valid ? q : 0, rx = valid ? p - (int)__umul24((unsigned)q, AW) : 0;
-            // the accumulators start from the bias (lane element i of tile t is output channel t*16 + kg*4 + i): one
-            // operand of the first MFMA instead of eight additions per group
-            float4v acc[NT1];
+        uint32_t tapoff[2];  // byte offset of this lane's tap in k-steps 0 and 1, relative to the group's base pixel
 #pragma unroll
-            for (int t = 0; t < NT1; ++t) acc[t] = (float4v){bias[t][0], bias[t][1], bias[t][2], bias[t][3]};
-            half8 bf1[3];
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {
-                const int tap = ks * 4 + kg;
-                bf1[ks] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
-                if (tap < 9) {
-                    const int ky = tap / 3, kx = tap - ky * 3;
-                    bf1[ks] = *reinterpret_cast<const half8*>(s_in + (__umul24((unsigned)(ry + ky), IW) + rx + kx) * kCIn);
-                }
-            }
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks)
-#pragma unroll
-                for (int t = 0; t < NT1; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][ks], bf1[ks], acc[t], 0, 0, 0);
-            if (valid) {
-                // outside the image the activation is the second convolution's zero padding.  Most tiles lie inside with
-                // their halo (workgroup-uniform test): no mask at all there; border tiles scale by 0 or 1 (relu6(...) is
-                // finite and >= 0, so x * 1 = x and x * 0 = +0 exactly)
-                float inside = 1.f;
-                if (!tile_interior) {
-                    const int gx = x0 - 1 + rx, gy = y0 - 1 + ry;
-                    inside = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? 1.f : 0.f;
-                }
-#pragma unroll
-                for (int t = 0; t < NT1; ++t) {
-                    half4 o;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float r = __builtin_amdgcn_fmed3f(acc[t][i], 0.f, 6.f);  // ReLU6
-                        o[i] = (_Float16)(tile_interior ? r : r * inside);
-                    }
-                    *reinterpret_cast<half4*>(s_act + __umul24((unsigned)p, AS) + t * 16 + kg * 4) = o;
-                }
-            }
+        for (int ks = 0; ks < 2; ++ks) {
+            const int tap = ks * 4 + kg, ky = tap / 3, kx = tap - ky * 3;
+            tapoff[ks] = (uint32_t)((ky * IW + kx) * kCIn * 2);
         }
+        constexpr uint32_t kTap8Off = (uint32_t)((2 * IW + 2) * kCIn * 2);
+        const bool tap2_real = kg == 0;  // k-step 2 holds tap 8, the bias slot (kg 1) and two padding taps
+        const char* tap2_pad = reinterpret_cast<const char*>(s_pad) + (kg == 1 ? 0 : 16);
+        auto layer1 = [&](auto interior_tag) {
+            constexpr bool INTERIOR = decltype(interior_tag)::value;
+            for (int rep = 0; rep < RTO_NET_DBG_BREP; ++rep) {
+                if (RTO_NET_DBG_BREP > 1) asm volatile("" ::: "memory");
+                int p = wave * 16 + col;
+                int ry = p >= AW ? 1 : 0, rx = p - ry * AW;
+                for (int g = wave; g < NG1; g += 4) {
+                    const uint32_t base = (uint32_t)((ry * IW + rx) * kCIn * 2);  // bytes into s_in
+                    const char* sin_b = reinterpret_cast<const char*>(s_in);
+                    half8 bf1[3];
+                    bf1[0] = *reinterpret_cast<const half8*>(sin_b + base + tapoff[0]);
+                    bf1[1] = *reinterpret_cast<const half8*>(sin_b + base + tapoff[1]);
+                    bf1[2] = *reinterpret_cast<const half8*>(tap2_real ? sin_b + base + kTap8Off : tap2_pad);
+                    float4v acc[NT1];
+#pragma unroll
+                    for (int t = 0; t < NT1; ++t) acc[t] = (float4v){0.f, 0.f, 0.f, 0.f};  // (the bias is one of the products)
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+                        for (int t = 0; t < NT1; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t][ks], bf1[ks], acc[t], 0, 0, 0);
+                    if (p < AH * AW) {  // (a lane beyond the region computed on whatever its addresses held: unused)
+                        // outside the image the activation is the second convolution's zero padding: border tiles scale by
+                        // 0 or 1 (relu6(...) is finite and >= 0, so x * 1 = x and x * 0 = +0 exactly)
+                        float inside = 1.f;
+                        if (!INTERIOR) {
+                            const int gx = x0 - 1 + rx, gy = y0 - 1 + ry;
+                            inside = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? 1.f : 0.f;
+                        }
+#pragma unroll
+                        for (int t = 0; t < NT1; ++t) {
+                            half4 o;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float r = __builtin_amdgcn_fmed3f(acc[t][i], 0.f, 6.f);  // ReLU6
+                                o[i] = (_Float16)(INTERIOR ? r : r * inside);
+                            }
+                            *reinterpret_cast<half4*>(s_act + __umul24((unsigned)p, AS) + t * 16 + kg * 4) = o;
+                        }
+                    }
+                    p += 64;
+                    rx += 64 - AW;
+                    ry += 1;
+                    if (rx >= AW) {
+                        rx -= AW;
+                        ry += 1;
+                    }
+                }
+            }
+        };
+        if (tile_interior)  // workgroup-uniform
+            layer1(std::true_type{});
+        else
+            layer1(std::false_type{});
     }
 #ifdef RTO_NET_DBG_STAMP
     if (ts == 0) st[3] = __builtin_amdgcn_s_memtime();
@@ -233,9 +254,10 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
     if (ts == 0) st[4] = __builtin_amdgcn_s_memtime();
 #endif
 
+#ifdef RTO_NET_OLD_C
     // ---- stage C: layer 2 on the kGH x kGW tile, softmax, stores
     {
-        const float(&bias)[4] = bias2;
+        const float4v bias = *reinterpret_cast<const float4v*>(s_b2 + kg * 4);
         constexpr int NG2 = kGH * kGW / 16;
 #ifndef RTO_NET_DBG_CREP
 #define RTO_NET_DBG_CREP 1
@@ -245,7 +267,7 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
             if (RTO_NET_DBG_CREP > 1) asm volatile("" ::: "memory");
             const int p = g * 16 + col;
             const int oy = p / kGW, ox = p - oy * kGW;
-            float4v acc = (float4v){bias[0], bias[1], bias[2], bias[3]};  // the bias: the first MFMA's C operand
+            float4v acc = bias;  // the bias: the first MFMA's C operand
             // all of the group's B fragments first, each into registers of its own, then the MFMA chain: with one
             // fragment register set the compiler serialises read -> wait -> MFMA nine times and the group costs nine
             // LDS latencies (measured: 1.5 k clocks per group at 4 waves per SIMD)
@@ -285,6 +307,76 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
             }
         }
     }
+#else
+    // ---- stage C: layer 2 on the kGH x kGW tile, softmax, stores
+    // A wave owns 16 columns x 4 rows of the tile and walks the 6 activation rows under them: each row's three
+    // B fragments (kx = 0..2; one ds_read_b128 per lane each) feed the MFMAs of up to three output rows (ky = row -
+    // output row), so a group costs 4.5 fragment reads instead of 9 -- the stage was bound by LDS reads (144 KB per
+    // tile against 576 clocks of MFMA).  Every accumulator still receives its taps in the order 0..8.
+    {
+        static_assert(kGW == 32 && kGH == 8, "stage C assigns (column block, row half) = wave");
+        const float4v bias = *reinterpret_cast<const float4v*>(s_b2 + kg * 4);
+#ifndef RTO_NET_DBG_CREP
+#define RTO_NET_DBG_CREP 1
+#endif
+        for (int rep = 0; rep < RTO_NET_DBG_CREP; ++rep) {
+            if (RTO_NET_DBG_CREP > 1) asm volatile("" ::: "memory");
+            const int ox = (wave & 1) * 16 + col, oy0 = (wave >> 1) * 4;
+            float4v acc[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = bias;  // the bias: the first MFMA's C operand
+            const _Float16* arow = s_act + __umul24(__umul24((unsigned)oy0, AW) + ox, AS) + kg * 8;
+            half8 cur[3], nxt[3];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) cur[kx] = *reinterpret_cast<const half8*>(arow + kx * AS);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                if (a < 5) {  // the next activation row is on its way while this one is multiplied
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) nxt[kx] = *reinterpret_cast<const half8*>(arow + ((a + 1) * AW + kx) * AS);
+                }
+                // (kx outside, output row inside: consecutive MFMAs write different accumulators, and each accumulator
+                //  still sees ky = 0..2, kx = 0..2 in order)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ky = a - r;
+                        if (ky >= 0 && ky < 3)
+                            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ky * 3 + kx], cur[kx], acc[r], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) cur[kx] = nxt[kx];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gx = x0 + ox, gy = y0 + oy0 + r;
+                if (gx < W && gy < H && kg * 4 < 2 * L) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = (float)(_Float16)__builtin_amdgcn_fmed3f(acc[r][i], 0.f, 6.f);  // ReLU6 -> fp16 activations, then .float()
+                    const int64_t pix = (int64_t)gy * W + gx;
+                    if (PACK) {  // (weight_out = the packed buffer of image blockIdx.z; kg 0: logits, kg 1: guidance)
+                        half4 h;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) h[i] = (_Float16)v[i];
+                        *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(weight_out) + pix * 8 + kg * 4) = h;
+                    } else if (L == 4) {
+                        if (kg == 0) {  // channels 0..3: softmax -> weight_map (network.py:113-114)
+                            float wgt[4];
+                            softmax_weights4(v, wgt);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) weight_out[i * HW + pix] = wgt[i];
+                        } else {  // channels 4..7: guidance_map (:116)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) guidance_out[i * HW + pix] = v[i];
+                        }
+                    }
+                }
+            }
+        }
+    }
+#endif
 #ifdef RTO_NET_DBG_STAMP
     if (ts == 0) {
         st[5] = __builtin_amdgcn_s_memtime();
@@ -298,7 +390,7 @@ __global__ void __launch_bounds__(256) guidance_fused(const float* __restrict__ 
 
 }  // namespace
 
-hipError_t launch_guidance_net(const float* aux, const void* w1, const float* b1, const void* w2, const float* b2, int c1,
+hipError_t launch_guidance_net(const float* aux, const void* w1, const void* w2, const float* b2, int c1,
                                int levels, int n, int H, int W, float* weight_out, float* guidance_out,
                                bool squares_implied, hipStream_t stream) {
     if (c1 != 32 || levels != 4) return hipErrorInvalidValue;  // the reference configuration (blender.txt:21-25)
@@ -306,7 +398,7 @@ hipError_t launch_guidance_net(const float* aux, const void* w1, const float* b1
     const dim3 grid((tiles_x + kStrip - 1) / kStrip, (H + kGH - 1) / kGH, n), block(256);
     const bool pack = guidance_out == nullptr;  // weight_out is then the packed fp16 buffer [n][H][W][8]
 #define RTO_NET(SQ, PK)                                                                                                   \
-    hipLaunchKernelGGL((guidance_fused<32, 4, SQ, PK>), grid, block, 0, stream, aux, (const _Float16*)w1, b1, (const _Float16*)w2, \
+    hipLaunchKernelGGL((guidance_fused<32, 4, SQ, PK>), grid, block, 0, stream, aux, (const _Float16*)w1, (const _Float16*)w2,     \
                        b2, weight_out, guidance_out, H, W)
     if (pack) {
         if (squares_implied) RTO_NET(true, true); else RTO_NET(false, true);

@@ -13,7 +13,6 @@ struct rto_guidance_net {
     int device = 0, c1 = 0, levels = 0;
     void* w1 = nullptr;   // fp16 [c1][96]
     void* w2 = nullptr;   // fp16 [16][9*c1]
-    float* b1 = nullptr;  // [c1]
     float* b2 = nullptr;  // [16]
     void* packed = nullptr;      // scratch of the packed route: fp16 [n][H][W][8]
     size_t packed_bytes = 0;
@@ -54,12 +53,15 @@ int rto_guidance_net_create(const float* w1, const float* b1, const float* w2, c
     for (int co = 0; co < c1; ++co)
         for (int ci = 0; ci < 8; ++ci)
             for (int t = 0; t < 9; ++t) p1[(size_t)co * 96 + t * 8 + ci] = (_Float16)w1[((size_t)co * 8 + ci) * 9 + t];
+    // the reference runs the module after `.half()` (network.py:194-201): its biases are fp16 values too.  Layer 1's
+    // occupies the first padding slot of its weight row (k = 72; the kernel multiplies it by a constant 1).
+    for (int co = 0; co < c1; ++co) p1[(size_t)co * 96 + 72] = (_Float16)b1[co];
     for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < c1; ++ci)
             for (int t = 0; t < 9; ++t)
                 p2[(size_t)co * 9 * c1 + (size_t)t * c1 + ci] = (_Float16)w2[((size_t)co * c1 + ci) * 9 + t];
     std::vector<float> pb2(16, 0.f);
-    for (int co = 0; co < cout; ++co) pb2[co] = b2[co];
+    for (int co = 0; co < cout; ++co) pb2[co] = (float)(_Float16)b2[co];
 
     int prev = 0;
     (void)hipGetDevice(&prev);
@@ -69,11 +71,9 @@ int rto_guidance_net_create(const float* w1, const float* b1, const float* w2, c
     n->c1 = c1;
     n->levels = levels;
     bool ok = hipMalloc(&n->w1, p1.size() * 2) == hipSuccess && hipMalloc(&n->w2, p2.size() * 2) == hipSuccess &&
-              hipMalloc((void**)&n->b1, c1 * sizeof(float)) == hipSuccess &&
               hipMalloc((void**)&n->b2, 16 * sizeof(float)) == hipSuccess;
     ok = ok && hipMemcpy(n->w1, p1.data(), p1.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(n->w2, p2.data(), p2.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(n->b1, b1, c1 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(n->b2, pb2.data(), 16 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
     (void)hipSetDevice(prev);
     if (!ok) {
@@ -94,7 +94,7 @@ int rto_guidance_net_forward_ex(const rto_guidance_net* net, void* stream, const
     if (!net || !aux || !weight_map || !guidance_map || n < 1 || H < 1 || W < 1)
         return fail(RTO_E_INVALID, "rto_guidance_net_forward: bad argument");
     DeviceScope scope(net->device);
-    const hipError_t e = rto::launch_guidance_net(aux, net->w1, net->b1, net->w2, net->b2, net->c1, net->levels, n, H, W,
+    const hipError_t e = rto::launch_guidance_net(aux, net->w1, net->w2, net->b2, net->c1, net->levels, n, H, W,
                                                   weight_map, guidance_map, (flags & RTO_NET_AUX_SQUARES_IMPLIED) != 0,
                                                   (hipStream_t)stream);
     if (e != hipSuccess) return fail(RTO_E_HIP, std::string("GuidanceNet launch failed: ") + hipGetErrorString(e));
@@ -114,7 +114,7 @@ int rto_guidance_net_forward_packed(rto_guidance_net* net, void* stream, const f
         if (hipMalloc(&net->packed, need) != hipSuccess) return fail(RTO_E_HIP, "hipMalloc(packed maps) failed");
         net->packed_bytes = need;
     }
-    const hipError_t e = rto::launch_guidance_net(aux, net->w1, net->b1, net->w2, net->b2, net->c1, net->levels, n, H, W,
+    const hipError_t e = rto::launch_guidance_net(aux, net->w1, net->w2, net->b2, net->c1, net->levels, n, H, W,
                                                   (float*)net->packed, nullptr, (flags & RTO_NET_AUX_SQUARES_IMPLIED) != 0,
                                                   (hipStream_t)stream);
     if (e != hipSuccess) return fail(RTO_E_HIP, std::string("GuidanceNet launch failed: ") + hipGetErrorString(e));
@@ -140,7 +140,6 @@ void rto_guidance_net_free(rto_guidance_net* net) {
     if (net->packed) (void)hipFree(net->packed);
     if (net->w1) (void)hipFree(net->w1);
     if (net->w2) (void)hipFree(net->w2);
-    if (net->b1) (void)hipFree(net->b1);
     if (net->b2) (void)hipFree(net->b2);
     delete net;
 }

@@ -71,7 +71,7 @@ hipError_t launch_filter_backward(const float* grad_out, const float* img_in, co
 
 // fused compact GuidanceNet (guidance_kernels.hip): w1 fp16 [c1][96], w2 fp16 [16][9*c1], b2 [16];
 // guidance_out == nullptr: weight_out receives the packed fp16 maps [n][H][W][8] instead
-hipError_t launch_guidance_net(const float* aux, const void* w1, const float* b1, const void* w2, const float* b2, int c1,
+hipError_t launch_guidance_net(const float* aux, const void* w1, const void* w2, const float* b2, int c1,
                                int levels, int n, int H, int W, float* weight_out, float* guidance_out,
                                bool squares_implied, hipStream_t stream);
 

@@ -303,6 +303,11 @@ int rto_probe_gather(uint64_t n_lines, int repeats);
 int rto_probe_gather_sweep(uint64_t table_bytes, int lines_per_gather, int blocked, int dependent, int wps,
                            int iters, int repeats, double out[4]);
 int rto_probe_valu(int kind, int wps, int iters, double out[4]);
+/* Test hook: host_out[i] = the threshold the renderer draws from the RNG float k / 2^23, k = first_k + i
+ * (rt_core.cuh:67-88 `-logf(1 - rng.next_float())` in the library's deterministic arithmetic), computed on the
+ * device by the very function the kernels call.  first_k + count <= 2^23: the whole domain can be compared with
+ * the oracle value by value. */
+int rto_probe_thresholds(uint32_t first_k, uint32_t count, float* host_out);
 
 #ifdef __cplusplus
 }

@@ -219,6 +219,17 @@ static inline void v_normalize(float* d) {
     d[0] *= invnorm; d[1] *= invnorm; d[2] *= invnorm;
 }
 
+/* rt_core.cuh:67-88: the value one threshold draw takes, t = -logf(1 - u), for the RNG float u = k / 2^23
+ * (pcg32.h:103-112 next_float = ((next_uint >> 9) | 0x3f800000) - 1).  out[i] for k = first_k + i: lets a test
+ * compare EVERY possible draw with the device function. */
+void orc_thresholds(uint32_t first_k, uint32_t count, float* out) {
+    for (uint32_t i = 0; i < count; ++i) {
+        union { uint32_t u; float f; } v;
+        v.u = ((first_k + i) & 0x7fffffu) | 0x3f800000u;
+        out[i] = -m_logf(1.0f - (v.f - 1.0f));
+    }
+}
+
 /* ------------------------------------------------------------------ sample_dst */
 /* rt_core.cuh:67-193.  The 1..4 specialisations (:90-185) produce the same sorted array as the
  * generic insertion (:67-88); ties are indistinguishable in the result. */

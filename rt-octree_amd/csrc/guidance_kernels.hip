@@ -254,60 +254,6 @@ __global__ void __launch_bounds__(256, 4) guidance_fused(const float* __restrict
     if (ts == 0) st[4] = __builtin_amdgcn_s_memtime();
 #endif
 
-#ifdef RTO_NET_OLD_C
-    // ---- stage C: layer 2 on the kGH x kGW tile, softmax, stores
-    {
-        const float4v bias = *reinterpret_cast<const float4v*>(s_b2 + kg * 4);
-        constexpr int NG2 = kGH * kGW / 16;
-#ifndef RTO_NET_DBG_CREP
-#define RTO_NET_DBG_CREP 1
-#endif
-        for (int rep = 0; rep < RTO_NET_DBG_CREP; ++rep)
-        for (int g = wave; g < NG2; g += 4) {
-            if (RTO_NET_DBG_CREP > 1) asm volatile("" ::: "memory");
-            const int p = g * 16 + col;
-            const int oy = p / kGW, ox = p - oy * kGW;
-            float4v acc = bias;  // the bias: the first MFMA's C operand
-            // all of the group's B fragments first, each into registers of its own, then the MFMA chain: with one
-            // fragment register set the compiler serialises read -> wait -> MFMA nine times and the group costs nine
-            // LDS latencies (measured: 1.5 k clocks per group at 4 waves per SIMD)
-            half8 bf[KS2];
-#pragma unroll
-            for (int ks = 0; ks < KS2; ++ks) {
-                const int k0 = ks * 32 + kg * 8;  // k = tap*C1 + ci
-                const int tap = k0 / C1, ci = k0 - tap * C1;
-                const int ky = tap / 3, kx = tap - ky * 3;
-                bf[ks] = *reinterpret_cast<const half8*>(s_act + __umul24(__umul24((unsigned)(oy + ky), AW) + ox + kx, AS) + ci);
-            }
-            __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks the reads back between the MFMAs)
-#pragma unroll
-            for (int ks = 0; ks < KS2; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ks], bf[ks], acc, 0, 0, 0);
-            const int gx = x0 + ox, gy = y0 + oy;
-            if (gx < W && gy < H && kg * 4 < 2 * L) {
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = (float)(_Float16)__builtin_amdgcn_fmed3f(acc[i], 0.f, 6.f);  // ReLU6 -> fp16 activations, then .float()
-                const int64_t pix = (int64_t)gy * W + gx;
-                if (PACK) {  // (weight_out = the packed buffer of image blockIdx.z; kg 0: logits, kg 1: guidance)
-                    half4 h;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) h[i] = (_Float16)v[i];
-                    *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(weight_out) + pix * 8 + kg * 4) = h;
-                } else if (L == 4) {
-                    if (kg == 0) {  // channels 0..3: softmax -> weight_map (network.py:113-114)
-                        float wgt[4];
-                        softmax_weights4(v, wgt);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) weight_out[i * HW + pix] = wgt[i];
-                    } else {  // channels 4..7: guidance_map (:116)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) guidance_out[i * HW + pix] = v[i];
-                    }
-                }
-            }
-        }
-    }
-#else
     // ---- stage C: layer 2 on the kGH x kGW tile, softmax, stores
     // A wave owns 16 columns x 4 rows of the tile and walks the 6 activation rows under them: each row's three
     // B fragments (kx = 0..2; one ds_read_b128 per lane each) feed the MFMAs of up to three output rows (ky = row -
@@ -318,7 +264,6 @@ __global__ void __launch_bounds__(256, 4) guidance_fused(const float* __restrict
         const float4v bias = *reinterpret_cast<const float4v*>(s_b2 + kg * 4);
 #ifndef RTO_NET_DBG_CREP
 #define RTO_NET_DBG_CREP 1
-#endif
         for (int rep = 0; rep < RTO_NET_DBG_CREP; ++rep) {
             if (RTO_NET_DBG_CREP > 1) asm volatile("" ::: "memory");
             const int ox = (wave & 1) * 16 + col, oy0 = (wave >> 1) * 4;

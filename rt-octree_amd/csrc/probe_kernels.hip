@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 #include "rto.h"
+#include "rto_device_math.h"
 
 namespace {
 __global__ void gather_probe_kernel(const uint32_t* __restrict__ buf, uint64_t n_lines, uint64_t stride_lines,
@@ -204,6 +205,25 @@ extern "C" int rto_probe_gather_sweep(uint64_t table_bytes, int lines_per_gather
     (void)hipFree(table);
     (void)hipFree(sink);
     (void)hipFree(cyc);
+    return e == hipSuccess ? RTO_OK : RTO_E_HIP;
+}
+
+// -det_log_one_minus(k / 2^23) for k = first_k .. first_k + count - 1: every value a threshold draw can take
+// (rt_core.cuh:67-88: t = -logf(1 - rng.next_float())), for the exhaustive comparison with the oracle
+__global__ void __launch_bounds__(256) threshold_probe_kernel(uint32_t first_k, uint32_t count, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const float u01 = __uint_as_float(((first_k + i) & 0x7fffffu) | 0x3f800000u) - 1.0f;  // pcg_next_float's mapping
+    out[i] = -rto::det_log_one_minus(u01);
+}
+
+extern "C" int rto_probe_thresholds(uint32_t first_k, uint32_t count, float* host_out) {
+    if (!host_out || count == 0 || (uint64_t)first_k + count > (1ull << 23)) return RTO_E_INVALID;
+    float* d = nullptr;
+    if (hipMalloc((void**)&d, (size_t)count * 4) != hipSuccess) return RTO_E_HIP;
+    hipLaunchKernelGGL(threshold_probe_kernel, dim3((count + 255u) / 256u), dim3(256), 0, nullptr, first_k, count, d);
+    const hipError_t e = hipMemcpy(host_out, d, (size_t)count * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
     return e == hipSuccess ? RTO_OK : RTO_E_HIP;
 }
 

@@ -60,7 +60,10 @@ RTO_DEV void pcg_advance_tab(Pcg32& r, uint32_t delta, const PcgJumpEntry* __res
     uint64_t s = r.state;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
+        // (entry 0 of every digit is the identity: a digit that is zero in all lanes of the wave -- the top byte of
+        //  idx * SPP for any frame below 2^24 samples -- costs one ballot instead of a gather and a 64-bit multiply)
         const uint32_t j = (delta >> (8 * c)) & 255u;
+        if (c >= 2 && __ballot(j != 0u) == 0ULL) continue;
         const PcgJumpEntry e = tab[c * 256 + j];
         s = e.mult * s + e.plus;
     }
@@ -114,12 +117,40 @@ RTO_DEV float det_logf(float x) {
     return det_logf_core(e, man);
 }
 
-// det_logf(1 - u) for u = pcg_next_float() in [0, 1 - 2^-23]: the argument is a positive normal number in
-// [2^-23, 1], so none of det_logf's special cases (NaN, infinity, zero, negative, subnormal) can occur and the same
-// value comes out of the core alone -- the threshold draws (6 per pixel) skip those tests and the subnormal loop.
+// det_logf(1 - u) for u = pcg_next_float() = k / 2^23, k < 2^23: the argument is a positive normal number in
+// [2^-23, 1], so none of det_logf's special cases (NaN, infinity, zero, negative, subnormal) can occur.  The
+// threshold draws (SPP per pixel; sample_kernel is VALU-bound) evaluate the same reduction and series with the
+// quotient from v_rcp_f64 + two Newton steps + one residual correction instead of the IEEE division sequence (~25
+// instructions) and with fused multiply-adds in the polynomial: the intermediate doubles differ from det_logf_core's in
+// the last bit or two, the float they round to does not -- for ALL 2^23 possible draws, which
+// tests/test_render_parity.py::test_every_threshold_draw_matches_the_oracle checks one by one against
+// oracle/rto_oracle.c (rto_probe_thresholds).
 RTO_DEV float det_log_one_minus(float u01) {
     const uint32_t u = __float_as_uint(1.0f - u01);
-    return det_logf_core((int)(u >> 23) - 127, u & 0x7fffffu);
+    int e = (int)(u >> 23) - 127;
+    double md = (double)__uint_as_float((u & 0x7fffffu) | 0x3f800000u);
+    if (md > 1.4142135623730951) {
+        md = md * 0.5;
+        e += 1;
+    }
+    const double n = md - 1.0, d = md + 1.0;  // exact: md has 24 significant bits
+    double y = __builtin_amdgcn_rcp(d);
+    y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+    double s = n * y;
+    s = __builtin_fma(__builtin_fma(-d, s, n), y, s);
+    const double s2 = s * s;
+    double p = 1.0 / 15.0;
+    p = __builtin_fma(p, s2, 1.0 / 13.0);
+    p = __builtin_fma(p, s2, 1.0 / 11.0);
+    p = __builtin_fma(p, s2, 1.0 / 9.0);
+    p = __builtin_fma(p, s2, 1.0 / 7.0);
+    p = __builtin_fma(p, s2, 1.0 / 5.0);
+    p = __builtin_fma(p, s2, 1.0 / 3.0);
+    p = p * s2;
+    const double s_2 = 2.0 * s;
+    const double lm = __builtin_fma(s_2, p, s_2);
+    return (float)__builtin_fma((double)e, 0.6931471805599453, lm);
 }
 
 RTO_DEV float det_expf(float x) {

@@ -443,3 +443,23 @@ def test_handles_release_their_device_memory(small_tree_sh9):
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < (8 << 20), (free0, free1)
+
+
+@pytest.mark.gpu
+def test_every_threshold_draw_matches_the_oracle():
+    """sample_dst's draws (rt_core.cuh:67-88: t = -logf(1 - rng.next_float())) can take 2^23 values, one per RNG float
+    k / 2^23.  The device computes them with a shorter instruction sequence than the oracle's det_logf (reciprocal +
+    Newton instead of the IEEE division, fused multiply-adds): every one of the 2^23 results must still be the
+    oracle's float, bit for bit."""
+    import ctypes as C
+
+    from rt_octree_amd._lib import check, lib
+    n = 1 << 23
+    got = np.empty(n, np.float32)
+    check(lib().rto_probe_thresholds(0, n, got.ctypes.data_as(C.c_void_p)))
+    want = np.empty(n, np.float32)
+    orc.lib().orc_thresholds(0, n, want.ctypes.data_as(C.c_void_p))
+    bad = np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))
+    assert bad.size == 0, "first mismatching draws k = %s" % bad[:8]
+    assert got[0] == 0.0 and np.all(got[1:] > 0) and np.all(np.isfinite(got))
+    assert np.all(np.diff(got.astype(np.float64)) >= 0)  # -log(1 - u) is monotone in u

@@ -1151,8 +1151,11 @@ RTO_DEV void leaf_contrib(const TreeDev& tree, uint32_t slot, const float* basis
     }
 }
 
+#ifndef RTO_SHADE_WPS
+#define RTO_SHADE_WPS 4
+#endif
 template <int SPP, int P, int MODE>
-__global__ void __launch_bounds__(256) shade_kernel(const TreeDev tree, const OptDev opt, const FrameBatch fb) {
+__global__ void __launch_bounds__(256, RTO_SHADE_WPS) shade_kernel(const TreeDev tree, const OptDev opt, const FrameBatch fb) {
     __shared__ uint32_t s_h[4][kShadeCap];       // packed hit entry
     __shared__ uint16_t s_q[4][kShadeCap];       // its pixel, relative to the wave's first pixel
     __shared__ float s_c[4][3 * kShadeCap];      // its contribution, [channel][entry]

@@ -19,7 +19,7 @@ def _nets(seed=0):
     return compact, denoiser.FusedGuidanceNet(compact)
 
 
-@pytest.mark.parametrize("shape", [(1, 64, 96), (2, 37, 53), (1, 8, 32), (3, 5, 7)])
+@pytest.mark.parametrize("shape", [(1, 64, 96), (2, 37, 53), (1, 8, 32), (3, 5, 7), (1, 20, 333), (2, 9, 161)])  # 333: strips of 5 + 5 + 1 tiles
 def test_fused_matches_fp32_network(shape):
     n, H, W = shape
     compact, fused = _nets()
@@ -76,7 +76,7 @@ def test_denoised_image_psnr():
     assert -10 * np.log10(mse) > 50.0
 
 
-@pytest.mark.parametrize("shape", [(2, 37, 53), (1, 64, 96)])
+@pytest.mark.parametrize("shape", [(2, 37, 53), (1, 64, 96), (1, 17, 350)])
 def test_squares_implied_reads_half_the_input_bit_identically(shape):
     """RTO_NET_AUX_SQUARES_IMPLIED: the renderer's aux planes 4..7 are the fp32 squares of planes 0..3; the kernel
     may square them itself instead of reading them -- same fp32 products, same fp16 inputs, same maps."""
@@ -94,7 +94,7 @@ def test_squares_implied_reads_half_the_input_bit_identically(shape):
     assert torch.equal(w0, w1) and torch.equal(g0, g1)
 
 
-@pytest.mark.parametrize("shape", [(2, 37, 53), (1, 64, 96), (3, 100, 41)])
+@pytest.mark.parametrize("shape", [(2, 37, 53), (1, 64, 96), (3, 100, 41), (1, 40, 330)])
 def test_packed_denoise_route_equals_the_fp32_maps_route(shape):
     """rto_guidance_net_forward_packed + rto_filtering_packed (fp16 logits + guidance, 16 B per pixel, softmax taken
     by the filter) == rto_guidance_net_forward + the factorised filter on fp32 maps, bit for bit."""

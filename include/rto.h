@@ -308,6 +308,11 @@ int rto_probe_valu(int kind, int wps, int iters, double out[4]);
  * device by the very function the kernels call.  first_k + count <= 2^23: the whole domain can be compared with
  * the oracle value by value. */
 int rto_probe_thresholds(uint32_t first_k, uint32_t count, float* host_out);
+/* Test hook: host_out[i] = f(x_i) computed on the device, x_i = the float with bit pattern first_bits + i * stride
+ * (wrapping), f = the library's deterministic logf (fn 0: thresholds), expf (fn 1: the SH colour's sigmoid) or the
+ * filter's fp32 exp (fn 2) -- the functions DESIGN.md "Math" defines in place of `__logf` / `__expf`
+ * (rt_core.cuh:74,95,314; filtering.cu:191).  Lets a test sweep the whole float range against the oracle. */
+int rto_probe_math(int fn, uint32_t first_bits, uint32_t stride, uint32_t count, float* host_out);
 
 #ifdef __cplusplus
 }

@@ -219,6 +219,19 @@ static inline void v_normalize(float* d) {
     d[0] *= invnorm; d[1] *= invnorm; d[2] *= invnorm;
 }
 
+/* The deterministic math above on the floats with bit patterns first_bits + i * stride (wrapping): fn 0 = orc_det_logf,
+ * 1 = orc_det_expf, 2 = orc_fexp.  The other half of the device-vs-oracle sweep (rto_probe_math). */
+void orc_math_sweep(int fn, uint32_t first_bits, uint32_t stride, uint32_t count, float* out) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t i = 0; i < (int64_t)count; ++i) {
+        union { uint32_t u; float f; } v;
+        v.u = first_bits + (uint32_t)i * stride;
+        out[i] = fn == 0 ? orc_det_logf(v.f) : fn == 1 ? orc_det_expf(v.f) : orc_fexp(v.f);
+    }
+}
+
 /* rt_core.cuh:67-88: the value one threshold draw takes, t = -logf(1 - u), for the RNG float u = k / 2^23
  * (pcg32.h:103-112 next_float = ((next_uint >> 9) | 0x3f800000) - 1).  out[i] for k = first_k + i: lets a test
  * compare EVERY possible draw with the device function. */

@@ -106,6 +106,7 @@ float orc_half2float(uint16_t h);
 /* pieces (exposed for known-answer tests) */
 void orc_sample_dst(int spp, orc_pcg32* rng, float* dst /*[spp+1]*/);
 void orc_thresholds(uint32_t first_k, uint32_t count, float* out);
+void orc_math_sweep(int fn, uint32_t first_bits, uint32_t stride, uint32_t count, float* out);
 /* returns leaf slot index (sub_ptr); xyz becomes leaf-local; *cube_sz = N^depth */
 int64_t orc_query(const orc_tree* t, float xyz[3], float* cube_sz, int* levels);
 void orc_sh_basis(int basis_dim, const float dir[3], float out[ORC_BASIS_MAX]);

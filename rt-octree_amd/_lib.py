@@ -105,6 +105,7 @@ SYMBOLS = {
                                          C.POINTER(C.c_double)]),
     "rto_probe_valu": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "rto_probe_thresholds": (C.c_int, [C.c_uint32, C.c_uint32, _P]),
+    "rto_probe_math": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     "rto_timer_reset": (C.c_int, [_P, _P]),
     "rto_timer_start": (C.c_int, [_P, C.c_int]),
     "rto_timer_stop": (C.c_int, [_P, C.c_int]),

@@ -227,6 +227,25 @@ extern "C" int rto_probe_thresholds(uint32_t first_k, uint32_t count, float* hos
     return e == hipSuccess ? RTO_OK : RTO_E_HIP;
 }
 
+// the device's deterministic math, evaluated on the floats with bit patterns first_bits + i * stride
+__global__ void __launch_bounds__(256) math_probe_kernel(int fn, uint32_t first_bits, uint32_t stride, uint32_t count,
+                                                         float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const float x = __uint_as_float(first_bits + i * stride);
+    out[i] = fn == 0 ? rto::det_logf(x) : fn == 1 ? rto::det_expf(x) : rto::fexp_f32(x);
+}
+
+extern "C" int rto_probe_math(int fn, uint32_t first_bits, uint32_t stride, uint32_t count, float* host_out) {
+    if (!host_out || count == 0 || fn < 0 || fn > 2) return RTO_E_INVALID;
+    float* d = nullptr;
+    if (hipMalloc((void**)&d, (size_t)count * 4) != hipSuccess) return RTO_E_HIP;
+    hipLaunchKernelGGL(math_probe_kernel, dim3((count + 255u) / 256u), dim3(256), 0, nullptr, fn, first_bits, stride, count, d);
+    const hipError_t e = hipMemcpy(host_out, d, (size_t)count * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    return e == hipSuccess ? RTO_OK : RTO_E_HIP;
+}
+
 // out[0] = wall ms, out[1] = mean shader cycles per wave, out[2] = waves, out[3] = VALU instructions per wave (nominal)
 extern "C" int rto_probe_valu(int kind, int wps, int iters, double out[4]) {
     if (!out || wps < 1 || wps > 8 || iters < 1 || kind < 0 || kind > 2) return RTO_E_INVALID;

@@ -74,6 +74,8 @@ def lib():
         L.orc_pcg32_next_float.restype = C.c_float
         L.orc_pcg32_advance.argtypes = [C.POINTER(Pcg32), C.c_int64]
         L.orc_pcg32_seed.argtypes = [C.POINTER(Pcg32), C.c_uint64, C.c_uint64]
+        L.orc_math_sweep.restype = None
+        L.orc_math_sweep.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_thresholds.restype = None
         L.orc_thresholds.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_det_logf.restype = C.c_float

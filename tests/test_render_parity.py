@@ -463,3 +463,32 @@ def test_every_threshold_draw_matches_the_oracle():
     assert bad.size == 0, "first mismatching draws k = %s" % bad[:8]
     assert got[0] == 0.0 and np.all(got[1:] > 0) and np.all(np.isfinite(got))
     assert np.all(np.diff(got.astype(np.float64)) >= 0)  # -log(1 - u) is monotone in u
+
+
+@pytest.mark.parametrize("fn,name", [(0, "det_logf"), (1, "det_expf"), (2, "fexp_f32")])
+def test_device_math_equals_the_oracle_across_the_float_range(fn, name):
+    """det_logf / det_expf / fexp_f32 stand in for the reference's `__logf` / `__expf` (DESIGN.md "Math"); device and
+    oracle must agree on EVERY input, not only on those the test scenes produce: every 61st float of the whole 2^32 bit
+    range (70 M values per function: all exponents, both signs, zeros, subnormals, infinities, NaNs), bit for bit."""
+    import ctypes as C
+
+    from rt_octree_amd._lib import check, lib
+    import os
+    stride, chunk = int(os.environ.get("RTO_MATH_SWEEP_STRIDE", "61")), 1 << 24  # 1 = all 2^32 floats (minutes)
+    total = (1 << 32) // stride
+    first = 0
+    mism = 0
+    while first < total:
+        n = min(chunk, total - first)
+        got = np.empty(n, np.float32)
+        want = np.empty(n, np.float32)
+        check(lib().rto_probe_math(fn, (first * stride) & 0xffffffff, stride, n, got.ctypes.data_as(C.c_void_p)))
+        orc.lib().orc_math_sweep(fn, (first * stride) & 0xffffffff, stride, n, want.ctypes.data_as(C.c_void_p))
+        g, w = got.view(np.uint32), want.view(np.uint32)
+        nan = np.isnan(got) & np.isnan(want)  # any NaN payload is the same answer
+        bad = np.flatnonzero((g != w) & ~nan)
+        assert bad.size == 0, "%s: first mismatch at bits 0x%08x: device %r oracle %r" % (
+            name, ((first + int(bad[0])) * stride) & 0xffffffff, got[bad[0]], want[bad[0]])
+        mism += int(bad.size)
+        first += n
+    assert mism == 0

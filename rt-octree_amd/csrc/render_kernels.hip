@@ -701,6 +701,7 @@ struct RayState {
     int prev_lvl;   // level of the node about to be visited
     uint32_t hoff;  // index of this pixel's first hit entry in the hand-off buffer
     uint32_t node;  // node about to be visited; kGridNext = the top grid is visited next
+    float cxy __attribute__((ext_vector_type(2)));  // cen[0], cen[1] as a register pair for the packed march arithmetic
 };
 constexpr uint32_t kGridNext = 0xffffffffu;
 
@@ -778,7 +779,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     // LDS: [max_depth+1-top_levels][256] ancestor stack | [SPP+1][256] sorted thresholds | frame table
     extern __shared__ uint32_t s_mem[];
     const int tid = threadIdx.x;
-    uint32_t* stack = s_mem + tid;
+    uint32_t* stack = s_mem + tid;  // [level - G][256]
     const int stack_levels = tree.max_depth + 1 - tree.top_levels;  // levels top_levels.. only
     float* s_dst = reinterpret_cast<float*>(s_mem + (size_t)stack_levels * 256) + tid;
     FrameDesc* s_frames = reinterpret_cast<FrameDesc*>(s_mem + (size_t)(stack_levels + SPP + 1) * 256);
@@ -813,24 +814,34 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     const gptr2_t topgrid = (gptr2_t)topgrid_p;
     const int G = tree.top_levels;  // grid bits per axis; the LDS stack holds node levels G.. (entry 0 = level G)
     if (G == 0) stack[0] = 0u;      // no top grid: level 0 is the root
+    uint32_t* const stack_g = stack - G * 256;  // indexed by node level (only ever with levels >= G)
 
 #ifdef RTO_DBG_COUNTERS
     unsigned dbg_wave_steps = 0, dbg_lane_steps = 0, dbg_lane_loads = 0, dbg_lane_leafs = 0, dbg_refills = 0, dbg_refilled = 0;
 #endif
     RayState rs;
-    bool active = false;    // marching
+    // a lane marches a ray while rs.t < rs.tmax: that comparison IS the lane's state (an ended ray has t >= tmax or
+    // tmax = -1), so the wave-level count of marching lanes is the ballot of one v_cmp instead of a loop-carried flag
+    rs.t = 0.f;
+    rs.tmax = -1.f;
     bool drained = false;   // queue exhausted (wave-uniform)
     const uint32_t kChunk = chunk;           // rays per global dequeue (a multiple of the 64-ray tile)
     uint32_t res_next = 0, res_end = 0;      // the wave's private reservoir (wave-uniform)
 
     for (;;) {
-        const unsigned long long act_mask = __ballot(active);
-        if (64 - __popcll(act_mask) >= REFILL || act_mask == 0ULL) {
+        bool active = rs.t < rs.tmax;
+        int n_active;
+        {
+            const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
+            asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n_active) : "s"(am) : "scc");
+        }
+        if (n_active <= 64 - REFILL) {  // (includes the empty wave: REFILL <= 64)
             for (;;) {
                 // (a finished ray needs no retiring: the stale threshold behind its last hit entry ends the list)
                 if (drained) break;
                 // ---- refill: hand the next queue entries to the idle lanes (ballot + prefix sum)
-                const unsigned long long need = __ballot(!active);
+                const bool idle = !(rs.t < rs.tmax);
+                const unsigned long long need = __builtin_amdgcn_ballot_w64(idle);
                 const int n_need = __popcll(need);
                 if (n_need < REFILL) break;
                 // The wave draws rays from a private reservoir [res_next, res_end) and tops it up from
@@ -862,7 +873,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                 const uint32_t take = (uint32_t)n_need < res_end - res_next ? (uint32_t)n_need : res_end - res_next;
                 const uint32_t first = res_next;
                 res_next += take;
-                if (!active) {
+                if (idle) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32),
                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
                     const uint32_t r = first + rank;
@@ -892,9 +903,10 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                             rs.spp = 0;
                             rs.src = 0;
                             rs.t = tmin;
+                            rs.cxy.x = rs.cen[0];
+                            rs.cxy.y = rs.cen[1];
                             rs.pix = rs.piy = rs.piz = 0;
                             rs.prev_lvl = 0;
-                            active = rs.t < rs.tmax;
                             {  // locate the first position: fixed-point coordinates + first node
 #pragma unroll
                                 for (int i = 0; i < 3; ++i) rs.pos[i] = clamp_unit(rs.cen[i] + rs.t * rs.dir[i]);
@@ -903,11 +915,14 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                                 rs.piz = (uint32_t)(rs.pos[2] * 16777216.f);
                                 rs.node = G > 0 ? kGridNext : 0u;
                             }
+                        } else {
+                            rs.tmax = -1.f;  // missed the box (ray_enter wrote a tmax that the stale t might undercut)
                         }
                     }
                 }
             }
-            if (__ballot(active) == 0ULL) {
+            active = rs.t < rs.tmax;
+            if (__builtin_amdgcn_ballot_w64(active) == 0ULL) {
                 if (drained) break;
                 continue;
             }
@@ -924,9 +939,9 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                 const uint32_t gs = 24u - (uint32_t)G;
                 const uint32_t key = (((rs.pix >> gs) << G | (rs.piy >> gs)) << G) | (rs.piz >> gs);
                 const uint32_t sh = 23u - (uint32_t)rs.prev_lvl;
-                const uint32_t ci = (__builtin_amdgcn_ubfe(rs.pix, sh, 1u) << 2) |
-                                    (__builtin_amdgcn_ubfe(rs.piy, sh, 1u) << 1) | __builtin_amdgcn_ubfe(rs.piz, sh, 1u);
-                uint32_t slot = (rs.node << 3) | ci;
+                uint32_t slot = (rs.node << 1) | __builtin_amdgcn_ubfe(rs.pix, sh, 1u);  // node * 8 + child digit,
+                slot = (slot << 1) | __builtin_amdgcn_ubfe(rs.piy, sh, 1u);                 // three v_lshl_or
+                slot = (slot << 1) | __builtin_amdgcn_ubfe(rs.piz, sh, 1u);
                 uint32_t w;
 #ifdef RTO_DBG_GRIDUNIQ
                 {  // how many distinct top-grid cells / nodew lines does one wave-level load touch?
@@ -975,7 +990,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                 if ((int32_t)w >= -(1 << 30)) {  // internal: one level down
                     rs.node += w;
                     ++rs.prev_lvl;
-                    stack[(rs.prev_lvl - G) * 256] = rs.node;
+                    stack_g[rs.prev_lvl * 256] = rs.node;
                 } else {  // leaf: the march step (rt_core.cuh:241-270)
                     const int lvl = rs.prev_lvl;
                     // rs.pos is clamp(cen + t * dir) of this very t (computed when the previous step
@@ -983,16 +998,19 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     const float cube_sz = __uint_as_float((uint32_t)(128 + lvl) << 23);
                     const float inv_cube = __uint_as_float((uint32_t)(126 - lvl) << 23);
                     // _dda_unit (rt_core.cuh:38-51) on the leaf-local point frac(pos * cube_sz)
-                    const float b0 = -__builtin_amdgcn_fractf(rs.pos[0] * cube_sz) * rs.invdir[0];
-                    const float b1 = -__builtin_amdgcn_fractf(rs.pos[1] * cube_sz) * rs.invdir[1];
+                    // (x and y as packed pairs: v_pk_mul_f32 / v_pk_add_f32 are the same IEEE operations, two per issue)
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    const f2 ixy = {rs.invdir[0], rs.invdir[1]};
+                    const f2 sxy = (f2){rs.pos[0], rs.pos[1]} * cube_sz;
+                    const f2 bxy = -(f2){__builtin_amdgcn_fractf(sxy.x), __builtin_amdgcn_fractf(sxy.y)} * ixy;
+                    const f2 cxy = bxy + ixy;
                     const float b2 = -__builtin_amdgcn_fractf(rs.pos[2] * cube_sz) * rs.invdir[2];
-                    const float a0 = __builtin_fmaxf(b0, b0 + rs.invdir[0]);
-                    const float a1 = __builtin_fmaxf(b1, b1 + rs.invdir[1]);
+                    const float a0 = __builtin_fmaxf(bxy.x, cxy.x);
+                    const float a1 = __builtin_fmaxf(bxy.y, cxy.y);
                     const float a2 = __builtin_fmaxf(b2, b2 + rs.invdir[2]);
                     const float tm = __builtin_fminf(1e4f, __builtin_fminf(__builtin_fminf(a0, a1), a2));
                     const float delta_t = tm * inv_cube + step_size;
                     const float sigma = half_bits_to_float((uint16_t)w);
-                    bool done = false;
                     if (sigma > sigma_thresh) {
                         const float delta = delta_t * rs.delta_scale * sigma;
                         const float reach = rs.src + delta;
@@ -1005,35 +1023,43 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                             } while (reach >= rs.cur);
                             hits[rs.hoff + rs.sh_nums * hstride] = hit_pack<SPP>(slot, cnt);
                             ++rs.sh_nums;
-                            done = rs.spp == (uint32_t)SPP;
+                            if (rs.spp == (uint32_t)SPP) rs.tmax = -1.f;  // the last threshold: the ray ends
                         }
                         rs.src = reach;
                     }
                     rs.t += delta_t;
-                    active = !done && rs.t < rs.tmax;
+                    active = rs.t < rs.tmax;
 #ifdef RTO_DBG_COUNTERS
                     ++dbg_lane_leafs;
 #endif
                     if (active) {  // next position -> restart node (deepest ancestor shared with this step)
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) rs.pos[i] = clamp_unit(rs.cen[i] + rs.t * rs.dir[i]);
-                        const uint32_t ix = (uint32_t)(rs.pos[0] * 16777216.f);
-                        const uint32_t iy = (uint32_t)(rs.pos[1] * 16777216.f);
+                        const f2 pxy = rs.cxy + (f2){rs.dir[0], rs.dir[1]} * rs.t;
+                        rs.pos[0] = clamp_unit(pxy.x);
+                        rs.pos[1] = clamp_unit(pxy.y);
+                        rs.pos[2] = clamp_unit(rs.cen[2] + rs.t * rs.dir[2]);
+                        const f2 qxy = (f2){rs.pos[0], rs.pos[1]} * 16777216.f;
+                        const uint32_t ix = (uint32_t)qxy.x;
+                        const uint32_t iy = (uint32_t)qxy.y;
                         const uint32_t iz = (uint32_t)(rs.pos[2] * 16777216.f);
                         const uint32_t diff = (ix ^ rs.pix) | (iy ^ rs.piy) | (iz ^ rs.piz);
-                        int m = __clz((int)diff) - 8;
+                        // deepest level whose cell still holds both points: leading equal bits of the 24-bit coordinates,
+                        // capped at the leaf's level (v_ffbh_u32 returns -1 for diff = 0; as an unsigned number that
+                        // loses the minimum as well)
+                        uint32_t lead;
+                        asm("v_ffbh_u32 %0, %1" : "=v"(lead) : "v"(diff));
+                        const uint32_t mu = lead - 8u;
 #ifdef RTO_DBG_COUNTERS
-                        if (m >= lvl) ++dbg_refilled;      // next leaf is a sibling (same parent node)
-                        if (m == lvl - 1) ++dbg_refills;   // next leaf is a cousin (same grandparent)
+                        if ((int)mu >= lvl) ++dbg_refilled;      // next leaf is a sibling (same parent node)
+                        if ((int)mu == lvl - 1) ++dbg_refills;   // next leaf is a cousin (same grandparent)
 #endif
-                        m = m < lvl ? m : lvl;
+                        const int m = (int)(mu < (uint32_t)lvl ? mu : (uint32_t)lvl);
                         rs.pix = ix;
                         rs.piy = iy;
                         rs.piz = iz;
                         if (m < G) {
                             rs.node = kGridNext;
                         } else {
-                            rs.node = stack[(m - G) * 256];
+                            rs.node = stack_g[m * 256];
                             rs.prev_lvl = m;
                         }
                     }

@@ -7,7 +7,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(PKG_DIR, "lib", "librto.so")
+LIB_PATH = os.environ.get("RTO_LIB") or os.path.join(PKG_DIR, "lib", "librto.so")  # (RTO_LIB: another build of the same library, for same-box A/B runs)
 
 RTO_OK = 0
 

@@ -975,14 +975,22 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     }
                 }
 #endif
+                // Both addresses exist in registers before either load is issued.  Left to itself the compiler sinks each
+                // address computation into its branch, and when a temporary of the second branch lands in the register the
+                // first branch's load is still writing, it has to put an s_waitcnt vmcnt(0) between the two loads -- the
+                // iteration then pays two memory latencies back to back (measured: 8.16 instead of 7.16 ms per 100
+                // frames from a one-instruction difference elsewhere in the kernel that renumbered the registers).
+                gptr_t pn = nodew + slot;
+                gptr2_t pg = topgrid + key;
+                asm volatile("" : "+v"(pn), "+v"(pg));
                 if (grid) {  // the iteration's one load: 8 bytes of the top grid ...
-                    const u32x2 e = topgrid[key];  // (through the L1 as well: non-temporal costs 15 %)
+                    const u32x2 e = *pg;  // (through the L1 as well: non-temporal costs 15 %)
                     slot = e.x & kGridSlotMask;
                     rs.prev_lvl = (int)(e.x >> kGridSlotBits);
                     rs.node = slot >> 3;
                     w = e.y;
                 } else {  // ... or 4 bytes of the traversal image
-                    w = nodew[slot];  // (through the L1: a non-temporal load here costs 50 %)
+                    w = *pn;  // (through the L1: a non-temporal load here costs 50 %)
                 }
 #ifdef RTO_DBG_COUNTERS
                 ++dbg_lane_loads;

@@ -15,8 +15,16 @@ from rt_octree_amd import synth  # noqa: E402
 def main():
     import torch
     settings = [a for a in sys.argv[1:] if "=" in a] or ["xcd_queues=0", "xcd_queues=1"]
-    tree = synth.make_tree(depth_limit=10, basis_dim=16, shell=2.5)
-    dt = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+    cache = "/dev/shm/rto_ab_tree_d10_b16.npz"  # (20 s to generate: shared by the runs of one A/B job)
+    if os.path.exists(cache):
+        z = np.load(cache)
+        dt = R.N3Tree.from_arrays(z["child"], z["data"], z["scale"], z["offset"], str(z["data_format"]))
+    else:
+        tree = synth.make_tree(depth_limit=10, basis_dim=16, shell=2.5)
+        np.savez(cache + ".tmp.npz", child=tree.child, data=tree.data, scale=tree.scale, offset=tree.offset,
+                 data_format=tree.data_format)
+        os.replace(cache + ".tmp.npz", cache)
+        dt = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
     W = H = 800
     fx = synth.blender_focal(W)
     cams = []

@@ -403,12 +403,13 @@ RTO_DEV bool block_tile(const TileMap& tm, int b, int& tx, int& ty) {
 //   planar      [SPP][H*W]:  i * SIZE + p   (a wave's 64 hit stores go to 64 different lines once its lanes hold
 //                                            unrelated pixels)
 //   pixel-major [H*W][SPP]:  p * SPP + i   (a pixel's thresholds / hit list are one contiguous run: 24 B at SPP 6)
-// (measured, 32 frames of 800x800 SPP 6: pixel-major traversal 2.98 ms, planar 2.81 ms; shading 0.78 vs 0.80 ms --
-// planar stays)
-#ifdef RTO_HITS_PIXEL_MAJOR
-constexpr bool kHitsPixelMajor = true;
-#else
+// Pixel-major is the default.  Measured in ONE box (tools/ab_variants.sh), 100 frames of 800x800 SPP 6,
+// with the terminator-free lists: traversal 7.28 vs 7.34 ms, shading 1.96 vs 2.17 ms.  (An earlier comparison across two
+// boxes and two register allocations -- see the load-overlap note in render_persist -- had it 6 % behind.)
+#ifdef RTO_HITS_PLANAR
 constexpr bool kHitsPixelMajor = false;
+#else
+constexpr bool kHitsPixelMajor = true;
 #endif
 template <int SPP>
 RTO_DEV uint32_t hit_index(uint32_t pixel, uint32_t i, uint32_t SIZE) {

@@ -468,7 +468,7 @@ def main():
 
     # counter passes of THIS workload committed under profiles/ (tools/profile_round.sh); bytes and L1 line
     # accesses scale with the frames of a launch
-    traffic = tcp = traffic_src = None
+    traffic = tcp = traffic_src = valu = None
     wid = workload_id(args, W, H)
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if wid and os.path.exists(pmc_path):
@@ -479,6 +479,16 @@ def main():
                 scale = frames_per_launch / float(pj["frames_per_launch"])
                 traffic = (pj["fetch_bytes"] + pj["write_bytes"]) * scale
                 traffic_src = pj.get("source")
+                if pj.get("valu_insts") and pj.get("kernel_clocks"):
+                    simds = float(pj.get("cus", 256)) * 4.0
+                    valu = {"wave_insts_per_launch": pj["valu_insts"] * scale,
+                            "insts_per_clk_per_simd": pj["valu_insts"] / simds / pj["kernel_clocks"],
+                            "peak_insts_per_clk_per_simd": 0.25,
+                            "frac": pj["valu_insts"] * 4.0 / simds / pj["kernel_clocks"],
+                            "busy_frac": (pj.get("valu_active_quads") or 0.0) * 4.0 / simds / pj["kernel_clocks"],
+                            "note": "a CDNA4 SIMD issues one wave64 VALU instruction per 4 clocks: frac = SQ_INSTS_VALU x 4 / "
+                                    "(SIMDs x kernel clocks), busy_frac the same from SQ_ACTIVE_INST_VALU (quad-cycles), "
+                                    "both from the committed counter passes of this workload"}
                 ce = doc.get("ceilings")
                 if pj.get("tcp_line_accesses") and ce:
                     cus = float(pj.get("cus", 256))
@@ -504,7 +514,7 @@ def main():
                                    "four independent gathers in flight per wave -- rates no dependent walk can reach."}
         except Exception as e:  # a malformed profile must not break the bench line
             print("[bench] ignoring %s: %r" % (pmc_path, e), file=sys.stderr)
-            traffic = tcp = None
+            traffic = tcp = valu = None
     achieved = traffic / t_launch / 1e9 if (traffic and t_launch > 0) else None
 
     if rank != 0:
@@ -630,6 +640,7 @@ def main():
         "shade_kernel_avg_launch_ms": kt["shade_ms"],
         "units_per_frame": {k: v / count_steps for k, v in units.items()},
         "tcp": tcp,
+        "valu": valu,
     }
     out = {
         "metric": "FPS @ 800x800 (Lego SPP=6) + PSNR vs ref; 1/2/4/8 GPU scaling",

@@ -38,6 +38,8 @@ def main():
              "fetch_bytes": m("FETCH_SIZE") * 1024.0, "write_bytes": m("WRITE_SIZE") * 1024.0,
              "tcp_line_accesses": m("TCP_TOTAL_CACHE_ACCESSES_sum"), "tcp_tcc_read_req": m("TCP_TCC_READ_REQ_sum"),
              "tcc_hit": m("TCC_HIT_sum"), "tcc_miss": m("TCC_MISS_sum"),
+             # wave-level VALU instructions (a SIMD issues one per 4 clocks) and the quad-cycles the VALU was busy
+             "valu_insts": m("SQ_INSTS_VALU"), "valu_active_quads": m("SQ_ACTIVE_INST_VALU"),
              # GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md "DVFS give-back")
              "kernel_clocks": (m("GRBM_GUI_ACTIVE") or 0) / 8.0,
              "source": "%s: rocprofv3 --pmc, one pass per counter group (FETCH_SIZE; WRITE_SIZE; TCC/TCP; GRBM), "

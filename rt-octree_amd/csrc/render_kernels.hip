@@ -1516,7 +1516,7 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
                                    int refill, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
     const int chunk_override = (refill / 1000) * 64;  // tuning: refill = 1000 * tiles_per_dequeue + threshold
     refill %= 1000;
-    if (SPP == 6) {  // tuning instantiations only for the benchmark configuration
+    if constexpr (SPP == 6) {  // tuning instantiations only for the benchmark configuration
 #define RTO_F(R, O) return launch_batch_impl<SPP, R, O>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, occ, ev, stream)
         switch (refill) {  // A/B set kept for tools/ab_tuning.py: 100 * waves/SIMD + refill threshold
             case 808: RTO_F(8, 8);

@@ -1,0 +1,36 @@
+"""Code-generation guard for the traversal kernel (no GPU needed: hipcc cross-compiles gfx950).
+
+render_persist issues two gathers per node visit -- 4 bytes of the traversal image for the lanes inside the tree, 8
+bytes of the top grid for the others -- and its speed depends on both being in flight together.  Round 2 found a build
+in which the register allocator had put an `s_waitcnt vmcnt(0)` BETWEEN the two loads (a temporary of the second branch
+reused the first load's destination register): same instructions, same memory traffic, 14 % slower ("A
+register-allocation cliff").  The kernel now forms both addresses before either load; this test keeps it that way."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "rt-octree_amd", "csrc")
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
+def test_the_two_gathers_of_a_node_visit_are_issued_back_to_back(tmp_path):
+    asm = tmp_path / "render_kernels.s"
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math",
+                    "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-S", "--cuda-device-only",
+                    os.path.join(CSRC, "render_kernels.hip"), "-o", str(asm)], check=True, capture_output=True, timeout=900)
+    text = asm.read_text()
+    for spp in (1, 6):  # the benchmark's instantiations (C5, C2 / C4)
+        m = re.search(r"^_ZN3rto14render_persistILi%dELi32ELi6EEE[^\n]*\n(.*?)s_endpgm" % spp, text, re.S | re.M)
+        assert m, "render_persist<%d,32,6> not found in the assembly" % spp
+        body = [ln.split(";")[0].strip() for ln in m.group(1).splitlines()]
+        body = [ln for ln in body if ln and not ln.startswith(".") or ln.startswith(".LBB")]
+        grid = max(i for i, ln in enumerate(body) if ln.startswith("global_load_dwordx2"))  # the top-grid entry
+        node = max(i for i, ln in enumerate(body[:grid]) if ln.startswith("global_load_dword "))  # the slot word
+        between = body[node + 1:grid]
+        assert len(between) <= 8, "unexpected code between the two gathers: %s" % between
+        assert not any("vmcnt" in ln for ln in between), "a wait separates the two gathers: %s" % between
+        assert not any(ln.startswith("v_") for ln in between), "VALU work between the two gathers: %s" % between

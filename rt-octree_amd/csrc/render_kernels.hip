@@ -529,7 +529,7 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
             float tv = -det_log_one_minus(pcg_next_float(rng));
 #pragma unroll
             for (int i = 0; i < n; ++i) {  // static-index insertion: same sorted array
-                const float lo = f_min(dst[i], tv), hi = f_max(dst[i], tv);
+                const float lo = __builtin_fminf(dst[i], tv), hi = __builtin_fmaxf(dst[i], tv);  // (see sample_kernel)
                 dst[i] = lo;
                 tv = hi;
             }
@@ -755,7 +755,9 @@ __global__ void __launch_bounds__(256) sample_kernel(const FrameBatch fb, const 
         float tv = -det_log_one_minus(pcg_next_float(rng));
 #pragma unroll
         for (int i = 0; i < n; ++i) {  // static-index insertion: same sorted array
-            const float lo = f_min(dst[i], tv), hi = f_max(dst[i], tv);
+            // (v_min_f32 / v_max_f32: the draws are never NaN, and the only zero a draw can be is -0.0 = -log(1 - 0), so
+            //  these return what the reference's `a < b ? a : b` forms do -- in half the instructions)
+            const float lo = __builtin_fminf(dst[i], tv), hi = __builtin_fmaxf(dst[i], tv);
             dst[i] = lo;
             tv = hi;
         }

@@ -131,6 +131,12 @@ int rto_tree_load_npz(const char* path, int device, rto_tree** out);
  * SH16 trees: + 64 / 128 B per leaf slot, i.e. the device footprint roughly doubles, for ~11 % faster shading = ~2 % more
  * frames/s on the benchmark scene).  Same pixels either way. */
 #define RTO_TREE_COMPACT 2
+/* RTO_TREE_KEEP_REFERENCE: a dense SH9 / SH16 tree that has the aligned copy renders through the fast and the batched
+ * kernels from the traversal image + that copy alone, so by default the upload RELEASES the reference-layout child[] and
+ * data[] arrays once the derived ones exist (device footprint of the benchmark tree: 2.2 GB instead of 4.0 GB for a
+ * 1.7 GB file) and rebuilds them -- the same leaf values -- on the first launch that selects the generic kernel
+ * (rto_ctx_set_kernel(RTO_KERNEL_GENERIC)), which then pays one pass over the tree.  This flag keeps them resident. */
+#define RTO_TREE_KEEP_REFERENCE 4
 int rto_tree_load_npz_ex(const char* path, int device, int flags, rto_tree** out);
 /* Same upload from host arrays: child int32 [capacity*N^3], data fp16 bits
  * [capacity*N^3*data_dim], data_format like "SH9"/"SH16"/"RGBA" (DataFormat::parse,
@@ -138,6 +144,10 @@ int rto_tree_load_npz_ex(const char* path, int device, int flags, rto_tree** out
 int rto_tree_from_arrays(const int32_t* child, const uint16_t* data, int64_t capacity, int N,
                          int data_dim, const char* data_format, const float scale[3],
                          const float offset[3], int device, rto_tree** out);
+/* the same with the RTO_TREE_* flags of rto_tree_load_npz_ex (RTO_TREE_QUANT_DIRECT does not apply to arrays) */
+int rto_tree_from_arrays_ex(const int32_t* child, const uint16_t* data, int64_t capacity, int N,
+                            int data_dim, const char* data_format, const float scale[3],
+                            const float offset[3], int device, int flags, rto_tree** out);
 /* main_headless.cpp:400-405 (llff): switch the NDC warp on. width <= 0 turns it off. */
 int rto_tree_set_ndc(rto_tree* t, float ndc_width, float ndc_height, float ndc_focal);
 int rto_tree_get_info(const rto_tree* t, rto_tree_info* info);
@@ -281,9 +291,14 @@ int rto_guidance_net_forward_ex(const rto_guidance_net* net, void* stream, const
  * widens those values; rto_filtering_packed then runs the factorised filter (RTO_FILTER_FACTORISED) on them, taking
  * the softmax itself: img_in / img_out [n][H][W][4] fp32.  Output = rto_guidance_net_forward_ex +
  * rto_filtering_batch_mode(FACTORISED) bit for bit, from half the map bytes.  Same stream for both calls; one
- * handle per stream at a time. */
+ * handle per stream at a time.
+ * rto_filtering_packed is told the extent of the images it is handed and refuses (RTO_E_INVALID) one that differs from
+ * the maps' -- a handle shared between contexts of different batch sizes cannot overrun the smaller one.  The scratch
+ * grows on demand, which synchronises the device once; rto_guidance_net_reserve sizes it up front so that a timed or
+ * captured region never does. */
 int rto_guidance_net_forward_packed(rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W, int flags);
-int rto_filtering_packed(const rto_guidance_net* net, void* stream, const float* img_in, float* img_out);
+int rto_guidance_net_reserve(rto_guidance_net* net, int n, int H, int W);
+int rto_filtering_packed(const rto_guidance_net* net, void* stream, const float* img_in, float* img_out, int n, int H, int W);
 void rto_guidance_net_free(rto_guidance_net* net);
 
 /* ---- profiling aid ---- */
@@ -298,11 +313,14 @@ int rto_probe_gather(uint64_t n_lines, int repeats);
  * interleaved (blocked = 0) or in runs (blocked = 1); dependent = 1 chains each gather's address on the
  * previous one's value (the traversal's shape), 0 keeps four in flight per wave.
  * out = {wall ms per launch, mean shader-clock cycles per wave, waves, gathers per wave}.
- * rto_probe_valu: 16 independent chains per lane; kind 0 = v_fma_f32, 1 = integer, 2 = the traversal's op
- * mix.  out = {wall ms, mean cycles per wave, waves, nominal VALU instructions per wave}. */
+ * rto_probe_valu: persistent waves (`wps` per SIMD on every CU) run `iters` times ONE asm block of exactly 32
+ * wave-level VALU instructions on independent registers; `kind` picks the opcode (rto_probe_valu_name(kind) names
+ * it, NULL past the last kind).  out = {wall ms, mean s_memtime ticks per wave, waves, VALU instructions per wave
+ * (exact), ticks from the first wave's start to the last wave's end, CUs}. */
 int rto_probe_gather_sweep(uint64_t table_bytes, int lines_per_gather, int blocked, int dependent, int wps,
                            int iters, int repeats, double out[4]);
-int rto_probe_valu(int kind, int wps, int iters, double out[4]);
+int rto_probe_valu(int kind, int wps, int iters, double out[6]);
+const char* rto_probe_valu_name(int kind);
 /* Test hook: host_out[i] = the threshold the renderer draws from the RNG float k / 2^23, k = first_k + i
  * (rt_core.cuh:67-88 `-logf(1 - rng.next_float())` in the library's deterministic arithmetic), computed on the
  * device by the very function the kernels call.  first_k + count <= 2^23: the whole domain can be compared with

@@ -59,6 +59,9 @@ SYMBOLS = {
     "rto_tree_from_arrays": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_char_p,
                                        C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
                                        C.POINTER(_P)]),
+    "rto_tree_from_arrays_ex": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_char_p,
+                                          C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int,
+                                          C.POINTER(_P)]),
     "rto_tree_set_ndc": (C.c_int, [_P, C.c_float, C.c_float, C.c_float]),
     "rto_tree_get_info": (C.c_int, [_P, C.POINTER(CTreeInfo)]),
     "rto_tree_probe_npz": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
@@ -98,12 +101,14 @@ SYMBOLS = {
     "rto_guidance_net_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rto_guidance_net_forward_ex": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int]),
     "rto_guidance_net_forward_packed": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "rto_filtering_packed": (C.c_int, [_P, _P, _P, _P]),
+    "rto_filtering_packed": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
+    "rto_guidance_net_reserve": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "rto_guidance_net_free": (None, [_P]),
     "rto_probe_gather": (C.c_int, [C.c_uint64, C.c_int]),
     "rto_probe_gather_sweep": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(C.c_double)]),
     "rto_probe_valu": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "rto_probe_valu_name": (C.c_char_p, [C.c_int]),
     "rto_probe_thresholds": (C.c_int, [C.c_uint32, C.c_uint32, _P]),
     "rto_probe_math": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     "rto_timer_reset": (C.c_int, [_P, _P]),

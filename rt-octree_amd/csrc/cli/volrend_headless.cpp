@@ -266,7 +266,7 @@ int main(int argc, char** argv) {
         if (timed) rto_timer_stop(ctx, RTO_T_TORCH);
         if (rc != RTO_OK) return rc;
         if (timed) rto_timer_start(ctx, RTO_T_FILTER);
-        rc = packed ? rto_filtering_packed(denoiser->fused_handle(), stream, rto_ctx_noisy(ctx), rto_ctx_image(ctx))
+        rc = packed ? rto_filtering_packed(denoiser->fused_handle(), stream, rto_ctx_noisy(ctx), rto_ctx_image(ctx), n, height, width)
                     : rto_filtering_batch_mode(stream, w, g, L, height, width, n, rto_ctx_noisy(ctx), rto_ctx_image(ctx), filter_mode);
         if (timed) rto_timer_stop(ctx, RTO_T_FILTER);
         return rc;

@@ -264,6 +264,7 @@ __global__ void __launch_bounds__(256, 4) guidance_fused(const float* __restrict
         const float4v bias = *reinterpret_cast<const float4v*>(s_b2 + kg * 4);
 #ifndef RTO_NET_DBG_CREP
 #define RTO_NET_DBG_CREP 1
+#endif
         for (int rep = 0; rep < RTO_NET_DBG_CREP; ++rep) {
             if (RTO_NET_DBG_CREP > 1) asm volatile("" ::: "memory");
             const int ox = (wave & 1) * 16 + col, oy0 = (wave >> 1) * 4;
@@ -321,7 +322,6 @@ __global__ void __launch_bounds__(256, 4) guidance_fused(const float* __restrict
             }
         }
     }
-#endif
 #ifdef RTO_NET_DBG_STAMP
     if (ts == 0) {
         st[5] = __builtin_amdgcn_s_memtime();

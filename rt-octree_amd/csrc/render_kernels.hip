@@ -364,6 +364,22 @@ __global__ void build_shrec_kernel(const uint16_t* __restrict__ data, int64_t n_
     out[i] = k < data_dim - 1 ? data[slot * data_dim + k] : (uint16_t)0;
 }
 
+// The reference-layout arrays back from the derived ones (rto_abi.cpp ensure_reference_arrays): a tree that renders through
+// the fast / batched kernels keeps only nodew + shrec resident; the generic kernel's child[] / data[] are rebuilt on
+// first use.  Leaf slots get their exact fp16 values back (coefficients from shrec, sigma from the leaf word); an
+// internal slot's sigma -- which no query ever returns -- becomes 0.
+__global__ void rebuild_reference_kernel(const uint16_t* __restrict__ shrec, const uint32_t* __restrict__ nodew, int64_t n_slots,
+                                         int data_dim, int rec, uint16_t* __restrict__ data, int32_t* __restrict__ child) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per half of data[]
+    if (i >= n_slots * data_dim) return;
+    const int64_t slot = i / data_dim;
+    const int k = (int)(i - slot * data_dim);
+    const uint32_t w = nodew[slot];
+    const bool leaf = nodew_is_leaf(w);
+    data[i] = k < data_dim - 1 ? shrec[slot * rec + k] : (leaf ? (uint16_t)(w & 0xffffu) : (uint16_t)0);
+    if (k == 0) child[slot] = leaf ? 0 : (int32_t)w;
+}
+
 // Top-of-tree shortcut (TreeDev::topgrid): one thread per cell of the 2^G-per-axis grid walks its
 // root path over node levels 0..G-1 and records where it ends: {slot | level << kGridSlotBits, nodew[slot]}.
 __global__ void build_topgrid_kernel(const uint32_t* __restrict__ nodew, int G, uint2* __restrict__ grid) {
@@ -986,6 +1002,22 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                 gptr_t pn = nodew + slot;
                 gptr2_t pg = topgrid + key;
                 asm volatile("" : "+v"(pn), "+v"(pg));
+#ifdef RTO_STUB_LOADS
+                // Calibration build only (tools/calibrate_valu.sh): both gathers replaced by a hash of their address -- a
+                // procedural stand-in for the tree with the same loop, the same divergence and no memory latency, to measure
+                // what the loop body sustains in VALU instructions per clock at 1..8 waves per SIMD.  Never shipped.
+                if (grid) {
+                    const uint32_t hsh = key * 0x9E3779B1u;
+                    const uint32_t glv = 2u + (hsh >> 30);
+                    slot = (key << 3) & kGridSlotMask;
+                    rs.prev_lvl = (int)glv;
+                    rs.node = slot >> 3;
+                    w = (glv == 5u && (hsh & 0x100u)) ? 1u : (kLeafTag | ((hsh & 0x600u) ? 0u : 0x4D00u));
+                } else {
+                    const uint32_t hsh = slot * 0x9E3779B1u;
+                    w = (rs.prev_lvl < 9 && (hsh >> 29) < 3u) ? 1u : (kLeafTag | ((hsh & 0x600u) ? 0u : 0x4D00u));
+                }
+#else
                 if (grid) {  // the iteration's one load: 8 bytes of the top grid ...
                     const u32x2 e = *pg;  // (through the L1 as well: non-temporal costs 15 %)
                     slot = e.x & kGridSlotMask;
@@ -995,6 +1027,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                 } else {  // ... or 4 bytes of the traversal image
                     w = *pn;  // (through the L1: a non-temporal load here costs 50 %)
                 }
+#endif
 #ifdef RTO_DBG_COUNTERS
                 ++dbg_lane_loads;
 #endif
@@ -1394,6 +1427,14 @@ hipError_t launch_build_shrec(const uint16_t* data, int64_t n_slots, int data_di
     return hipGetLastError();
 }
 
+hipError_t launch_rebuild_reference(const uint16_t* shrec, const uint32_t* nodew, int64_t n_slots, int data_dim, int rec,
+                                    uint16_t* data, int32_t* child, hipStream_t stream) {
+    const int64_t n = n_slots * data_dim;
+    hipLaunchKernelGGL(rebuild_reference_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, shrec, nodew, n_slots,
+                       data_dim, rec, data, child);
+    return hipGetLastError();
+}
+
 hipError_t launch_build_topgrid(const uint32_t* nodew, int G, uint2* grid, hipStream_t stream) {
     const unsigned n = 1u << (3 * G);
     hipLaunchKernelGGL(build_topgrid_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, nodew, G, grid);
@@ -1450,12 +1491,20 @@ template <int SPP, int REFILL, int WPS>
 static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                     const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
                                     int chunk_override, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
+    // dynamic LDS: ancestor stack + thresholds per lane, then the frame table of THIS batch (96 B per frame: a batch of
+    // one does not pay for 128)
     const size_t lds = (size_t)(tree.max_depth + 1 - tree.top_levels + SPP + 1) * 256 * sizeof(uint32_t) +
-                       sizeof(FrameDesc) * kMaxBatch;
+                       sizeof(FrameDesc) * (size_t)fb.n;
     const void* fn = reinterpret_cast<const void*>(&render_persist<SPP, REFILL, WPS>);
     OccupancyCache local;
     if (!occ) occ = &local;
     if (occ->blocks_per_cu == 0 || occ->fn != fn || occ->lds != lds) {
+        if (lds > 64 * 1024) {  // beyond the default dynamic-LDS window: ask for it (the CU has 160 KB)
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                (void)hipGetLastError();
+                return hipErrorInvalidConfiguration;  // the caller reports it (deep tree x SPP 32) and takes the generic kernel
+            }
+        }
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_persist<SPP, REFILL, WPS>, 256, lds) != hipSuccess || nb < 1)
             nb = 2;
@@ -1463,7 +1512,7 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
         occ->fn = fn;
         occ->lds = lds;
     }
-    const int blocks_per_cu = occ->blocks_per_cu;
+    const int blocks_per_cu = occ->cap > 0 && occ->cap < occ->blocks_per_cu ? occ->cap : occ->blocks_per_cu;
     const int tiles = ((fb.width + 7) / 8) * ((fb.height + 7) / 8) * fb.n;
     int grid = num_cus * blocks_per_cu;
     if (grid > (tiles + 3) / 4) grid = (tiles + 3) / 4;  // never more waves than 8x8 tiles
@@ -1527,6 +1576,8 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
             case 624: RTO_F(24, 6);
             case 640: RTO_F(40, 6);
             case 432: RTO_F(32, 4);
+            case 232: RTO_F(32, 2);
+            case 132: RTO_F(32, 1);
             default: break;
         }
 #undef RTO_F

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -88,6 +89,12 @@ struct rto_tree {
     void* d_qsigma = nullptr;
     bool quant = false;  // rendered from the codebooks; only the batched path can shade it
     bool fast_ok = false;
+    // Footprint (VERDICT r2 task 8): a dense SH9 / SH16 tree that renders through the fast / batched kernels reads only
+    // nodew + topgrid + shrec, so child[] / data[] are released after the upload and rebuilt from those two on the first
+    // launch that selects the generic kernel (ensure_reference_arrays).  RTO_TREE_KEEP_REFERENCE keeps them resident.
+    bool reference_dropped = false;
+    int shrec_halves = 0;
+    std::mutex rebuild_mutex;
 };
 
 struct rto_ctx {
@@ -388,7 +395,7 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
     }
 
     if (t->fast_ok && !quant && fmt.format == RTO_FMT_SH && (fmt.basis_dim == 9 || fmt.basis_dim == 16) &&
-        !(flags & RTO_TREE_COMPACT) && !std::getenv("RTO_NO_SHREC")) {  // (the variable: tests)
+        !(flags & RTO_TREE_COMPACT)) {
         // aligned copy of the SH coefficients for the shading kernels (+ 64 / 128 B per slot)
         const int rec = 3 * fmt.basis_dim * 2 <= 64 ? 32 : 64;  // = shrec_halves()
         const size_t rb = (size_t)n_slots * rec * 2;
@@ -397,10 +404,20 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
             if (e == hipSuccess) e = hipDeviceSynchronize();
             if (e != hipSuccess) return fail(RTO_E_HIP, std::string("build_shrec failed: ") + hipGetErrorString(e));
             dev_bytes += rb;
+            t->shrec_halves = rec;
         } else {  // not enough memory for the copy: shade from data[]
             (void)hipGetLastError();
             t->d_shrec = nullptr;
         }
+    }
+
+    if (t->d_shrec && !(flags & RTO_TREE_KEEP_REFERENCE)) {
+        // the fast / batched kernels never read child[] / data[] of such a tree: release them (rebuilt on demand)
+        (void)hipFree(t->d_data);
+        (void)hipFree(t->d_child);
+        t->d_data = t->d_child = nullptr;
+        t->reference_dropped = true;
+        dev_bytes -= data_bytes + 16 + child_bytes;
     }
 
     rto::TreeDev& d = t->dev;
@@ -449,6 +466,42 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
     inf.max_depth = max_depth;
     inf.device_bytes = (int64_t)dev_bytes;
     *out = t;
+    return RTO_OK;
+}
+
+// child[] / data[] of a tree that dropped them at upload, back on the device for the generic kernel (same leaf values:
+// tests/test_render_parity.py::test_generic_kernel_on_a_tree_without_reference_arrays)
+int ensure_reference_arrays(const rto_tree* tree) {
+    if (!tree->reference_dropped) return RTO_OK;
+    rto_tree* t = const_cast<rto_tree*>(tree);  // derived, lazily materialised state of a logically const tree
+    std::lock_guard<std::mutex> lock(t->rebuild_mutex);
+    if (!t->reference_dropped) return RTO_OK;
+    DeviceGuard guard(t->device);
+    if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");
+    const int64_t n_slots = t->info.capacity * t->dev.N3;
+    const size_t data_bytes = (size_t)n_slots * t->dev.data_dim * sizeof(uint16_t), child_bytes = (size_t)n_slots * sizeof(int32_t);
+    void *d_data = nullptr, *d_child = nullptr;
+    if (hipMalloc(&d_data, data_bytes + 16) != hipSuccess || hipMalloc(&d_child, child_bytes) != hipSuccess) {
+        if (d_data) (void)hipFree(d_data);
+        (void)hipGetLastError();
+        return set_err(RTO_E_HIP, "the generic kernel needs the tree's child[] / data[] arrays back on the device: hipMalloc failed");
+    }
+    hipError_t e = hipMemset((char*)d_data + data_bytes, 0, 16);
+    if (e == hipSuccess)
+        e = rto::launch_rebuild_reference((const uint16_t*)t->d_shrec, (const uint32_t*)t->d_nodew, n_slots, t->dev.data_dim,
+                                          t->shrec_halves, (uint16_t*)d_data, (int32_t*)d_child, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipFree(d_data);
+        (void)hipFree(d_child);
+        return set_err(RTO_E_HIP, std::string("rebuilding child[] / data[] failed: ") + hipGetErrorString(e));
+    }
+    t->d_data = d_data;
+    t->d_child = d_child;
+    t->dev.data = (const uint16_t*)d_data;
+    t->dev.child = (const int32_t*)d_child;
+    t->info.device_bytes += (int64_t)(data_bytes + 16 + child_bytes);
+    t->reference_dropped = false;
     return RTO_OK;
 }
 
@@ -624,6 +677,12 @@ int rto_tree_probe_npz(const char* path, char* json_out, size_t cap) {
 int rto_tree_from_arrays(const int32_t* child, const uint16_t* data, int64_t capacity, int N, int data_dim,
                          const char* data_format, const float scale[3], const float offset[3], int device,
                          rto_tree** out) {
+    return rto_tree_from_arrays_ex(child, data, capacity, N, data_dim, data_format, scale, offset, device, 0, out);
+}
+
+int rto_tree_from_arrays_ex(const int32_t* child, const uint16_t* data, int64_t capacity, int N, int data_dim,
+                            const char* data_format, const float scale[3], const float offset[3], int device, int flags,
+                            rto_tree** out) {
     if (!scale || !offset) return set_err(RTO_E_INVALID, "rto_tree_from_arrays: null scale/offset");
     rto::DataFormat fmt;
     if (data_format && data_format[0]) {
@@ -635,7 +694,7 @@ int rto_tree_from_arrays(const int32_t* child, const uint16_t* data, int64_t cap
         fmt.format = RTO_FMT_SH;
         fmt.basis_dim = (data_dim - 1) / 3;
     }
-    return upload_tree(child, data, capacity, N, data_dim, fmt, scale, offset, device, out);
+    return upload_tree(child, data, capacity, N, data_dim, fmt, scale, offset, device, out, nullptr, flags & ~RTO_TREE_QUANT_DIRECT);
 }
 
 int rto_tree_set_ndc(rto_tree* t, float w, float h, float focal) {
@@ -883,6 +942,9 @@ int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value) {
         return build_tile_tables(c);
     } else if (k == "refill") {
         c->refill = value;
+    } else if (k == "blocks_per_cu") {  // occupancy of the persistent traversal kernel: 0 = what fits, else a cap (1..8)
+        if (value < 0 || value > 8) return set_err(RTO_E_INVALID, "blocks_per_cu must be 0..8");
+        c->occ.cap = value;
     } else if (k == "strip_rows") {
         if (value < 1) return set_err(RTO_E_INVALID, "strip_rows must be >= 1");
         c->strip_rows = value;
@@ -971,14 +1033,17 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
     const bool fast_here = tree->fast_ok && slots_fit_spp(tree->info.capacity * tree->dev.N3, o->spp);
     if (kernel == RTO_KERNEL_AUTO) kernel = fast_here ? RTO_KERNEL_FAST : RTO_KERNEL_GENERIC;
     if (kernel == RTO_KERNEL_FAST && !fast_here)
-        return set_err(RTO_E_UNSUPPORTED, "fast kernel needs an N == 2 tree of depth <= 24 whose leaf slots fit 32 - ceil(log2 spp) bits "
-                                          "(2^29 slots at spp <= 8, 2^27 at spp 32)");
+        return set_err(RTO_E_UNSUPPORTED, "fast kernel needs an N == 2 tree of depth <= 24 whose leaf slots fit 31 - ceil(log2 spp) bits "
+                                          "(2^28 slots at spp <= 8, 2^26 at spp 32: a hit entry is {valid bit, count - 1, slot})");
 
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");
     hipStream_t stream = (hipStream_t)stream_;
     if (kernel == RTO_KERNEL_FAST) {
         int rc = ensure_jump_table(ctx, stream);
+        if (rc != RTO_OK) return rc;
+    } else {
+        int rc = ensure_reference_arrays(tree);  // (a no-op unless the upload released them)
         if (rc != RTO_OK) return rc;
     }
 
@@ -1023,8 +1088,9 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");
     if (!tree->fast_ok || !slots_fit_spp(tree->info.capacity * tree->dev.N3, o->spp)) {
-        // No traversal image (N != 2, depth > 24, >= 2^29 leaf slots) or more slots than a hit-list entry can name at
-        // this SPP: the same frames, one launch of the generic kernel each -- same images, without the batching gain.
+        // No traversal image (N != 2, depth > 24, >= 2^29 leaf slots: the top-grid entry's budget) or more slots than a
+        // hit-list entry can name at this SPP (2^28 at spp <= 8, 2^26 at spp 32): the same frames, one launch of the
+        // generic kernel each -- same images, without the batching gain.
         if (tree->quant)
             return set_err(RTO_E_UNSUPPORTED, "a quantised tree kept quantised has too many leaf slots for the batched kernels at this spp");
         const rto::OptDev od = make_opt_dev(o);
@@ -1117,6 +1183,12 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     hipError_t e = rto::launch_render_batch(o->spp, tree->dev, od, fb, ctx->jump, ctx->queue,
                                             ctx->hits + (size_t)slot0 * o->spp * px,  // = fb.f[0].hits: the kernel indexes frames from here
                                             ctx->num_cus, ctx->refill, &ctx->occ, ev, stream);
+    if (e == hipErrorInvalidConfiguration)
+        return set_err(RTO_E_UNSUPPORTED, "batched render: the traversal kernel needs (max_depth + 1 - top_levels + spp + 1) KB of LDS for its "
+                                          "ancestor stack and thresholds plus 96 B per frame -- depth " + std::to_string(tree->dev.max_depth) +
+                                          " at spp " + std::to_string(o->spp) + " with " + std::to_string(n) +
+                                          " frames exceeds what the device grants a workgroup; render fewer samples per launch or "
+                                          "frame by frame with the generic kernel (rto_ctx_set_kernel)");
     if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("batched render launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
 }

@@ -101,19 +101,43 @@ int rto_guidance_net_forward_ex(const rto_guidance_net* net, void* stream, const
     return RTO_OK;
 }
 
+// grows the scratch of the packed route to n x H x W pixels.  Growing frees the old buffer, which earlier work may still
+// read: that is the one place this file synchronises -- callers that must stay asynchronous reserve up front.
+static int reserve_packed(rto_guidance_net* net, int n, int H, int W) {
+    const size_t need = (size_t)n * H * W * 16;
+    if (need <= net->packed_bytes) return RTO_OK;
+    if (net->packed) {
+        if (hipDeviceSynchronize() != hipSuccess || hipFree(net->packed) != hipSuccess) return fail(RTO_E_HIP, "hipFree failed");
+        net->packed = nullptr;
+        net->packed_bytes = 0;
+        net->packed_n = 0;
+    }
+    if (hipMalloc(&net->packed, need) != hipSuccess) return fail(RTO_E_HIP, "hipMalloc(packed maps) failed");
+    net->packed_bytes = need;
+    return RTO_OK;
+}
+
+static int pointer_device(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return a.device;
+}
+
+int rto_guidance_net_reserve(rto_guidance_net* net, int n, int H, int W) {
+    if (!net || n < 1 || H < 1 || W < 1) return fail(RTO_E_INVALID, "rto_guidance_net_reserve: bad argument");
+    DeviceScope scope(net->device);
+    return reserve_packed(net, n, H, W);
+}
+
 int rto_guidance_net_forward_packed(rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W, int flags) {
     if (!net || !aux || n < 1 || H < 1 || W < 1) return fail(RTO_E_INVALID, "rto_guidance_net_forward_packed: bad argument");
+    if (pointer_device(aux) != net->device)
+        return fail(RTO_E_INVALID, "rto_guidance_net_forward_packed: aux is not memory of the network's device");
     DeviceScope scope(net->device);
-    const size_t need = (size_t)n * H * W * 16;
-    if (need > net->packed_bytes) {  // grow the scratch (first use or a larger batch); earlier work may still read it
-        if (net->packed) {
-            if (hipDeviceSynchronize() != hipSuccess || hipFree(net->packed) != hipSuccess) return fail(RTO_E_HIP, "hipFree failed");
-            net->packed = nullptr;
-            net->packed_bytes = 0;
-        }
-        if (hipMalloc(&net->packed, need) != hipSuccess) return fail(RTO_E_HIP, "hipMalloc(packed maps) failed");
-        net->packed_bytes = need;
-    }
+    if (const int rc = reserve_packed(net, n, H, W)) return rc;
     const hipError_t e = rto::launch_guidance_net(aux, net->w1, net->w2, net->b2, net->c1, net->levels, n, H, W,
                                                   (float*)net->packed, nullptr, (flags & RTO_NET_AUX_SQUARES_IMPLIED) != 0,
                                                   (hipStream_t)stream);
@@ -124,9 +148,17 @@ int rto_guidance_net_forward_packed(rto_guidance_net* net, void* stream, const f
     return RTO_OK;
 }
 
-int rto_filtering_packed(const rto_guidance_net* net, void* stream, const float* img_in, float* img_out) {
+int rto_filtering_packed(const rto_guidance_net* net, void* stream, const float* img_in, float* img_out, int n, int H, int W) {
     if (!net || !img_in || !img_out || img_in == img_out) return fail(RTO_E_INVALID, "rto_filtering_packed: bad argument");
     if (!net->packed || net->packed_n < 1) return fail(RTO_E_INVALID, "rto_filtering_packed: no packed maps (call rto_guidance_net_forward_packed first)");
+    // the images are the caller's: their extent must be the one the maps were computed for, or the kernel would read and
+    // write past a smaller buffer
+    if (n != net->packed_n || H != net->packed_h || W != net->packed_w)
+        return fail(RTO_E_INVALID, "rto_filtering_packed: " + std::to_string(n) + " x " + std::to_string(H) + " x " + std::to_string(W) +
+                                       " images, but the packed maps hold " + std::to_string(net->packed_n) + " x " +
+                                       std::to_string(net->packed_h) + " x " + std::to_string(net->packed_w));
+    if (pointer_device(img_out) != net->device || pointer_device(img_in) != net->device)
+        return fail(RTO_E_INVALID, "rto_filtering_packed: the images are not memory of the network's device");
     DeviceScope scope(net->device);
     const hipError_t e = rto::launch_filter_fast_packed(net->packed, net->packed_h, net->packed_w, net->packed_n, img_in, img_out,
                                                         (hipStream_t)stream);

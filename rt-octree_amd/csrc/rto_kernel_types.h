@@ -45,9 +45,10 @@ struct TreeDev {
     // above level G costs this one 8-byte, L2-resident load.  nullptr / 0 when absent.
     const uint2* topgrid;
     int top_levels;
-    // Aligned copy of the SH coefficients for shading (dense SH9 / SH16 / SH25 trees, N == 2): per slot the 3 B
-    // coefficients in data[]'s order, padded to a multiple of 32 B (64 / 96 / 160 B) so that a record is fetched by
-    // 16-byte loads from sectors of its own; nullptr when absent (shading then reads data[]).
+    // Aligned copy of the SH coefficients for shading (dense SH9 / SH16 trees, N == 2; SH25 gains nothing from it and
+    // keeps data[]): per slot the 3 B coefficients in data[]'s order, zero-padded to 64 B (SH9) / 128 B (SH16) so that
+    // a record is ONE 128-byte line fetched by 16-byte loads; nullptr when absent (shading then reads data[]).  When it
+    // exists the host releases `data` and `child` after the upload (both nullptr until the generic kernel asks for them).
     const uint16_t* shrec;
     // Quantised tree rendered WITHOUT expansion (the inputs of n3tree.cpp:279-340):
     // `data` is nullptr; per leaf slot one record of q_rec u16 values, `qrec[slot * q_rec + ...]`:

@@ -13,6 +13,9 @@ hipError_t launch_build_nodew(const int32_t* child, const uint16_t* data, int64_
 
 // aligned copy of the SH coefficients (TreeDev::shrec): `rec` halves per slot = shrec_halves(basis_dim)
 hipError_t launch_build_shrec(const uint16_t* data, int64_t n_slots, int data_dim, int rec, uint16_t* out, hipStream_t stream);
+// child[] / data[] (reference layout) rebuilt from the traversal image and the aligned coefficient copy
+hipError_t launch_rebuild_reference(const uint16_t* shrec, const uint32_t* nodew, int64_t n_slots, int data_dim, int rec,
+                                    uint16_t* data, int32_t* child, hipStream_t stream);
 
 // top-of-tree shortcut grid: 2^(3G) entries (TreeDev::topgrid)
 hipError_t launch_build_topgrid(const uint32_t* nodew, int G, uint2* grid, hipStream_t stream);
@@ -32,6 +35,7 @@ struct OccupancyCache {
     const void* fn = nullptr;
     size_t lds = 0;
     int blocks_per_cu = 0;
+    int cap = 0;  // tuning ("blocks_per_cu"): launch at most this many workgroups per CU (0 = what fits)
 };
 
 // persistent batched renderer (N == 2 trees): fb.n frames in one launch (traversal kernel, then the

@@ -206,6 +206,11 @@ class FusedGuidanceNet:
                                                 1 if squares_implied else 0))
         return wm, gm
 
+    def reserve(self, n, H, W):
+        """size the packed-map scratch up front (growing it later synchronises the device once)"""
+        from ._lib import check, lib
+        check(lib().rto_guidance_net_reserve(self._h, int(n), int(H), int(W)))
+
     def forward_packed(self, aux, stream=None, squares_implied=False):
         """the network, its 8 fp16 output channels kept packed in the handle's scratch (rto_guidance_net_forward_packed)"""
         from ._lib import check, lib
@@ -213,12 +218,15 @@ class FusedGuidanceNet:
         assert c == 8 and aux.dtype == torch.float32 and aux.is_contiguous()
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
         check(lib().rto_guidance_net_forward_packed(self._h, V._stream_ptr(s), aux.data_ptr(), n, H, W, 1 if squares_implied else 0))
+        self._packed_shape = (n, H, W)
 
-    def filter_packed(self, img_in, img_out, stream=None):
-        """factorised filter on the packed maps of the last forward_packed: img_in / img_out device pointers or tensors"""
+    def filter_packed(self, img_in, img_out, stream=None, shape=None):
+        """factorised filter on the packed maps of the last forward_packed: img_in / img_out device pointers or tensors
+        of `shape` = (n, H, W) images (default: the extent of that forward; the library refuses any other)"""
         from ._lib import check, lib
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
-        check(lib().rto_filtering_packed(self._h, V._stream_ptr(s), V._dev_ptr(img_in), V._dev_ptr(img_out)))
+        n, H, W = shape if shape is not None else self._packed_shape
+        check(lib().rto_filtering_packed(self._h, V._stream_ptr(s), V._dev_ptr(img_in), V._dev_ptr(img_out), int(n), int(H), int(W)))
 
     def __del__(self):
         try:

@@ -150,24 +150,48 @@ def test_batched_path_on_shallow_and_deep_trees(depth, basis):
 
 
 @pytest.mark.parametrize("basis", [9, 16])
-def test_shading_from_the_aligned_copy_and_from_data_agree(basis, monkeypatch):
+def test_shading_from_the_aligned_copy_and_from_data_agree(basis):
     """dense SH9 / SH16 trees are shaded from an aligned copy of their coefficients (TreeDev::shrec); with the copy
-    switched off (RTO_NO_SHREC; RTO_TREE_COMPACT for files) the kernels read the 2-byte-aligned records of data[] --
-    same fp16 values, same pixels"""
+    switched off (RTO_TREE_COMPACT) the kernels read the 2-byte-aligned records of data[] -- same fp16 values, same
+    pixels.  With the copy the reference-layout arrays are released after the upload (RTO_TREE_KEEP_REFERENCE keeps
+    them): the footprint is the padded copy + the traversal image, not data + copy."""
     tree = synth.make_tree(depth_limit=5, basis_dim=basis, seed=basis)
     ht, dt = make_pair(tree)
-    assert dt.device_bytes > tree.data.nbytes * 1.9  # data + the padded copy
-    monkeypatch.setenv("RTO_NO_SHREC", "1")
-    _, dt_plain = make_pair(tree)
-    monkeypatch.delenv("RTO_NO_SHREC")
-    assert dt_plain.device_bytes < dt.device_bytes
+    dt_keep = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format, keep_reference=True)
+    dt_plain = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format, compact=True)
+    assert dt_keep.device_bytes > tree.data.nbytes * 1.9  # data + the padded copy
+    assert dt.device_bytes < dt_keep.device_bytes - tree.data.nbytes * 0.99  # data[] and child[] released
+    assert dt_plain.device_bytes < dt_keep.device_bytes
     ocam, cam = cameras(64, 48, POSES[1])
     want = oracle_frame(ht, ocam, 6, frame=2)[0]
-    for t in (dt, dt_plain):
+    for t in (dt, dt_keep, dt_plain):
         assert_bits_equal(hip_frame(t, cam, 6, frame=2, kernel=R.KERNEL_FAST)[0], want, "single frame")
         ctx = R.RenderContext(64, 48, frames=1)
         R.launch_renderer_batch(t, [cam], R.RenderOptions(spp=6, denoise=False), ctx, rng_jumps=[2])
         assert_bits_equal(ctx.download_aux(), want, "batched")
+
+
+@pytest.mark.parametrize("basis", [9, 16])
+def test_generic_kernel_on_a_tree_without_reference_arrays(basis):
+    """the generic kernel (root-restart float descent over child[] / data[], the plain statement of the reference) on a
+    tree whose upload released those arrays: they are rebuilt from the traversal image + the aligned copy on first
+    use -- same leaf values, so the oracle's pixels -- and the footprint grows by exactly what was released"""
+    tree = synth.make_tree(depth_limit=6, basis_dim=basis, seed=40 + basis)
+    ht, dt = make_pair(tree)
+    before = dt.device_bytes
+    ocam, cam = cameras(72, 56, POSES[2])
+    want = oracle_frame(ht, ocam, 4, frame=3)
+    aux_f, rgba_f, ctx = hip_frame(dt, cam, 4, frame=3, kernel=R.KERNEL_FAST)
+    dt._refresh()
+    assert dt.device_bytes == before  # the fast kernel needed nothing back
+    aux_g, rgba_g, _ = hip_frame(dt, cam, 4, frame=3, kernel=R.KERNEL_GENERIC, ctx=ctx)
+    dt._refresh()
+    assert dt.device_bytes >= before + tree.data.nbytes + tree.child.nbytes
+    for a in (aux_f, aux_g):
+        assert_bits_equal(a, want[0], "aux")
+    assert_bits_equal(rgba_g, want[1], "rgba")
+    aux_f2, _, _ = hip_frame(dt, cam, 4, frame=3, kernel=R.KERNEL_FAST, ctx=ctx)  # and the fast kernel still renders
+    assert_bits_equal(aux_f2, want[0], "fast after the rebuild")
 
 
 def test_camera_inside_box_and_miss(small_tree_sh9):

@@ -30,7 +30,12 @@ Rank 0 prints ONE JSON line (contract in the task statement) with these extra ob
                     kernel's L1 line accesses to the gather ceilings measured by tools/probe_ceiling.py --
                     the resource that actually bounds it.
   reference_loop -- the reference's own loop shape: ONE frame per launch with a host synchronisation per
-                    frame (Timer::record, render_context.hpp:179-188), single-frame kernel.
+                    frame (Timer::record, render_context.hpp:179-188), single-frame kernel; `pipelined` = the same
+                    per-frame operator calls with --ref-loop-inflight frames in flight (frame i+1 is launched before
+                    the host waits for frame i), wall-clock frames/s.
+  parity_spot    -- untimed: pixels of frames of the LAST TIMED launch group compared bit for bit with the CPU oracle
+                    (the checker, oracle/): a line can never be fast and wrong.
+  value_exact    -- the same frames timed once more through the bit-exact route (exact filter, fp32 maps).
   cpu_baseline   -- the CPU oracle (oracle/, kind "port": the reference has no CPU renderer) on a
                     bounded sample of the same frames, all host cores.
 """
@@ -75,6 +80,10 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores)")
     ap.add_argument("--ref-loop-frames", type=int, default=48,
                     help="frames of the one-frame-per-launch pass reported as reference_loop (0 = skip)")
+    ap.add_argument("--ref-loop-inflight", type=int, default=4,
+                    help="frames in flight in the pipelined variant of the reference loop (1 = skip it)")
+    ap.add_argument("--spot-pixels", type=int, default=64, help="oracle spot pixels per checked frame of the last timed group (0 = skip)")
+    ap.add_argument("--no-exact-pass", action="store_true", help="skip the second timed pass through the bit-exact filter route")
     ap.add_argument("--tree", default="", help="render this tree.npz instead of the synthetic one")
     ap.add_argument("--shuffle-nodes", type=int, default=0, metavar="SEED",
                     help="store the synthetic tree's nodes in a random order (seed > 0): svox-refined trees have no "
@@ -120,12 +129,29 @@ def tree_cache_path(args, scene=0):
 
 
 def workload_id(args, W, H):
-    """key into profiles/pmc_traffic.json: the BASELINE configurations the counter passes were taken on"""
+    """key into profiles/pmc_traffic.json: the BASELINE configurations the counter passes were taken on.  None for
+    anything the committed counters do not describe: another scene or tree, development tuning, another library
+    build (RTO_LIB), more than one stream."""
     if args.tree or args.shuffle_nodes or args.scenes != 1 or args.quant_direct or args.shell != 2.5:
+        return None
+    if args.tuning or os.environ.get("RTO_LIB") or args.streams != 1:
         return None
     key = (W, H, args.spp, args.basis, args.depth, bool(args.no_denoise), args.radius, args.fx, args.cam_radius)
     return {(800, 800, 6, 16, 10, False, 1.5, 0.0, 4.0311): "c2", (800, 800, 1, 16, 10, True, 1.5, 0.0, 4.0311): "c5",
             (1920, 1080, 6, 25, 10, False, 1.12, 1160.0, 2.6): "c4"}.get(key)
+
+
+KERNEL_SOURCES = ("render_kernels.hip", "rto_kernel_types.h", "rto_device_math.h", "rto_launch.h")
+
+
+def kernel_code_id():
+    """identity of the traversal kernel's code: sha256 over the sources it is compiled from (what the counter passes in
+    profiles/pmc_traffic.json are tied to -- tools/pmc_traffic.py stores the same value)"""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "rt-octree_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 # BASELINE.json configs[3] (TanksAndTemple Truck 1920x1080 SPP 6 + denoise) as a synthetic stand-in: SH25, a tree
@@ -312,11 +338,11 @@ def main():
     def frame_of(step, scene_map):  # (scene, pose) of this rank's `step`-th frame
         return pose_schedule(step, rank, world, len(poses), n_scenes, scene_map)
 
-    def group(scene, idx, ev, lane=0):
+    def group(scene, idx, ev, lane=0, exact=False):
         """The frames `idx` (poses of one scene): traversal + shading, GuidanceNet, filter; all asynchronous
         on the lane's stream, no host sync (the reference synchronises once per frame,
         render_context.hpp:179-188).  Frame i of the reference run uses the RNG advanced (100 + i) times
-        (SURVEY 8e)."""
+        (SURVEY 8e).  exact: the bit-exact denoise route (fp32 maps + exact filter) whatever the command line says."""
         n = len(idx)
         lctx, lstream, lnet, laux = lanes[lane]
         lctx.rng_seed()
@@ -328,34 +354,34 @@ def main():
             ev[1].record(lstream)
         if denoise:
             lctx.select_frame(0)
-            if packed_route:  # GuidanceNet -> fp16 maps in the handle's scratch -> factorised filter
+            if packed_route and not exact:  # GuidanceNet -> fp16 maps in the handle's scratch -> factorised filter
                 lnet.forward_packed(laux[:n], stream=lstream, squares_implied=True)
                 if ev:
                     ev[2].record(lstream)
-                lnet.filter_packed(lctx.noisy_ptr, lctx.image_ptr, stream=lstream)
+                lnet.filter_packed(lctx.noisy_ptr, lctx.image_ptr, stream=lstream, shape=(n, H, W))
             else:
                 with torch.no_grad(), torch.cuda.stream(lstream):
                     wm, gm = lnet(laux[:n], stream=lstream, squares_implied=True) if not args.torch_net else lnet(laux[:n])
                 if ev:
                     ev[2].record(lstream)
-                R.filtering(lstream, wm, gm, lctx.noisy_ptr, lctx.image_ptr, mode=filter_mode)
+                R.filtering(lstream, wm, gm, lctx.noisy_ptr, lctx.image_ptr, mode=R.FILTER_EXACT if exact else filter_mode)
             if ev:
                 ev[3].record(lstream)
 
     def plan(n_frames, scene_map):
         return plan_groups(n_frames, B, rank, world, len(poses), n_scenes, scene_map)
 
-    def timed(scene_map):
+    def timed(scene_map, exact=False):
         warm, work = plan(args.warmup * B, scene_map), plan(n_frames, scene_map)
         events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in work]
         if work:  # allocation pass (untimed, whatever --warmup is): every lane sees the largest group once, so no
             # buffer of the library or of torch's allocator is created inside the timed region
             big = max(work, key=lambda g: len(g[1]))
             for ln in range(len(lanes)):
-                group(big[0], big[1], None, ln)
+                group(big[0], big[1], None, ln, exact)
             torch.cuda.synchronize(dev)
         for g, (sc, idx) in enumerate(warm):
-            group(sc, idx, None, g % len(lanes))
+            group(sc, idx, None, g % len(lanes), exact)
         torch.cuda.synchronize(dev)
         for lc, _, _, _ in lanes:
             lc.kernel_timing(True)
@@ -363,7 +389,7 @@ def main():
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for g, (sc, idx) in enumerate(work):
-            group(sc, idx, events[g], g % len(lanes))
+            group(sc, idx, events[g], g % len(lanes), exact)
         torch.cuda.synchronize(dev)
         barrier()
         elapsed = time.perf_counter() - t0
@@ -376,6 +402,7 @@ def main():
             lc.kernel_timing(False)
         n_launch = max(sum(k["launches"] for k in kts), 1)  # per-launch means, weighted over the lanes
         kt = {"launches": sum(k["launches"] for k in kts),
+              "raygen_ms": sum(k["raygen_ms"] * k["launches"] for k in kts) / n_launch,
               "traverse_ms": sum(k["traverse_ms"] * k["launches"] for k in kts) / n_launch,
               "shade_ms": sum(k["shade_ms"] * k["launches"] for k in kts) / n_launch}
         # Timer::report formula (render_context.hpp:190-206), per frame, from the per-group event pairs
@@ -384,45 +411,83 @@ def main():
         filter_ms = sum(e[2].elapsed_time(e[3]) for e in events) / n_frames if denoise else 0.0
         all_ms = render_ms + torch_ms + filter_ms
         return elapsed, kt, {"render_ms": render_ms, "torch_ms": torch_ms, "filter_ms": filter_ms,
-                             "fps": 1000.0 / all_ms if all_ms > 0 else 0.0, "frames": n_frames}
+                             "fps": 1000.0 / all_ms if all_ms > 0 else 0.0, "frames": n_frames}, work
 
     # ---------------- warm-up + timed region(s) ----------------
-    elapsed, kt, tstats = timed(maps[0])
+    if denoise and not args.torch_net:
+        for _, _, lnet, _ in lanes:  # the packed-map scratch at its final size: no allocation (= device sync) in a timed region
+            lnet.reserve(B, H, W)
+    elapsed, kt, tstats, work = timed(maps[0])
     alt = None
     if len(maps) > 1:
-        e2, _, t2 = timed(maps[1])
+        e2, _, t2, _ = timed(maps[1])
         alt = {"scene_map": maps[1], "value": n_frames * world / e2, "ms_per_step": e2 / args.steps * 1e3,
                "reference_timer_fps": t2["fps"]}
+    # the same frames once more through the bit-exact route (exact filter on fp32 maps): VERDICT r2 task 3
+    exact_pass = None
+    if denoise and not args.no_exact_pass and not args.exact_filter and not args.torch_net:
+        e3, _, t3, _ = timed(maps[0], exact=True)
+        exact_pass = {"value": n_frames * world / e3, "ms_per_step": e3 / args.steps * 1e3, "reference_timer": t3,
+                      "route": "fused GuidanceNet -> fp32 weight / guidance planes -> filter_fused (bit-identical to the CPU oracle's filter)"}
+        group(work[-1][0], work[-1][1], None, (len(work) - 1) % len(lanes))  # leave the headline route's frames in the buffers
+        torch.cuda.synchronize(dev)
+    last_group, last_lane = work[-1], (len(work) - 1) % len(lanes)
 
     # ---------------- untimed: the reference's loop shape (one frame per launch, sync per frame) ----------------
+    # frames of the last timed launch group, kept for the oracle spot check below (later passes reuse the buffers)
+    spot_frames = []
+    if world == 1 and args.spot_pixels > 0 and not args.quant_direct and not args.tree:
+        lctx = lanes[last_lane][0]
+        nlast = len(last_group[1])
+        for slot in sorted({0, nlast // 2, nlast - 1}):
+            lctx.select_frame(slot)
+            spot_frames.append((last_group[0], last_group[1][slot], lctx.download_aux(stream=lanes[last_lane][1])))
+        lctx.select_frame(0)
+
     ref_loop = None
     if args.ref_loop_frames > 0 and not args.quant_direct:
         nf = args.ref_loop_frames
+
+        def one_frame(lctx, lstream, lnet, laux, sc, i, evs=None):
+            """the reference's loop body (main_headless.cpp:485-543) for pose i: per-frame operator calls only"""
+            lctx.rng_seed()
+            lctx.rng_advance((WARM_FRAMES_REF + i) << 32)
+            if evs:
+                evs[0].record(lstream)
+            R.launch_renderer(trees[sc], cams[i], opt, lctx, lstream)
+            if evs:
+                evs[1].record(lstream)
+            if denoise:
+                lctx.select_frame(0)
+                if packed_route:
+                    lnet.forward_packed(laux[:1], stream=lstream, squares_implied=True)
+                    if evs:
+                        evs[2].record(lstream)
+                    lnet.filter_packed(lctx.noisy_ptr, lctx.image_ptr, stream=lstream, shape=(1, H, W))
+                else:
+                    with torch.no_grad(), torch.cuda.stream(lstream):
+                        wm, gm = lnet(laux[:1], stream=lstream, squares_implied=True) if not args.torch_net else lnet(laux[:1])
+                    if evs:
+                        evs[2].record(lstream)
+                    R.filtering(lstream, wm, gm, lctx.noisy_ptr, lctx.image_ptr, mode=filter_mode)
+                if evs:
+                    evs[3].record(lstream)
+
+        def lane_net():
+            if not denoise:
+                return None
+            return compact.half().to(dev) if args.torch_net else denoiser.FusedGuidanceNet(compact, device=local_rank)
+
         one = R.RenderContext(W, H, device=local_rank, frames=1)
         one_aux = torch.as_tensor(one.batch_views()[0], device=dev)
+        one_net = lane_net()
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         sums = [0.0, 0.0, 0.0]
         t_wall = 0.0
         for k in range(-8, nf):  # 8 untimed warm-up frames
             sc, i = frame_of(max(k, 0), maps[0])
             t1 = time.perf_counter()
-            one.rng_seed()
-            one.rng_advance((WARM_FRAMES_REF + i) << 32)
-            evs[0].record(stream)
-            R.launch_renderer(trees[sc], cams[i], opt, one, stream)
-            evs[1].record(stream)
-            if denoise:
-                one.select_frame(0)
-                if packed_route:
-                    net.forward_packed(one_aux[:1], stream=stream, squares_implied=True)
-                    evs[2].record(stream)
-                    net.filter_packed(one.noisy_ptr, one.image_ptr, stream=stream)
-                else:
-                    with torch.no_grad():
-                        wm, gm = net(one_aux[:1], stream=stream, squares_implied=True) if not args.torch_net else net(one_aux[:1])
-                    evs[2].record(stream)
-                    R.filtering(stream, wm, gm, one.noisy_ptr, one.image_ptr, mode=filter_mode)
-                evs[3].record(stream)
+            one_frame(one, stream, one_net, one_aux, sc, i, evs)
             (evs[3] if denoise else evs[1]).synchronize()  # Timer::record: the host waits for every frame
             if k >= 0:
                 t_wall += time.perf_counter() - t1
@@ -431,11 +496,50 @@ def main():
                     sums[1] += evs[1].elapsed_time(evs[2])
                     sums[2] += evs[2].elapsed_time(evs[3])
         tot = sum(sums)
+        seq_last = one.download_image()
         ref_loop = {"batch": 1, "frames": nf, "fps": 1000.0 * nf / tot if tot > 0 else 0.0,
                     "render_ms": sums[0] / nf, "torch_ms": sums[1] / nf, "filter_ms": sums[2] / nf,
                     "wall_fps": nf / t_wall if t_wall > 0 else 0.0,
                     "note": "one rto_launch_renderer (single-frame kernel) + GuidanceNet + filter per frame, host waits for each "
-                            "frame like Timer::record (render_context.hpp:179-188); fps = 1000 / (render + torch + filter)"}
+                            "frame like Timer::record (render_context.hpp:179-188); fps = 1000 / (render + torch + filter) from "
+                            "the per-frame event pairs, wall_fps = frames / host wall clock of the same loop"}
+        # The same per-frame operator calls, software-pipelined: frame k is launched on lane k mod D (its own context and
+        # stream) BEFORE the host waits for frame k - D + 1 -- still one launch and one host wait per frame, but the
+        # tail of a frame (a handful of long rays on an otherwise empty chip) overlaps the next frames' heads.
+        D = max(1, min(8, args.ref_loop_inflight))
+        if D > 1:
+            plane = [(one, stream, one_net, one_aux)]
+            for _ in range(1, D):
+                c2 = R.RenderContext(W, H, device=local_rank, frames=1)
+                plane.append((c2, torch.cuda.Stream(dev), lane_net(), torch.as_tensor(c2.batch_views()[0], device=dev)))
+            done = [torch.cuda.Event() for _ in range(D)]
+            npipe = max(nf, 4 * D)
+            t0p = None
+            for k in range(-2 * D, npipe):
+                if k == 0:
+                    torch.cuda.synchronize(dev)
+                    t0p = time.perf_counter()
+                ln = k % D
+                if k >= -D:
+                    done[ln].synchronize()  # the host waits for the frame this lane rendered D frames ago
+                sc, i = frame_of(max(k, 0) % max(nf, 1), maps[0])
+                lc, ls, lnn, la = plane[ln]
+                one_frame(lc, ls, lnn, la, sc, i)
+                done[ln].record(ls)
+            torch.cuda.synchronize(dev)
+            wall = time.perf_counter() - t0p
+            last_ln = (npipe - 1) % D
+            _, i_last = frame_of((npipe - 1) % max(nf, 1), maps[0])
+            _, i_seq = frame_of(nf - 1, maps[0])
+            same = None
+            if i_last == i_seq:
+                same = bool(np.array_equal(plane[last_ln][0].download_image().view(np.uint32), seq_last.view(np.uint32)))
+            ref_loop["pipelined"] = {"frames_in_flight": D, "frames": npipe, "wall_fps": npipe / wall,
+                                     "last_frame_bit_identical_to_the_sequential_loop": same,
+                                     "note": "same operator calls per frame; lane k mod D = its own context + stream; the host waits for "
+                                             "frame k - D before launching frame k"}
+            for c2, _, _, _ in plane[1:]:
+                c2.free()
         one.free()
 
     # ---------------- untimed: work units of the same frames -> algorithmic bytes ----------------
@@ -469,30 +573,45 @@ def main():
     # counter passes of THIS workload committed under profiles/ (tools/profile_round.sh); bytes and L1 line
     # accesses scale with the frames of a launch
     traffic = tcp = traffic_src = valu = None
+    traffic_stale = None
+    code_id = kernel_code_id()
     wid = workload_id(args, W, H)
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if wid and os.path.exists(pmc_path):
         try:
             doc = json.load(open(pmc_path))
             pj = doc.get("workloads", {}).get(wid)
-            if pj:
+            # the counters describe ONE build of the kernel: a run of other code must not wear them (VERDICT r2 task 7)
+            traffic_stale = bool(pj) and pj.get("kernel_code_id") != code_id
+            if pj and not traffic_stale:
                 scale = frames_per_launch / float(pj["frames_per_launch"])
                 traffic = (pj["fetch_bytes"] + pj["write_bytes"]) * scale
-                traffic_src = pj.get("source")
-                if pj.get("valu_insts") and pj.get("kernel_clocks"):
+                traffic_src = "%s; counters of kernel code %s" % (pj.get("source"), pj.get("kernel_code_id"))
+                vc = doc.get("valu_ceiling") or {}
+                if pj.get("valu_insts") and pj.get("kernel_clocks") and vc.get("traversal_mix_insts_per_clk_per_simd"):
                     simds = float(pj.get("cus", 256)) * 4.0
+                    rate = pj["valu_insts"] / simds / pj["kernel_clocks"]
+                    ceil = vc["traversal_mix_insts_per_clk_per_simd"]
                     valu = {"wave_insts_per_launch": pj["valu_insts"] * scale,
-                            "insts_per_clk_per_simd": pj["valu_insts"] / simds / pj["kernel_clocks"],
-                            "peak_insts_per_clk_per_simd": 0.25,
-                            "frac": pj["valu_insts"] * 4.0 / simds / pj["kernel_clocks"],
-                            "busy_frac": (pj.get("valu_active_quads") or 0.0) * 4.0 / simds / pj["kernel_clocks"],
-                            "note": "a CDNA4 SIMD issues one wave64 VALU instruction per 4 clocks: frac = SQ_INSTS_VALU x 4 / "
-                                    "(SIMDs x kernel clocks), busy_frac the same from SQ_ACTIVE_INST_VALU (quad-cycles), "
-                                    "both from the committed counter passes of this workload"}
+                            "salu_insts_per_launch": (pj.get("salu_insts") or 0.0) * scale,
+                            "insts_per_clk_per_simd": rate,
+                            "salu_insts_per_clk_per_simd": (pj.get("salu_insts") or 0.0) / simds / pj["kernel_clocks"],
+                            "ceiling_insts_per_clk_per_simd": ceil, "frac": rate / ceil,
+                            "full_rate_opcode_ceiling": vc.get("full_rate_insts_per_clk_per_simd"),
+                            "half_rate_opcode_ceiling": vc.get("half_rate_insts_per_clk_per_simd"),
+                            "wait_any_frac": pj.get("wait_any_frac"), "wait_inst_any_frac": pj.get("wait_inst_any_frac"),
+                            "active_inst_any_frac": pj.get("active_inst_any_frac"),
+                            "lanes_per_valu_inst": pj.get("lanes_per_valu_inst"),
+                            "note": "frac = SQ_INSTS_VALU / (SIMDs x kernel clocks) over the rate the traversal's opcode mix sustains "
+                                    "at 8 waves per SIMD with no memory in the way (profiles/r3_valu_calibration.json: asm probe, "
+                                    "counters on the probe itself; the traversal loop with its gathers stubbed reaches the same 0.29). "
+                                    "A SIMD issues ~0.45 instructions per clock in all: plain add / mul / fma / logic opcodes at "
+                                    "0.41-0.45, every other VALU opcode (3-operand, shifts left, min / max, conversions, compares, "
+                                    "packed, SGPR operand) at 0.235-0.245, SALU instructions out of the same budget"}
                 ce = doc.get("ceilings")
                 if pj.get("tcp_line_accesses") and ce:
                     cus = float(pj.get("cus", 256))
-                    clk = pj["kernel_clocks"]  # shader clocks of the profiled launch (GRBM_GUI_ACTIVE / XCDs)
+                    clk = pj["kernel_clocks"]  # shader clocks of the profiled launch
                     lines = pj["tcp_line_accesses"] / cus
                     l1_miss = pj["tcp_tcc_read_req"] / cus
                     l2_miss = l1_miss * pj["tcc_miss"] / max(pj["tcc_hit"] + pj["tcc_miss"], 1)
@@ -507,11 +626,10 @@ def main():
                            "l2_hit_rate": 1.0 - l2_miss / max(l1_miss, 1.0),
                            "ceilings_lines_per_clk_per_cu": ce, "frac": model_clk / clk, "frac_lower": lower,
                            "note": "frac = (L1-hit lines / ceiling + L2-served lines / ceiling + lines from beyond L2 / ceiling) / "
-                                   "kernel clocks: the share of the kernel its L1s need for the gathers at the rates "
-                                   "tools/probe_ceiling.py measured for DEPENDENT scattered dword loads, the traversal's shape "
-                                   "(profiles/r2_probe_ceiling.json); the three classes overlap a little in the real kernel, so "
-                                   "values around 1 mean: at that ceiling.  frac_lower prices the same lines at the rates of "
-                                   "four independent gathers in flight per wave -- rates no dependent walk can reach."}
+                                   "kernel clocks, at the rates tools/probe_ceiling.py measured for DEPENDENT scattered dword loads, "
+                                   "the traversal's shape (profiles/r2_probe_ceiling.json: one gather in flight per wave, so these are "
+                                   "latency-bound concurrency figures at 6 waves per SIMD, not the L1's throughput limit); frac_lower "
+                                   "prices the same lines at the rates of four independent gathers in flight per wave."}
         except Exception as e:  # a malformed profile must not break the bench line
             print("[bench] ignoring %s: %r" % (pmc_path, e), file=sys.stderr)
             traffic = tcp = valu = None
@@ -583,6 +701,38 @@ def main():
                "render_s_per_frame": t_render / args.cpu_frames, "net_s_per_frame": t_net / args.cpu_frames,
                "filter_s_per_frame": t_filter / args.cpu_frames, "steps_per_frame": cpu_steps / args.cpu_frames}
 
+    # ---------------- parity spot check (untimed): pixels of the last timed launch group vs the CPU oracle ----------------
+    parity = None
+    if spot_frames:
+        import ctypes as C
+
+        import orc
+        zs = {}
+        checked = mismatched = hit = 0
+        rs = np.random.RandomState(12345)
+        for sc, i, aux in spot_frames:
+            if sc not in zs:
+                z = np.load(paths[sc])
+                zs[sc] = orc.HostTree(z["child"], z["data"], z["invradius3"], z["offset"], str(z["data_format"]))
+            ocam = orc.camera(W, H, fx, fx, np.ascontiguousarray(poses[i][:3, :4].T, np.float32).reshape(-1))
+            oopt = orc.default_options(spp=args.spp, denoise=int(denoise))
+            base = orc.rng(frame=WARM_FRAMES_REF + i)
+            for idx in list(rs.randint(0, W * H, args.spot_pixels)) + [0, W * H - 1, (H // 2) * W + W // 2]:
+                a8, px4 = (C.c_float * 8)(), (C.c_float * 4)()
+                orc.lib().orc_render_pixel(C.byref(zs[sc].c), C.byref(ocam), C.byref(oopt), C.byref(base), int(idx), a8, px4, None)
+                y, x = divmod(int(idx), W)
+                same = np.array_equal(np.array(a8[:], np.float32).view(np.uint32), aux[:, y, x].view(np.uint32))
+                checked += 1
+                mismatched += 0 if same else 1
+                hit += 1 if a8[3] > 0 else 0
+        parity = {"pixels_checked": checked, "mismatches": mismatched, "pixels_with_hits": hit,
+                  "frames": [[sc, i] for sc, i, _ in spot_frames],
+                  "what": "8 aux planes (fp32 bits) of random pixels + corners + centre of frames of the LAST TIMED launch group "
+                          "against oracle/'s render_kernel + trace_ray for that pixel (orc_render_pixel); the oracle is the "
+                          "checker here, never the thing measured"}
+        if mismatched:
+            print("[bench] PARITY FAILURE: %d of %d spot pixels differ from the oracle" % (mismatched, checked), file=sys.stderr)
+
     # ---------------- PSNR (untimed, pose 0): SPP-6 raw / denoised vs a high-SPP reference ----------------
     psnr = None
     if args.psnr_frames > 0:
@@ -608,11 +758,19 @@ def main():
                 wm, gm = net(aux_t[:1])
             R.filtering(stream, wm, gm, ctx.noisy_ptr, ctx.image_ptr, mode=R.FILTER_EXACT)
             exact = ctx.download_image()
+            exact8 = ctx.download_rgba8()
             psnr["denoised_db"] = _psnr(exact, ref_img)
             R.filtering(stream, wm, gm, ctx.noisy_ptr, ctx.image_ptr, mode=R.FILTER_FAST)
             fast = ctx.download_image()
+            fast8 = ctx.download_rgba8()
             psnr["denoised_factorised_filter_db"] = _psnr(fast, ref_img)
             psnr["factorised_vs_exact_filter_db"] = _psnr(fast, exact)
+            d8 = fast8.astype(np.int16) - exact8.astype(np.int16)
+            psnr["rgba8_bytes_differing_factorised_vs_exact"] = {
+                "differing": int(np.count_nonzero(d8)), "of": int(d8.size), "max_abs_step": int(np.abs(d8).max()),
+                "note": "(uint8_t)(f * 255) truncates (main_headless.cpp:535-538): the factorised filter's <= 2e-5 relative "
+                        "difference steps over an integer boundary in these bytes -- the headline `value` is the tolerance "
+                        "route, `value_exact` the bit-exact one"}
             psnr["note"] = ("GuidanceNet trained by tools/train_guidance.py on this synthetic scene (pose 0 held out); "
                             "no ts_*.ts of the reference exists offline" if trained else
                             "GuidanceNet has seeded RANDOM weights: the denoised figure shows the pipeline runs, not denoiser quality")
@@ -628,7 +786,7 @@ def main():
         "basis": ("counters: FETCH_SIZE + WRITE_SIZE of this workload (profiles/pmc_traffic.json) / this run's launch duration"
                   if achieved is not None else
                   "ALGORITHMIC bytes (no counter pass is committed for this workload): see algorithmic_note"),
-        "traffic": traffic, "traffic_source": traffic_src,
+        "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale, "kernel_code_id": code_id,
         "algorithmic_bytes_per_launch": alg_bytes_launch, "algorithmic_gbps": alg_gbps,
         "algorithmic_frac": alg_gbps / HBM_PEAK_GBS,
         "algorithmic_note": "SURVEY 8d formula: 4 B per level of a root-restart walk + 2 B per step + SH record per hit leaf + 48 B per "
@@ -637,7 +795,7 @@ def main():
         "avg_launch_ms": kt["traverse_ms"],
         "measured_copy_bw": copy_gbps,
         "launches": kt["launches"], "frames_per_launch": frames_per_launch,
-        "shade_kernel_avg_launch_ms": kt["shade_ms"],
+        "shade_kernel_avg_launch_ms": kt["shade_ms"], "thresholds_kernel_avg_launch_ms": kt["raygen_ms"],
         "units_per_frame": {k: v / count_steps for k, v in units.items()},
         "tcp": tcp,
         "valu": valu,
@@ -651,6 +809,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
+        "value_exact": exact_pass["value"] if exact_pass else None,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32" if not denoise else "f32 (traversal, filter) + f16 x f16 -> f32 (GuidanceNet conv, %s)" % ("MIOpen" if args.torch_net else "fused MFMA kernel"),
@@ -671,6 +830,8 @@ def main():
             "render_ms": tstats["render_ms"], "torch_ms": tstats["torch_ms"], "filter_ms": tstats["filter_ms"],
             "fps": tstats["fps"], "frames": tstats["frames"]},
         "reference_loop": ref_loop,
+        "exact_route": exact_pass,
+        "parity_spot": parity,
         "alt_scene_map": alt,
         "roofline": roof,
         "psnr": psnr,

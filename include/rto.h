@@ -192,6 +192,9 @@ int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value);
  * returns the mean milliseconds per launch of each kernel, then resets the ring. */
 int rto_ctx_kernel_timing(rto_ctx* c, int enable);
 int rto_ctx_kernel_timing_read(rto_ctx* c, float* traverse_ms, float* shade_ms, int* launches);
+/* the same with the thresholds kernel (sample_kernel: RNG jump, SPP draws, sort for every pixel of the batch) reported too,
+ * as raygen_ms */
+int rto_ctx_kernel_timing_read3(rto_ctx* c, float* raygen_ms, float* traverse_ms, float* shade_ms, int* launches);
 /* Work counters for the roofline's ALGORITHMIC byte count.  When enabled, the fast
  * kernel's counting instantiation runs instead of the timed one and accumulates, over the launches
  * since the last rto_ctx_get_stats(reset=1): {rays, rays_in_box, march steps, descent levels a

@@ -84,6 +84,7 @@ SYMBOLS = {
     "rto_ctx_set_tuning": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "rto_ctx_kernel_timing": (C.c_int, [_P, C.c_int]),
     "rto_ctx_kernel_timing_read": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "rto_ctx_kernel_timing_read3": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "rto_ctx_enable_stats": (C.c_int, [_P, C.c_int]),
     "rto_ctx_get_stats": (C.c_int, [_P, _P, C.POINTER(C.c_uint64), C.c_int]),
     "rto_launch_renderer": (C.c_int, [_P, C.POINTER(CCamera), C.POINTER(COptions), _P, _P]),

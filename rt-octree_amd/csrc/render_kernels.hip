@@ -713,14 +713,18 @@ struct RayState {
     float cen[3], dir[3], invdir[3];
     float pos[3];  // clamp(cen + t * dir, 0, 1 - 1e-6): the point the next march step starts from
     float delta_scale, t, tmax, src, cur;      // cur = next threshold to cross (dst[spp])
-    uint32_t spp, sh_nums;
+    uint32_t spp;
     uint32_t pix, piy, piz;
     int prev_lvl;   // level of the node about to be visited
-    uint32_t hoff;  // index of this pixel's first hit entry in the hand-off buffer
+    uint32_t hoff;  // index of this pixel's next free hit entry in the hand-off buffer
     uint32_t node;  // node about to be visited; kGridNext = the top grid is visited next
     float cxy __attribute__((ext_vector_type(2)));  // cen[0], cen[1] as a register pair for the packed march arithmetic
+    // _dda_unit's max(t1, t1 + invdir) per axis is t1 + (invdir > 0 ? invdir : 0): the sign of invdir is the ray's, not the
+    // step's (exit_add below)
+    float exit_add[3];
 };
 constexpr uint32_t kGridNext = 0xffffffffu;
+constexpr int kCamFloats = 14;  // fx, fy, transform[12]: what a ray set-up reads of a FrameDesc
 
 // position p of a ray queue -> (frame, x, y).  The queue holds `qtiles` tiles per frame, frame after
 // frame, 64 rays per 8x8 tile: tile_order[qt0 + j] (ty << 16 | tx) or, without a table, row-major
@@ -801,9 +805,15 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     uint32_t* stack = s_mem + tid;  // [level - G][256]
     const int stack_levels = tree.max_depth + 1 - tree.top_levels;  // levels top_levels.. only
     float* s_dst = reinterpret_cast<float*>(s_mem + (size_t)stack_levels * 256) + tid;
-    FrameDesc* s_frames = reinterpret_cast<FrameDesc*>(s_mem + (size_t)(stack_levels + SPP + 1) * 256);
+    // the cameras of the batch: {fx, fy, transform[12]} per frame = the head of a FrameDesc (56 of its 96 bytes: at 100 frames
+    // per launch the table then leaves room for 8 workgroups per CU)
+    float* s_cams = reinterpret_cast<float*>(s_mem + (size_t)(stack_levels + SPP + 1) * 256);
     __shared__ int s_qstart[kMaxQueues + 1];
-    if (tid < fb.n) s_frames[tid] = fb.f[tid];  // the batch's frame table: device memory -> LDS
+    static_assert(offsetof(FrameDesc, transform) == 8 && kCamFloats == 14, "s_cams copies the first 14 floats of a FrameDesc");
+    for (int i = tid; i < fb.n * kCamFloats; i += 256) {  // device memory -> LDS
+        const int f = i / kCamFloats;
+        s_cams[i] = reinterpret_cast<const float*>(fb.f + f)[i - f * kCamFloats];
+    }
 #pragma unroll
     for (int k = 0; k <= kMaxQueues; ++k)
         if (tid == 64 + k) s_qstart[k] = fb.qstart[k];
@@ -847,14 +857,12 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     const uint32_t kChunk = chunk;           // rays per global dequeue (a multiple of the 64-ray tile)
     uint32_t res_next = 0, res_end = 0;      // the wave's private reservoir (wave-uniform)
 
+    // Two nested loops (round 3): the OUTER one refills the wave, the INNER one marches until REFILL lanes are idle again.
+    // The inner loop's back edge is one compare + population count + branch; with a single loop that re-decided "refill?"
+    // at its top the compiler spent 14 scalar instructions per iteration on that decision -- and scalar instructions come
+    // out of the same issue budget as the vector ones (profiles/r3_valu_calibration.json).
     for (;;) {
-        bool active = rs.t < rs.tmax;
-        int n_active;
         {
-            const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
-            asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n_active) : "s"(am) : "scc");
-        }
-        if (n_active <= 64 - REFILL) {  // (includes the empty wave: REFILL <= 64)
             for (;;) {
                 // (a finished ray needs no retiring: the stale threshold behind its last hit entry ends the list)
                 if (drained) break;
@@ -898,19 +906,18 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     const uint32_t r = first + rank;
                     int frame, x, y;
                     if (rank < take && ray_pixel(r, res_t0, res_tiles, (uint32_t)fb.n, fb.tile_major != 0, tiles8_x, W, H, tile_order, frame, x, y)) {
-                        const FrameDesc& fd = s_frames[frame];
+                        const float* fd = s_cams + frame * kCamFloats;
                         CamDev cam;
                         cam.width = W;
                         cam.height = H;
-                        cam.fx = fd.fx;
-                        cam.fy = fd.fy;
+                        cam.fx = fd[0];
+                        cam.fy = fd[1];
 #pragma unroll
-                        for (int i = 0; i < 12; ++i) cam.transform[i] = fd.transform[i];
+                        for (int i = 0; i < 12; ++i) cam.transform[i] = fd[2 + i];
                         float vdir[3];
                         ray_setup(x, y, cam, tree, rs.dir, vdir, rs.cen);
                         float tmin;
                         rs.hoff = (uint32_t)frame * (uint32_t)SPP * SIZE + hit_index<SPP>((uint32_t)(y * W + x), 0u, SIZE);
-                        rs.sh_nums = 0;
                         if (ray_enter(tree, opt, rs.dir, rs.cen, 1e9f, rs.invdir, rs.delta_scale, tmin, rs.tmax)) {
                             // sorted thresholds of this pixel (sample_kernel left them in the hand-off
                             // buffer, where the ray's hit list will overwrite them)
@@ -924,6 +931,8 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                             rs.t = tmin;
                             rs.cxy.x = rs.cen[0];
                             rs.cxy.y = rs.cen[1];
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) rs.exit_add[i] = rs.invdir[i] > 0.f ? rs.invdir[i] : 0.f;
                             rs.pix = rs.piy = rs.piz = 0;
                             rs.prev_lvl = 0;
                             {  // locate the first position: fixed-point coordinates + first node
@@ -940,13 +949,16 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     }
                 }
             }
-            active = rs.t < rs.tmax;
-            if (__builtin_amdgcn_ballot_w64(active) == 0ULL) {
-                if (drained) break;
-                continue;
-            }
         }
-
+        bool active = rs.t < rs.tmax;
+        if (__builtin_amdgcn_ballot_w64(active) == 0ULL) {
+            if (drained) break;
+            continue;  // (every ray of the round missed the volume)
+        }
+        // once the queues are empty there is nothing to refill with: march until the last ray ends
+        const int exit_at = drained ? 0 : 64 - REFILL;
+        int n_active;
+        do {
 #ifdef RTO_DBG_COUNTERS
         ++dbg_wave_steps;
         dbg_lane_steps += (unsigned)__popcll(__ballot(active));
@@ -1044,15 +1056,19 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     // _dda_unit (rt_core.cuh:38-51) on the leaf-local point frac(pos * cube_sz)
                     // (x and y as packed pairs: v_pk_mul_f32 / v_pk_add_f32 are the same IEEE operations, two per issue)
                     typedef float f2 __attribute__((ext_vector_type(2)));
+                    // max(t1, t2) with t1 = -p * invdir, t2 = t1 + invdir (rt_core.cuh:44-48): invdir > 0 gives t2 >= t1, so the
+                    // maximum IS t1 + invdir; invdir < 0 gives t2 <= t1, so it is t1 = t1 + 0 (a zero's sign aside, which the
+                    // sums below cannot observe).  One add per axis instead of an add and a max (round 3: the kernel is bound
+                    // by instruction issue and v_max_f32 costs two issue slots, profiles/r3_valu_calibration.json).
+                    // The 1e4 start of the reference's running minimum never survives: dir is a unit vector, so one axis has
+                    // |invdir| <= sqrt(3) and its exit time is below 2.
                     const f2 ixy = {rs.invdir[0], rs.invdir[1]};
                     const f2 sxy = (f2){rs.pos[0], rs.pos[1]} * cube_sz;
                     const f2 bxy = -(f2){__builtin_amdgcn_fractf(sxy.x), __builtin_amdgcn_fractf(sxy.y)} * ixy;
-                    const f2 cxy = bxy + ixy;
+                    const f2 axy = bxy + (f2){rs.exit_add[0], rs.exit_add[1]};
                     const float b2 = -__builtin_amdgcn_fractf(rs.pos[2] * cube_sz) * rs.invdir[2];
-                    const float a0 = __builtin_fmaxf(bxy.x, cxy.x);
-                    const float a1 = __builtin_fmaxf(bxy.y, cxy.y);
-                    const float a2 = __builtin_fmaxf(b2, b2 + rs.invdir[2]);
-                    const float tm = __builtin_fminf(1e4f, __builtin_fminf(__builtin_fminf(a0, a1), a2));
+                    const float a2 = b2 + rs.exit_add[2];
+                    const float tm = __builtin_fminf(__builtin_fminf(axy.x, axy.y), a2);
                     const float delta_t = tm * inv_cube + step_size;
                     const float sigma = half_bits_to_float((uint16_t)w);
                     if (sigma > sigma_thresh) {
@@ -1065,18 +1081,21 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                                 ++rs.spp;
                                 rs.cur = s_dst[rs.spp * 256];
                             } while (reach >= rs.cur);
-                            hits[rs.hoff + rs.sh_nums * hstride] = hit_pack<SPP>(slot, cnt);
-                            ++rs.sh_nums;
+                            hits[rs.hoff] = hit_pack<SPP>(slot, cnt);
+                            rs.hoff += hstride;  // (the next free entry of this pixel's list)
                             if (rs.spp == (uint32_t)SPP) rs.tmax = -1.f;  // the last threshold: the ray ends
                         }
                         rs.src = reach;
                     }
                     rs.t += delta_t;
                     active = rs.t < rs.tmax;
+                    if (active)
 #ifdef RTO_DBG_COUNTERS
                     ++dbg_lane_leafs;
 #endif
-                    if (active) {  // next position -> restart node (deepest ancestor shared with this step)
+                    {  // next position -> restart node (deepest ancestor shared with this step).  (Running this for rays that
+                       // just ended as well -- one divergent branch less per iteration -- measured 3 % SLOWER in one box:
+                       // the register allocator pays for the merged live ranges with a dozen copies.)
                         const f2 pxy = rs.cxy + (f2){rs.dir[0], rs.dir[1]} * rs.t;
                         rs.pos[0] = clamp_unit(pxy.x);
                         rs.pos[1] = clamp_unit(pxy.y);
@@ -1110,6 +1129,12 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                 }
             }
         }
+            active = rs.t < rs.tmax;
+            {
+                const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
+                asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n_active) : "s"(am) : "scc");
+            }
+        } while (n_active > exit_at);
     }
 #ifdef RTO_DBG_COUNTERS
     {
@@ -1487,6 +1512,9 @@ hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev&
     }
 }
 
+#ifndef RTO_WPS_DEFAULT
+#define RTO_WPS_DEFAULT 7
+#endif
 template <int SPP, int REFILL, int WPS>
 static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                     const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
@@ -1494,7 +1522,7 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
     // dynamic LDS: ancestor stack + thresholds per lane, then the frame table of THIS batch (96 B per frame: a batch of
     // one does not pay for 128)
     const size_t lds = (size_t)(tree.max_depth + 1 - tree.top_levels + SPP + 1) * 256 * sizeof(uint32_t) +
-                       sizeof(FrameDesc) * (size_t)fb.n;
+                       sizeof(float) * kCamFloats * (size_t)fb.n;
     const void* fn = reinterpret_cast<const void*>(&render_persist<SPP, REFILL, WPS>);
     OccupancyCache local;
     if (!occ) occ = &local;
@@ -1524,14 +1552,15 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
     const uint32_t chunk = chunk_override > 0 ? (uint32_t)chunk_override
                                               : (rays_per_wave >= 2048 ? 256u : rays_per_wave >= 512 ? 128u : 64u);
     const int64_t size = (int64_t)fb.width * fb.height;
+    if (ev) (void)hipEventRecord(ev[0], stream);
     hipLaunchKernelGGL(sample_kernel<SPP>, dim3((unsigned)((size + 255) / 256), fb.n), dim3(256), 0, stream, fb, jump);
     // arm the ray queues on the launch stream (576 B): a launch never depends on how the previous one on
     // this context ended
     if (hipMemsetAsync(queue, 0, kQueueWords * sizeof(unsigned long long), stream) != hipSuccess) return hipErrorLaunchFailure;
-    if (ev) (void)hipEventRecord(ev[0], stream);
+    if (ev) (void)hipEventRecord(ev[1], stream);
     hipLaunchKernelGGL((render_persist<SPP, REFILL, WPS>), dim3(grid), dim3(256), lds, stream, tree, opt, fb, queue, hits, chunk);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
-    if (ev) (void)hipEventRecord(ev[1], stream);
+    if (ev) (void)hipEventRecord(ev[2], stream);
 #ifndef RTO_SHADE_P
 #define RTO_SHADE_P 2
 #endif
@@ -1557,7 +1586,7 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
     else
         RTO_SHADE(0);
 #undef RTO_SHADE
-    if (ev) (void)hipEventRecord(ev[2], stream);
+    if (ev) (void)hipEventRecord(ev[3], stream);
     return hipGetLastError();
 }
 
@@ -1573,8 +1602,10 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
             case 808: RTO_F(8, 8);
             case 816: RTO_F(16, 8);
             case 832: RTO_F(32, 8);
-            case 624: RTO_F(24, 6);
-            case 640: RTO_F(40, 6);
+            case 724: RTO_F(24, 7);
+            case 732: RTO_F(32, 7);
+            case 740: RTO_F(40, 7);
+            case 632: RTO_F(32, 6);
             case 432: RTO_F(32, 4);
             case 232: RTO_F(32, 2);
             case 132: RTO_F(32, 1);
@@ -1582,11 +1613,12 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
         }
 #undef RTO_F
     }
-    // Refill once half the lanes are idle, 6 waves per SIMD: measured best at 32 frames per launch
-    // (2.75 ms vs 2.92 for 16 idle lanes at 8 waves/SIMD; 4 to 8 waves/SIMD differ by < 2 % -- the
-    // kernel is bound by the L1s, not by latency hiding -- and larger refill rounds waste fewer issue
-    // slots on the partially filled ray set-up)
-    return launch_batch_impl<SPP, 32, 6>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, occ, ev, stream);
+    // Refill once half the lanes are idle (larger refill rounds waste fewer issue slots on the partially filled ray set-up:
+    // 32 idle lanes beat 16 by 4 %); registers budgeted for RTO_WPS_DEFAULT waves per SIMD.  Occupancy matters (round 3,
+    // measured with the real knob, tuning key blocks_per_cu: 1 / 2 / 3 / 4 / 5 / 6 workgroups per CU take 26.2 / 14.4 /
+    // 10.6 / 8.8 / 7.8 / 7.35 ms per 100 frames -- round 2's "4 to 8 waves within 2 %" compared __launch_bounds__ hints,
+    // which change the register budget, not the number of resident waves).
+    return launch_batch_impl<SPP, 32, RTO_WPS_DEFAULT>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, occ, ev, stream);
 }
 
 hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,

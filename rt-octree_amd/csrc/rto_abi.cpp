@@ -116,7 +116,7 @@ struct rto_ctx {
     int hits_spp = 0;
     // per-kernel event timing of the batched path (off by default)
     bool kt_on = false;
-    std::vector<hipEvent_t> kt_ev;  // kKtRing triples
+    std::vector<hipEvent_t> kt_ev;  // kKtRing quadruples
     int kt_count = 0;               // launches recorded since the last read
     float* aux = nullptr;
     float* noisy = nullptr;
@@ -958,7 +958,7 @@ int rto_ctx_kernel_timing(rto_ctx* c, int enable) {
     if (!c) return set_err(RTO_E_INVALID, "rto_ctx_kernel_timing: null context");
     DeviceGuard guard(c->device);
     if (enable && c->kt_ev.empty()) {
-        c->kt_ev.resize((size_t)kKtRing * 3);
+        c->kt_ev.resize((size_t)kKtRing * 4);
         for (auto& e : c->kt_ev) HIP_TRY(hipEventCreate(&e));
     }
     c->kt_on = enable != 0;
@@ -967,17 +967,25 @@ int rto_ctx_kernel_timing(rto_ctx* c, int enable) {
 }
 
 int rto_ctx_kernel_timing_read(rto_ctx* c, float* traverse_ms, float* shade_ms, int* launches) {
+    return rto_ctx_kernel_timing_read3(c, nullptr, traverse_ms, shade_ms, launches);
+}
+
+int rto_ctx_kernel_timing_read3(rto_ctx* c, float* raygen_ms, float* traverse_ms, float* shade_ms, int* launches) {
     if (!c) return set_err(RTO_E_INVALID, "rto_ctx_kernel_timing_read: null context");
     DeviceGuard guard(c->device);
-    double t = 0, s = 0;
+    double g = 0, t = 0, s = 0;
     for (int i = 0; i < c->kt_count; ++i) {
-        float a = 0, b = 0;
-        HIP_TRY(hipEventSynchronize(c->kt_ev[(size_t)i * 3 + 2]));
-        HIP_TRY(hipEventElapsedTime(&a, c->kt_ev[(size_t)i * 3], c->kt_ev[(size_t)i * 3 + 1]));
-        HIP_TRY(hipEventElapsedTime(&b, c->kt_ev[(size_t)i * 3 + 1], c->kt_ev[(size_t)i * 3 + 2]));
+        float r = 0, a = 0, b = 0;
+        const hipEvent_t* e = &c->kt_ev[(size_t)i * 4];
+        HIP_TRY(hipEventSynchronize(e[3]));
+        HIP_TRY(hipEventElapsedTime(&r, e[0], e[1]));
+        HIP_TRY(hipEventElapsedTime(&a, e[1], e[2]));
+        HIP_TRY(hipEventElapsedTime(&b, e[2], e[3]));
+        g += r;
         t += a;
         s += b;
     }
+    if (raygen_ms) *raygen_ms = c->kt_count ? (float)(g / c->kt_count) : 0.f;
     if (traverse_ms) *traverse_ms = c->kt_count ? (float)(t / c->kt_count) : 0.f;
     if (shade_ms) *shade_ms = c->kt_count ? (float)(s / c->kt_count) : 0.f;
     if (launches) *launches = c->kt_count;
@@ -1179,7 +1187,7 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     const rto::OptDev od = make_opt_dev(o);
     HIP_TRY(rto::launch_write_frames(frames, n, ctx->d_frames, stream));
     hipEvent_t* ev = nullptr;
-    if (ctx->kt_on && ctx->kt_count < kKtRing) ev = &ctx->kt_ev[(size_t)ctx->kt_count++ * 3];
+    if (ctx->kt_on && ctx->kt_count < kKtRing) ev = &ctx->kt_ev[(size_t)ctx->kt_count++ * 4];
     hipError_t e = rto::launch_render_batch(o->spp, tree->dev, od, fb, ctx->jump, ctx->queue,
                                             ctx->hits + (size_t)slot0 * o->spp * px,  // = fb.f[0].hits: the kernel indexes frames from here
                                             ctx->num_cus, ctx->refill, &ctx->occ, ev, stream);

@@ -39,7 +39,7 @@ struct OccupancyCache {
 };
 
 // persistent batched renderer (N == 2 trees): fb.n frames in one launch (traversal kernel, then the
-// shading kernel); `queue` = kQueueWords u64 (zeroed on the stream before every launch); ev = nullptr or 3 events recorded before / between / after
+// shading kernel); `queue` = kQueueWords u64 (zeroed on the stream before every launch); ev = nullptr or 4 events recorded before the thresholds kernel, before / after the traversal, after the shading
 hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
                                int refill, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream);

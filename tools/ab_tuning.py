@@ -39,6 +39,8 @@ def main():
     ref = None
     for rnd in range(3):
         for sset in settings:
+            ctx.set_tuning("blocks_per_cu", 0)
+            ctx.set_tuning("refill", 0)
             for kv in sset.split(","):
                 k, v = kv.split("=")
                 ctx.set_tuning(k, int(v))
@@ -54,8 +56,8 @@ def main():
             if ref is None:
                 ref = aux
             same = np.array_equal(aux.view(np.uint32), ref.view(np.uint32))
-            print("round %d %-28s traverse %.3f ms  shade %.3f ms per launch  same_bits=%s"
-                  % (rnd, sset, kt["traverse_ms"], kt["shade_ms"], same), flush=True)
+            print("round %d %-28s raygen %.3f ms  traverse %.3f ms  shade %.3f ms per launch  same_bits=%s"
+                  % (rnd, sset, kt["raygen_ms"], kt["traverse_ms"], kt["shade_ms"], same), flush=True)
 
 
 if __name__ == "__main__":

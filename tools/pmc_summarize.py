@@ -35,7 +35,8 @@ def main():
                     if not fam:
                         continue
                     key = (fam, row["Counter_Name"])
-                    disp = row.get("Dispatch_Id") or row.get("Correlation_Id")
+                    # (pass directory, dispatch): a counter collected in two passes is averaged, not added up
+                    disp = (d, row.get("Dispatch_Id") or row.get("Correlation_Id"))
                     acc.setdefault(key, {}).setdefault(disp, 0.0)
                     acc[key][disp] += float(row["Counter_Value"])
     kernels = {}

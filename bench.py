@@ -434,6 +434,46 @@ def main():
     last_group, last_lane = work[-1], (len(work) - 1) % len(lanes)
 
     # ---------------- untimed: the reference's loop shape (one frame per launch, sync per frame) ----------------
+    # ---------------- untimed, N > 1: the path's one collective -- the final gather of RGBA8 frames to rank 0 ----------------
+    # (rt-octree_amd/sharding.py gather_frames: one padded all_gather, RCCL over xGMI with device tensors; the same code
+    #  tests/test_sharding.py runs over gloo on CPUs and, given two GPUs, over RCCL.)  K frames per rank, global frame
+    #  g -> rank g mod N; rank 0 then renders a frame that ANOTHER rank owned and compares the bytes: images must not
+    #  depend on N.
+    gather = None
+    if world > 1 and maps[0] == "pose":
+        from rt_octree_amd import sharding
+        K = 2
+        steps_g = list(range(K))
+        sc_g = [frame_of(st, "pose") for st in steps_g]
+        if len({sc for sc, _ in sc_g}) == 1:
+            ctx.rng_seed()
+            R.launch_renderer_batch(trees[sc_g[0][0]], [cams[i] for _, i in sc_g], opt, ctx, stream,
+                                    rng_jumps=[WARM_FRAMES_REF + i for _, i in sc_g])
+            local = {}
+            for k, st in enumerate(steps_g):
+                ctx.select_frame(k)
+                local[st * world + rank] = ctx.download_rgba8(noisy=denoise, stream=stream)
+            ctx.select_frame(0)
+            barrier()
+            t0g = time.perf_counter()
+            frames_g = sharding.gather_frames(local, K * world, rank, world, dist=dist, device=dev if backend == "nccl" else None)
+            barrier()
+            tg = time.perf_counter() - t0g
+            if rank == 0:
+                other = 1  # global frame 1 belongs to rank 1: (scene, pose) = pose_schedule(0, 1, world, ...)
+                sc_o, i_o = pose_schedule(0, 1, world, len(poses), n_scenes, "pose")
+                same = None
+                if sc_o in trees:
+                    ctx.rng_seed()
+                    R.launch_renderer_batch(trees[sc_o], [cams[i_o]], opt, ctx, stream, rng_jumps=[WARM_FRAMES_REF + i_o])
+                    ctx.select_frame(0)
+                    same = bool(np.array_equal(ctx.download_rgba8(noisy=denoise, stream=stream), frames_g[other]))
+                nbytes = sum(f.nbytes for f in frames_g)
+                gather = {"frames": len(frames_g), "bytes": nbytes, "seconds": tg, "backend": backend,
+                          "frame_of_rank_1_rendered_on_rank_0_is_identical": same,
+                          "note": "sharding.gather_frames: one padded all_gather of uint8 [K,H,W,4] per rank (host -> device -> "
+                                  "RCCL -> host, untimed plumbing); the timed region has no collective"}
+
     # frames of the last timed launch group, kept for the oracle spot check below (later passes reuse the buffers)
     spot_frames = []
     if world == 1 and args.spot_pixels > 0 and not args.quant_direct and not args.tree:
@@ -591,7 +631,7 @@ def main():
                 if pj.get("valu_insts") and pj.get("kernel_clocks") and vc.get("traversal_mix_insts_per_clk_per_simd"):
                     simds = float(pj.get("cus", 256)) * 4.0
                     rate = pj["valu_insts"] / simds / pj["kernel_clocks"]
-                    ceil = vc["traversal_mix_insts_per_clk_per_simd"]
+                    ceil = vc.get("ceiling_insts_per_clk_per_simd") or vc["traversal_mix_insts_per_clk_per_simd"]
                     valu = {"wave_insts_per_launch": pj["valu_insts"] * scale,
                             "salu_insts_per_launch": (pj.get("salu_insts") or 0.0) * scale,
                             "insts_per_clk_per_simd": rate,
@@ -602,9 +642,10 @@ def main():
                             "wait_any_frac": pj.get("wait_any_frac"), "wait_inst_any_frac": pj.get("wait_inst_any_frac"),
                             "active_inst_any_frac": pj.get("active_inst_any_frac"),
                             "lanes_per_valu_inst": pj.get("lanes_per_valu_inst"),
-                            "note": "frac = SQ_INSTS_VALU / (SIMDs x kernel clocks) over the rate the traversal's opcode mix sustains "
-                                    "at 8 waves per SIMD with no memory in the way (profiles/r3_valu_calibration.json: asm probe, "
-                                    "counters on the probe itself; the traversal loop with its gathers stubbed reaches the same 0.29). "
+                            "note": "frac = SQ_INSTS_VALU / (SIMDs x kernel clocks) over the rate the traversal's instruction stream sustains "
+                                    "with no memory in the way: the larger of the asm probe's figure for its opcode mix at 8 waves per "
+                                    "SIMD (0.290, profiles/r3_valu_calibration.json, counters on the probe itself) and the traversal "
+                                    "loop's own with both gathers stubbed (0.293, profiles/r3_a_stubbed_loads_pmc.json). "
                                     "A SIMD issues ~0.45 instructions per clock in all: plain add / mul / fma / logic opcodes at "
                                     "0.41-0.45, every other VALU opcode (3-operand, shifts left, min / max, conversions, compares, "
                                     "packed, SGPR operand) at 0.235-0.245, SALU instructions out of the same budget"}
@@ -831,6 +872,7 @@ def main():
             "fps": tstats["fps"], "frames": tstats["frames"]},
         "reference_loop": ref_loop,
         "exact_route": exact_pass,
+        "final_gather": gather,
         "parity_spot": parity,
         "alt_scene_map": alt,
         "roofline": roof,

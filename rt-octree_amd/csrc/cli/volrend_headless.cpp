@@ -11,7 +11,12 @@
 //   * `--batch B` (1..128, default 100: the reference's 200-pose test loop in two launches) renders B poses per launch of the persistent ray-queue kernel and
 //     denoises them as one batch; images are identical to B = 1 (one launch per frame, the reference's loop), the report is still per frame;
 //   * extra flags `--shard i/N` (render poses i, i+N, ...: frame sharding across GPUs, one process
-//     per GPU) and `--warmup K` (default 100 like the reference).
+//     per GPU), `--gpus N` (this process touches no GPU: it starts N copies of itself, `--shard i/N` on GPU i each,
+//     and prints the report of their union) and `--warmup K` (default 100 like the reference).
+#include <spawn.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +27,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "denoiser_torch.h"
@@ -30,6 +36,7 @@
 #include "rto.h"
 
 namespace fs = std::filesystem;
+extern char** environ;
 
 namespace {
 
@@ -47,7 +54,7 @@ struct Args {
 const std::map<std::string, std::string> kShort = {{"w", "width"},      {"h", "height"},     {"s", "step_size"},
                                                    {"e", "stop_thresh"}, {"a", "sigma_thresh"}, {"o", "write_images"},
                                                    {"i", "intrin"},      {"r", "reverse_yz"}};
-const char* kFlags[] = {"reverse_yz", "write_buffer", "help", "print_poses", "quant_direct", "torch_net", "fast_filter"};
+const char* kFlags[] = {"reverse_yz", "write_buffer", "help", "print_poses", "quant_direct", "torch_net", "fast_filter", "rank_report"};
 
 bool is_flag(const std::string& k) {
     for (const char* f : kFlags)
@@ -108,6 +115,8 @@ void usage() {
         "  -o,--write_images DIR   write r_<i>.png (or buf_<name>.bin with --write_buffer)\n"
         "  --write_buffer  --max_imgs N  --scale S  -i intrin  -r,--reverse_yz\n"
         "  --shard i/N        render poses i, i+N, ... only     --warmup K (100)\n"
+        "  --gpus N           frames sharded over N GPUs of this node: N child processes (--shard i/N, GPU i each), one\n"
+        "                     report for their union; images do not depend on N (per-pose RNG jump-ahead)\n"
         "  --batch B          poses per launch (1..128, default 100; 1 = one launch per frame like the reference's loop)\n"
         "  --torch_net        run the TorchScript GuidanceNet through libtorch even when it is the compact two-layer\n"
         "                     network the fused HIP kernel implements (default: fused)\n"
@@ -115,6 +124,136 @@ void usage() {
         "                     the default, bit-exact form to ~1e-6 relative)\n"
         "  --quant_direct     render a quantised tree.npz from its codebooks (no expansion to dense fp16)\n"
         "  --print_poses      parse the poses, print them (column-major 4x3) and exit\n");
+}
+
+// --gpus N: the reference is single-GPU (main_headless.cpp:234-238 picks ONE device); frames are independent, so N
+// processes render poses i, i + N, ... each on its own GPU.  This parent never touches a GPU: it starts the
+// children (posix_spawn of this very executable: nothing is exec'ed from a process that initialised HIP), relays their
+// output and merges their timing reports.  A child that fails makes the whole run fail.
+int run_multi_gpu(int argc, char** argv, int gpus) {
+    char self[4096];
+    const ssize_t sl = readlink("/proc/self/exe", self, sizeof(self) - 1);
+    if (sl <= 0) {
+        std::fputs("ERROR: cannot resolve /proc/self/exe\n", stderr);
+        return 1;
+    }
+    self[sl] = 0;
+    // the devices the children may use: the caller's HIP_VISIBLE_DEVICES list if there is one, else 0..N-1
+    std::vector<std::string> visible;
+    if (const char* hv = std::getenv("HIP_VISIBLE_DEVICES")) {
+        std::string cur;
+        for (const char* c = hv;; ++c) {
+            if (*c == ',' || *c == 0) {
+                if (!cur.empty()) visible.push_back(cur);
+                cur.clear();
+                if (!*c) break;
+            } else {
+                cur.push_back(*c);
+            }
+        }
+    }
+    struct Child {
+        pid_t pid = -1;
+        int fd = -1;
+        std::string out;
+        int status = -1;
+    };
+    std::vector<Child> kids((size_t)gpus);
+    for (int r = 0; r < gpus; ++r) {
+        std::vector<std::string> av;
+        av.push_back(self);
+        for (int i = 1; i < argc; ++i) {
+            const std::string a = argv[i];
+            if (a == "--gpus" || a == "--gpu") {  // replaced below
+                ++i;
+                continue;
+            }
+            if (a.rfind("--gpus=", 0) == 0 || a.rfind("--gpu=", 0) == 0) continue;
+            av.push_back(a);
+        }
+        av.push_back("--shard");
+        av.push_back(std::to_string(r) + "/" + std::to_string(gpus));
+        av.push_back("--gpu");
+        av.push_back("0");  // (the one device its HIP_VISIBLE_DEVICES shows)
+        av.push_back("--rank_report");
+        std::vector<char*> cav;
+        for (auto& a : av) cav.push_back(const_cast<char*>(a.c_str()));
+        cav.push_back(nullptr);
+        std::vector<std::string> env;
+        for (char** e = environ; *e; ++e)
+            if (std::strncmp(*e, "HIP_VISIBLE_DEVICES=", 20) != 0) env.push_back(*e);
+        env.push_back("HIP_VISIBLE_DEVICES=" + ((size_t)r < visible.size() ? visible[(size_t)r] : std::to_string(r)));
+        std::vector<char*> cenv;
+        for (auto& e : env) cenv.push_back(const_cast<char*>(e.c_str()));
+        cenv.push_back(nullptr);
+        int pfd[2];
+        if (pipe(pfd) != 0) {
+            std::perror("pipe");
+            return 1;
+        }
+        posix_spawn_file_actions_t fa;
+        posix_spawn_file_actions_init(&fa);
+        posix_spawn_file_actions_adddup2(&fa, pfd[1], STDOUT_FILENO);
+        posix_spawn_file_actions_addclose(&fa, pfd[0]);
+        posix_spawn_file_actions_addclose(&fa, pfd[1]);
+        const int rc = posix_spawn(&kids[(size_t)r].pid, self, &fa, nullptr, cav.data(), cenv.data());
+        posix_spawn_file_actions_destroy(&fa);
+        close(pfd[1]);
+        if (rc != 0) {
+            std::fprintf(stderr, "ERROR: cannot start rank %d: %s\n", r, std::strerror(rc));
+            return 1;
+        }
+        kids[(size_t)r].fd = pfd[0];
+    }
+    std::vector<std::thread> readers;
+    for (auto& k : kids)
+        readers.emplace_back([&k]() {
+            char buf[4096];
+            ssize_t n;
+            while ((n = read(k.fd, buf, sizeof(buf))) > 0) k.out.append(buf, (size_t)n);
+            close(k.fd);
+            waitpid(k.pid, &k.status, 0);
+        });
+    for (auto& t : readers) t.join();
+    bool ok = true;
+    double sum_ms[3] = {0, 0, 0}, sum_fps = 0;
+    long frames = 0;
+    for (int r = 0; r < gpus; ++r) {
+        const Child& k = kids[(size_t)r];
+        if (!WIFEXITED(k.status) || WEXITSTATUS(k.status) != 0) {
+            std::fprintf(stderr, "ERROR: rank %d (GPU %d) failed (status %d)\n", r, r, k.status);
+            ok = false;
+        }
+        size_t pos = 0;
+        while (pos < k.out.size()) {  // relay everything but the machine-readable line, tagged with the rank
+            size_t e = k.out.find('\n', pos);
+            if (e == std::string::npos) e = k.out.size();
+            const std::string line = k.out.substr(pos, e - pos);
+            pos = e + 1;
+            double a, b, c;
+            long n;
+            if (std::sscanf(line.c_str(), "RANK_REPORT %lf %lf %lf %ld", &a, &b, &c, &n) == 4) {
+                sum_ms[0] += a * n;
+                sum_ms[1] += b * n;
+                sum_ms[2] += c * n;
+                frames += n;
+                if (a + b + c > 0) sum_fps += 1000.0 / (a + b + c);
+            } else if (!line.empty()) {
+                std::printf("[rank %d] %s\n", r, line.c_str());
+            }
+        }
+    }
+    if (!ok) return 1;
+    if (frames > 0) {  // Timer::report (render_context.hpp:190-206) over the union of the ranks' frames
+        const double m0 = sum_ms[0] / frames, m1 = sum_ms[1] / frames, m2 = sum_ms[2] / frames;
+        std::printf("render: %.10f ms per frame\n", m0);
+        std::printf("torch:  %.10f ms per frame\n", m1);
+        std::printf("filter: %.10f ms per frame\n", m2);
+        std::printf("all:    %.10f ms per frame\n", m0 + m1 + m2);
+        std::printf("FPS:    %.10f\n", sum_fps);
+        std::printf("INFO: %ld frames on %d GPUs; FPS = the sum of the ranks' 1000 / (render + torch + filter)\n", frames, gpus);
+    }
+    return 0;
 }
 
 #define CHECK_RTO(expr)                                                          \
@@ -132,6 +271,20 @@ int main(int argc, char** argv) {
     if (args.has("help") || args.positional.size() < 2) {
         usage();
         return args.has("help") ? 0 : 1;
+    }
+    {
+        const int gpus = std::atoi(args.get("gpus", "1").c_str());
+        if (gpus < 1 || gpus > 64) {
+            std::fputs("ERROR: --gpus expects 1..64\n", stderr);
+            return 1;
+        }
+        if (gpus > 1) {
+            if (args.has("shard")) {
+                std::fputs("ERROR: --gpus N starts the shards itself; give one of --gpus and --shard\n", stderr);
+                return 1;
+            }
+            return run_multi_gpu(argc, argv, gpus);  // before anything that could touch a GPU
+        }
     }
     const std::string tree_path = args.positional[0], poses_path = args.positional[1];
     const int device = std::max(0, std::atoi(args.get("gpu", "-1").c_str()));
@@ -162,9 +315,18 @@ int main(int argc, char** argv) {
         std::fputs("WARNING: No camera poses specified, quitting\n", stderr);
         return 1;
     }
-    if (args.has("print_poses")) {  // host-only check of the pose loaders: no tree, no device
+    int shard_i = 0, shard_n = 1;
+    if (args.has("shard")) {
+        if (std::sscanf(args.get("shard", "0/1").c_str(), "%d/%d", &shard_i, &shard_n) != 2 || shard_n < 1 ||
+            shard_i < 0 || shard_i >= shard_n) {
+            std::fputs("ERROR: --shard expects i/N with 0 <= i < N\n", stderr);
+            return 1;
+        }
+    }
+    if (args.has("print_poses")) {  // host-only check of the pose loaders (and of the sharding): no tree, no device
         std::printf("POSES %zu %d %d %.9g %.9g\n", ps.trans.size(), ps.width, ps.height, ps.fx, ps.fy);
         for (size_t i = 0; i < ps.trans.size(); ++i) {
+            if ((int)(i % shard_n) != shard_i) continue;
             std::printf("%s", ps.basenames[i].c_str());
             for (float v : ps.trans[i]) std::printf(" %.9g", v);
             std::printf("\n");
@@ -195,15 +357,6 @@ int main(int argc, char** argv) {
             ps.basenames.resize(max_imgs);
         }
     }
-    int shard_i = 0, shard_n = 1;
-    if (args.has("shard")) {
-        if (std::sscanf(args.get("shard", "0/1").c_str(), "%d/%d", &shard_i, &shard_n) != 2 || shard_n < 1 ||
-            shard_i < 0 || shard_i >= shard_n) {
-            std::fputs("ERROR: --shard expects i/N with 0 <= i < N\n", stderr);
-            return 1;
-        }
-    }
-
     const std::string out_dir = args.get("write_images", "");
     if (!out_dir.empty()) fs::create_directories(out_dir);
 
@@ -351,6 +504,7 @@ int main(int argc, char** argv) {
         std::printf("filter: %.10f ms per frame\n", ms[2]);
         std::printf("all:    %.10f ms per frame\n", all);
         std::printf("FPS:    %.10f\n", all > 0 ? 1000.f / all : 0.f);
+        if (args.has("rank_report")) std::printf("RANK_REPORT %.10f %.10f %.10f %zu\n", ms[0], ms[1], ms[2], rendered);
         denoiser.reset();
         rto_ctx_free(ctx);
         rto_tree_free(tree);
@@ -389,6 +543,7 @@ int main(int argc, char** argv) {
     std::printf("filter: %.10f ms per frame\n", ms[2]);
     std::printf("all:    %.10f ms per frame\n", ms[0] + ms[1] + ms[2]);
     std::printf("FPS:    %.10f\n", fps);
+    if (args.has("rank_report")) std::printf("RANK_REPORT %.10f %.10f %.10f %d\n", ms[0], ms[1], ms[2], frames);
 
     denoiser.reset();
     rto_ctx_free(ctx);

@@ -212,6 +212,55 @@ def test_cli_pose_loader_blender(tmp_path):
     assert "Use NeRF camera convention" in r.stdout
 
 
+def test_cli_gpus_flag_shards_the_poses_over_child_processes(tmp_path):
+    """--gpus N: a parent that touches no GPU starts N copies of itself, `--shard i/N` with
+    HIP_VISIBLE_DEVICES = GPU i each, relays their output tagged by rank and fails if one of them fails.  Checked here
+    without a GPU through --print_poses: every pose printed by exactly one rank, pose i by rank i mod N."""
+    poses = synth.orbit_poses(7)
+    pp = synth.write_transforms_json(str(tmp_path / "transforms_test.json"), poses)
+    r = _run(["unused.npz", pp, "--print_poses", "-w", "400", "-h", "400", "--gpus", "3"])
+    assert r.returncode == 0, r.stderr
+    seen = {}
+    for line in r.stdout.splitlines():
+        m = re.match(r"\[rank (\d+)\] (r_(\d+)) (.*)", line)
+        if m:
+            assert int(m.group(3)) not in seen
+            seen[int(m.group(3))] = (int(m.group(1)), np.array([float(x) for x in m.group(4).split()], np.float32))
+    assert sorted(seen) == list(range(7))
+    for i, (rank, mat) in seen.items():
+        assert rank == i % 3
+        assert np.allclose(mat.reshape(4, 3), poses[i][:3, :4].T.astype(np.float32), atol=1e-6)
+    assert r.stdout.count("POSES 7 400 400") == 3  # every rank parsed the whole file
+    # a failing child fails the run; --gpus and --shard exclude each other
+    r = _run(["unused.npz", str(tmp_path / "nope.json"), "--print_poses", "--gpus", "2"])
+    assert r.returncode == 1
+    r = _run(["unused.npz", pp, "--print_poses", "--gpus", "2", "--shard", "0/2"])
+    assert r.returncode == 1 and "one of --gpus and --shard" in r.stderr
+    # the caller's own device list is dealt out in order
+    r = subprocess.run([BIN, "unused.npz", pp, "--print_poses", "--gpus", "2"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HIP_VISIBLE_DEVICES="5,3"))
+    assert r.returncode == 0 and "[rank 1] r_1 " in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_gpus_two_ranks_render_the_union(tmp_path):
+    """two ranks (sharing the one GPU of the test box: HIP_VISIBLE_DEVICES "0,0") write the PNGs of the unsharded run,
+    byte for byte, and the parent prints ONE report for their union"""
+    tree, tp, poses, pp = _scene(tmp_path, n=5)
+    op = synth.write_opt_json(str(tmp_path / "opt.json"), denoise=False, spp=6)
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    base = [tp, pp, "--options", op, "-w", "64", "-h", "48", "--warmup", "3"]
+    assert _run(base + ["-o", one]).returncode == 0
+    r = subprocess.run([BIN] + base + ["-o", two, "--gpus", "2"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HIP_VISIBLE_DEVICES="0,0"))
+    assert r.returncode == 0, r.stderr
+    assert sorted(os.listdir(two)) == sorted(os.listdir(one)) == ["r_%d.png" % i for i in range(5)]
+    for f in os.listdir(one):
+        assert open(os.path.join(one, f), "rb").read() == open(os.path.join(two, f), "rb").read(), f
+    assert re.search(r"\nrender: [0-9.]+ ms per frame\ntorch:  [0-9.]+ ms per frame\nfilter: [0-9.]+ ms per frame\nall:    [0-9.]+ ms per frame\nFPS:    [0-9.]+\nINFO: 5 frames on 2 GPUs", r.stdout)
+    assert "RANK_REPORT" not in r.stdout
+
+
 def test_cli_pose_loader_tt(tmp_path):
     """TanksAndTemple: 1920x1080, ../intrinsics.txt, OpenCV -> NeRF flip (main_headless.cpp:273-297,372-384)"""
     poses = synth.orbit_poses(3)

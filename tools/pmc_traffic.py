@@ -43,6 +43,16 @@ def main():
             "full_rate_insts_per_clk_per_simd": t["v_fma_f32"]["wps8"]["valu_per_clk_per_simd"],
             "half_rate_insts_per_clk_per_simd": t["v_med3_f32"]["wps8"]["valu_per_clk_per_simd"],
             "source": "profiles/r3_valu_calibration.json: asm probe, 8 waves per SIMD, SQ_INSTS_VALU / (SQ_BUSY_CYCLES / 32) / 1024 SIMDs"}
+        # the traversal loop itself with both gathers stubbed (-DRTO_STUB_LOADS): what ITS instruction stream sustains with no
+        # memory in the way; the ceiling quoted is the larger of the two
+        stub = os.path.join(ROOT, "profiles", "r3_a_stubbed_loads_pmc.json")
+        vc = doc["valu_ceiling"]
+        vc["ceiling_insts_per_clk_per_simd"] = vc["traversal_mix_insts_per_clk_per_simd"]
+        if os.path.exists(stub):
+            k = json.load(open(stub))["kernels"].get("render_persist", {})
+            if "SQ_INSTS_VALU" in k and "GRBM_GUI_ACTIVE" in k:
+                vc["stubbed_loop_insts_per_clk_per_simd"] = k["SQ_INSTS_VALU"]["mean"] / 1024.0 / (k["GRBM_GUI_ACTIVE"]["mean"] / 8.0)
+                vc["ceiling_insts_per_clk_per_simd"] = max(vc["ceiling_insts_per_clk_per_simd"], vc["stubbed_loop_insts_per_clk_per_simd"])
     code_id = bench.kernel_code_id()
     for spec in sys.argv[3:]:
         wid, path = spec.split("=")

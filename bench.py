@@ -94,6 +94,9 @@ def parse_args(argv=None):
                          "rank s mod N; 'both' = time both, headline the pose mapping")
     ap.add_argument("--quant-direct", action="store_true",
                     help="with --tree <quantised tree.npz>: render from the codebooks instead of the expanded fp16 tree")
+    ap.add_argument("--compact-records", action="store_true",
+                    help="RTO_TREE_COMPACT_RECORDS: coefficient records for the leaves of positive density only (smaller footprint, one "
+                         "more gather per hit leaf in the shading kernel)")
     ap.add_argument("--tuning", default="",
                     help="development: rto_ctx_set_tuning keys for the batched path, e.g. cu_queues=32,queue_group=16")
     ap.add_argument("--streams", type=int, default=1,
@@ -134,7 +137,7 @@ def workload_id(args, W, H):
     build (RTO_LIB), more than one stream."""
     if args.tree or args.shuffle_nodes or args.scenes != 1 or args.quant_direct or args.shell != 2.5:
         return None
-    if args.tuning or os.environ.get("RTO_LIB") or args.streams != 1:
+    if args.tuning or os.environ.get("RTO_LIB") or args.streams != 1 or args.compact_records:
         return None
     key = (W, H, args.spp, args.basis, args.depth, bool(args.no_denoise), args.radius, args.fx, args.cam_radius)
     return {(800, 800, 6, 16, 10, False, 1.5, 0.0, 4.0311): "c2", (800, 800, 1, 16, 10, True, 1.5, 0.0, 4.0311): "c5",
@@ -286,7 +289,8 @@ def main():
     need = set()
     for m in maps:
         need |= set(scenes_of_rank(rank, world, n_scenes, m))
-    trees = {s: R.N3Tree(paths[s], device=local_rank, quant_direct=args.quant_direct) for s in sorted(need)}  # tree.npz -> device
+    trees = {s: R.N3Tree(paths[s], device=local_rank, quant_direct=args.quant_direct, compact_records=args.compact_records)
+             for s in sorted(need)}  # tree.npz -> device
     tree = trees[min(trees)]
     poses = synth.orbit_poses(200, radius=args.cam_radius)
     fx = args.fx if args.fx > 0 else synth.blender_focal(W)

@@ -137,6 +137,12 @@ int rto_tree_load_npz(const char* path, int device, rto_tree** out);
  * 1.7 GB file) and rebuilds them -- the same leaf values -- on the first launch that selects the generic kernel
  * (rto_ctx_set_kernel(RTO_KERNEL_GENERIC)), which then pays one pass over the tree.  This flag keeps them resident. */
 #define RTO_TREE_KEEP_REFERENCE 4
+/* RTO_TREE_COMPACT_RECORDS: the aligned coefficient copy holds a record only for the leaf slots a ray can hit -- density
+ * > 0: a hit needs sigma > sigma_thresh (rt_core.cuh:252) -- found through a 4-byte-per-slot index (8.6 M of 17 M slots of
+ * the benchmark tree: 1.3 instead of 2.2 GB resident, 0.75x the file).  Same pixels; the shading kernels pay one more
+ * dependent gather per hit leaf (measured: DESIGN.md section 3).  Launches with sigma_thresh < 0 are refused for such a
+ * tree (RTO_E_UNSUPPORTED).  Ignored where no aligned copy is built (RTO_TREE_COMPACT, SH25, RGBA, quantised-direct). */
+#define RTO_TREE_COMPACT_RECORDS 8
 int rto_tree_load_npz_ex(const char* path, int device, int flags, rto_tree** out);
 /* Same upload from host arrays: child int32 [capacity*N^3], data fp16 bits
  * [capacity*N^3*data_dim], data_format like "SH9"/"SH16"/"RGBA" (DataFormat::parse,

@@ -54,7 +54,7 @@ struct Args {
 const std::map<std::string, std::string> kShort = {{"w", "width"},      {"h", "height"},     {"s", "step_size"},
                                                    {"e", "stop_thresh"}, {"a", "sigma_thresh"}, {"o", "write_images"},
                                                    {"i", "intrin"},      {"r", "reverse_yz"}};
-const char* kFlags[] = {"reverse_yz", "write_buffer", "help", "print_poses", "quant_direct", "torch_net", "fast_filter", "rank_report"};
+const char* kFlags[] = {"reverse_yz", "write_buffer", "help", "print_poses", "quant_direct", "torch_net", "fast_filter", "rank_report", "compact_records"};
 
 bool is_flag(const std::string& k) {
     for (const char* f : kFlags)
@@ -123,6 +123,8 @@ void usage() {
         "  --fast_filter      guided filter with factorised exponentials (4 exps per pixel instead of 164; agrees with\n"
         "                     the default, bit-exact form to ~1e-6 relative)\n"
         "  --quant_direct     render a quantised tree.npz from its codebooks (no expansion to dense fp16)\n"
+        "  --compact_records  keep SH coefficient records for the leaves of positive density only (half the footprint of a\n"
+        "                     dense SH9 / SH16 tree, same pixels, slower shading)\n"
         "  --print_poses      parse the poses, print them (column-major 4x3) and exit\n");
 }
 
@@ -335,7 +337,10 @@ int main(int argc, char** argv) {
     }
 
     rto_tree* tree = nullptr;
-    CHECK_RTO(rto_tree_load_npz_ex(tree_path.c_str(), device, args.has("quant_direct") ? RTO_TREE_QUANT_DIRECT : 0, &tree));
+    CHECK_RTO(rto_tree_load_npz_ex(tree_path.c_str(), device,
+                                   (args.has("quant_direct") ? RTO_TREE_QUANT_DIRECT : 0) |
+                                       (args.has("compact_records") ? RTO_TREE_COMPACT_RECORDS : 0),
+                                   &tree));
     if (dataset == "llff") CHECK_RTO(rto_tree_set_ndc(tree, (float)ps.width, (float)ps.height, ps.fx));  // :400-405
 
     int width = ps.width, height = ps.height;

@@ -356,27 +356,41 @@ __global__ void build_nodew_kernel(const int32_t* __restrict__ child, const uint
 // Aligned copy of the SH coefficients for the shading kernels (TreeDev::shrec): per slot the 3 B coefficients of
 // data[] in the same order, zero-padded to shrec_halves(B).  Derived data: the same fp16 values.
 __global__ void build_shrec_kernel(const uint16_t* __restrict__ data, int64_t n_slots, int data_dim, int rec,
-                                   uint16_t* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per output half
+                                   const uint32_t* __restrict__ recidx, uint16_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per half of a slot's record
     if (i >= n_slots * rec) return;
     const int64_t slot = i / rec;
     const int k = (int)(i - slot * rec);
-    out[i] = k < data_dim - 1 ? data[slot * data_dim + k] : (uint16_t)0;
+    int64_t dst = slot;
+    if (recidx) {  // compact records (RTO_TREE_COMPACT_RECORDS): only the slots that own one
+        const uint32_t r = recidx[slot];
+        if (r == kNoRecord) return;
+        dst = r;
+    }
+    out[dst * rec + k] = k < data_dim - 1 ? data[slot * data_dim + k] : (uint16_t)0;
 }
 
 // The reference-layout arrays back from the derived ones (rto_abi.cpp ensure_reference_arrays): a tree that renders through
 // the fast / batched kernels keeps only nodew + shrec resident; the generic kernel's child[] / data[] are rebuilt on
 // first use.  Leaf slots get their exact fp16 values back (coefficients from shrec, sigma from the leaf word); an
 // internal slot's sigma -- which no query ever returns -- becomes 0.
-__global__ void rebuild_reference_kernel(const uint16_t* __restrict__ shrec, const uint32_t* __restrict__ nodew, int64_t n_slots,
-                                         int data_dim, int rec, uint16_t* __restrict__ data, int32_t* __restrict__ child) {
+__global__ void rebuild_reference_kernel(const uint16_t* __restrict__ shrec, const uint32_t* __restrict__ nodew,
+                                         const uint32_t* __restrict__ recidx, int64_t n_slots, int data_dim, int rec,
+                                         uint16_t* __restrict__ data, int32_t* __restrict__ child) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per half of data[]
     if (i >= n_slots * data_dim) return;
     const int64_t slot = i / data_dim;
     const int k = (int)(i - slot * data_dim);
     const uint32_t w = nodew[slot];
     const bool leaf = nodew_is_leaf(w);
-    data[i] = k < data_dim - 1 ? shrec[slot * rec + k] : (leaf ? (uint16_t)(w & 0xffffu) : (uint16_t)0);
+    int64_t src = slot;
+    bool has = true;
+    if (recidx) {  // compact records: a slot without one (internal, or a leaf of zero density) reads as zeros
+        const uint32_t r = recidx[slot];
+        has = r != kNoRecord;
+        src = r;
+    }
+    data[i] = k < data_dim - 1 ? (has ? shrec[src * rec + k] : (uint16_t)0) : (leaf ? (uint16_t)(w & 0xffffu) : (uint16_t)0);
     if (k == 0) child[slot] = leaf ? 0 : (int32_t)w;
 }
 
@@ -457,7 +471,9 @@ RTO_DEV void shade_leaf_packed(const TreeDev& tree, uint32_t slot, const float* 
         // the aligned copy: 16-byte loads, every coefficient already at its packed position, one 128-byte line per
         // record (a 98-byte record at a 2-byte aligned address straddles 1.76 lines on average)
         constexpr int NQ = (3 * B * 2 + 15) / 16;  // 16-byte loads that hold coefficients
-        const uint4* __restrict__ q = reinterpret_cast<const uint4*>(tree.shrec + (uint64_t)slot * shrec_halves(B));
+        // (compact records: the slot's record index first -- one more dependent 4-byte gather per hit leaf)
+        const uint32_t ridx = tree.recidx ? tree.recidx[slot] : slot;
+        const uint4* __restrict__ q = reinterpret_cast<const uint4*>(tree.shrec + (uint64_t)ridx * shrec_halves(B));
         uint4 v[NQ];
 #pragma unroll
         for (int i = 0; i < NQ; ++i) v[i] = q[i];
@@ -1446,16 +1462,17 @@ hipError_t launch_build_nodew(const int32_t* child, const uint16_t* data, int64_
     return hipGetLastError();
 }
 
-hipError_t launch_build_shrec(const uint16_t* data, int64_t n_slots, int data_dim, int rec, uint16_t* out, hipStream_t stream) {
+hipError_t launch_build_shrec(const uint16_t* data, int64_t n_slots, int data_dim, int rec, const uint32_t* recidx, uint16_t* out,
+                              hipStream_t stream) {
     const int64_t n = n_slots * rec;
-    hipLaunchKernelGGL(build_shrec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data, n_slots, data_dim, rec, out);
+    hipLaunchKernelGGL(build_shrec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data, n_slots, data_dim, rec, recidx, out);
     return hipGetLastError();
 }
 
-hipError_t launch_rebuild_reference(const uint16_t* shrec, const uint32_t* nodew, int64_t n_slots, int data_dim, int rec,
-                                    uint16_t* data, int32_t* child, hipStream_t stream) {
+hipError_t launch_rebuild_reference(const uint16_t* shrec, const uint32_t* nodew, const uint32_t* recidx, int64_t n_slots, int data_dim,
+                                    int rec, uint16_t* data, int32_t* child, hipStream_t stream) {
     const int64_t n = n_slots * data_dim;
-    hipLaunchKernelGGL(rebuild_reference_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, shrec, nodew, n_slots,
+    hipLaunchKernelGGL(rebuild_reference_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, shrec, nodew, recidx, n_slots,
                        data_dim, rec, data, child);
     return hipGetLastError();
 }

@@ -84,6 +84,7 @@ struct rto_tree {
     void* d_nodew = nullptr;
     void* d_topgrid = nullptr;
     void* d_shrec = nullptr;  // aligned copy of the SH coefficients (shading)
+    void* d_recidx = nullptr; // RTO_TREE_COMPACT_RECORDS: slot -> record of d_shrec
     void* d_qrec = nullptr;
     void* d_qcolors = nullptr;
     void* d_qsigma = nullptr;
@@ -178,6 +179,32 @@ int ensure_jump_table(rto_ctx* c, hipStream_t stream) {
     c->jump_inc = c->rng.inc;
     c->jump_valid = true;
     return RTO_OK;
+}
+
+// IEEE binary16 -> binary32 (exact), for the host-side look at a leaf's density
+float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else {  // subnormal: renormalise
+            int e = -1;
+            uint32_t m = man;
+            do {
+                ++e;
+                m <<= 1;
+            } while (!(m & 0x400u));
+            bits = sign | (uint32_t)(127 - 15 - e) << 23 | (m & 0x3ffu) << 13;
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7f800000u | man << 13;
+    } else {
+        bits = sign | (exp + 127 - 15) << 23 | man << 13;
+    }
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
 }
 
 // Breadth-first node order of a tree: order[new] = old.  Children are visited in slot order, so after the
@@ -398,9 +425,27 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
         !(flags & RTO_TREE_COMPACT)) {
         // aligned copy of the SH coefficients for the shading kernels (+ 64 / 128 B per slot)
         const int rec = 3 * fmt.basis_dim * 2 <= 64 ? 32 : 64;  // = shrec_halves()
-        const size_t rb = (size_t)n_slots * rec * 2;
+        int64_t n_rec = n_slots;
+        if (flags & RTO_TREE_COMPACT_RECORDS) {
+            // records only for the leaf slots a ray can hit -- density > 0 (a hit needs sigma > sigma_thresh >= 0,
+            // rt_core.cuh:252; launches with a negative threshold are refused for such a tree) -- in slot order
+            std::vector<uint32_t> idx((size_t)n_slots, rto::kNoRecord);
+            uint32_t n = 0;
+            for (int64_t sl = 0; sl < n_slots; ++sl) {
+                if (child[sl] != 0) continue;
+                const float sg = half_to_float(data[(size_t)sl * data_dim + data_dim - 1]);
+                if (sg > 0.f) idx[(size_t)sl] = n++;
+            }
+            n_rec = n > 0 ? n : 1;
+            if (hipMalloc(&t->d_recidx, (size_t)n_slots * 4) != hipSuccess ||
+                hipMemcpy(t->d_recidx, idx.data(), (size_t)n_slots * 4, hipMemcpyHostToDevice) != hipSuccess)
+                return fail(RTO_E_HIP, "hipMalloc(record index) failed");
+            dev_bytes += (size_t)n_slots * 4;
+        }
+        const size_t rb = (size_t)n_rec * rec * 2;
         if (hipMalloc(&t->d_shrec, rb) == hipSuccess) {
-            hipError_t e = rto::launch_build_shrec((const uint16_t*)t->d_data, n_slots, data_dim, rec, (uint16_t*)t->d_shrec, nullptr);
+            hipError_t e = rto::launch_build_shrec((const uint16_t*)t->d_data, n_slots, data_dim, rec, (const uint32_t*)t->d_recidx,
+                                                   (uint16_t*)t->d_shrec, nullptr);
             if (e == hipSuccess) e = hipDeviceSynchronize();
             if (e != hipSuccess) return fail(RTO_E_HIP, std::string("build_shrec failed: ") + hipGetErrorString(e));
             dev_bytes += rb;
@@ -408,6 +453,11 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
         } else {  // not enough memory for the copy: shade from data[]
             (void)hipGetLastError();
             t->d_shrec = nullptr;
+            if (t->d_recidx) {
+                (void)hipFree(t->d_recidx);
+                t->d_recidx = nullptr;
+                dev_bytes -= (size_t)n_slots * 4;
+            }
         }
     }
 
@@ -430,6 +480,7 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
     d.topgrid = (const uint2*)t->d_topgrid;
     d.top_levels = top_levels;
     d.shrec = (const uint16_t*)t->d_shrec;
+    d.recidx = (const uint32_t*)t->d_recidx;
     d.qrec = (const uint16_t*)t->d_qrec;
     d.qcolors = (const uint2*)t->d_qcolors;
     d.q_retain = quant ? quant->n_retain : 0;
@@ -488,8 +539,8 @@ int ensure_reference_arrays(const rto_tree* tree) {
     }
     hipError_t e = hipMemset((char*)d_data + data_bytes, 0, 16);
     if (e == hipSuccess)
-        e = rto::launch_rebuild_reference((const uint16_t*)t->d_shrec, (const uint32_t*)t->d_nodew, n_slots, t->dev.data_dim,
-                                          t->shrec_halves, (uint16_t*)d_data, (int32_t*)d_child, nullptr);
+        e = rto::launch_rebuild_reference((const uint16_t*)t->d_shrec, (const uint32_t*)t->d_nodew, (const uint32_t*)t->d_recidx, n_slots,
+                                          t->dev.data_dim, t->shrec_halves, (uint16_t*)d_data, (int32_t*)d_child, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         (void)hipFree(d_data);
@@ -723,6 +774,7 @@ void rto_tree_free(rto_tree* t) {
     if (t->d_nodew) (void)hipFree(t->d_nodew);
     if (t->d_topgrid) (void)hipFree(t->d_topgrid);
     if (t->d_shrec) (void)hipFree(t->d_shrec);
+    if (t->d_recidx) (void)hipFree(t->d_recidx);
     for (void* p : {t->d_qrec, t->d_qcolors, t->d_qsigma})
         if (p) (void)hipFree(p);
     delete t;
@@ -1031,6 +1083,9 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
     if (cam->width != ctx->width || cam->height != ctx->height)
         return set_err(RTO_E_INVALID, "camera size does not match the render context");
     if (tree->device != ctx->device) return set_err(RTO_E_INVALID, "tree and context live on different devices");
+    if (tree->d_recidx && !(o->sigma_thresh >= 0.f))
+        return set_err(RTO_E_UNSUPPORTED, "a tree loaded with RTO_TREE_COMPACT_RECORDS keeps coefficient records for leaves of positive "
+                                          "density only: sigma_thresh must be >= 0");
     if (o->enable_probe)
         return set_err(RTO_E_UNSUPPORTED, "enable_probe is a GUI feature (volrend.cu:100-134), not on the headless path");
     if (tree->dev.format == RTO_FMT_SG || tree->dev.format == RTO_FMT_ASG)
@@ -1090,6 +1145,9 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     if (!spp_supported(o->spp))
         return set_err(RTO_E_SPP, "spp == " + std::to_string(o->spp) + " not supported. (supported: 1,2,3,4,6,8,16,32)");
     if (tree->device != ctx->device) return set_err(RTO_E_INVALID, "tree and context live on different devices");
+    if (tree->d_recidx && !(o->sigma_thresh >= 0.f))
+        return set_err(RTO_E_UNSUPPORTED, "a tree loaded with RTO_TREE_COMPACT_RECORDS keeps coefficient records for leaves of positive "
+                                          "density only: sigma_thresh must be >= 0");
     if (o->enable_probe) return set_err(RTO_E_UNSUPPORTED, "enable_probe is a GUI feature, not on the headless path");
     if (tree->dev.format == RTO_FMT_SG || tree->dev.format == RTO_FMT_ASG)
         return set_err(RTO_E_UNSUPPORTED, "SG/ASG bases are untested upstream and not built");

@@ -13,6 +13,7 @@ namespace rto {
 //   internal slot: the reference's child[] value (relative node offset, |v| < 2^30)
 //   leaf slot:     0x80000000 | fp16 bits of the slot's sigma  -> top two bits are 0b10
 constexpr uint32_t kLeafTag = 0x80000000u;
+constexpr uint32_t kNoRecord = 0xffffffffu;  // TreeDev::recidx entry of a slot without a coefficient record
 
 // Bit budgets of the packed words.  A top-grid entry is {slot | level << kGridSlotBits, word}: the level is < 8 (the
 // grid spans at most 6 node levels), which leaves 29 bits for the slot.  A hit-list entry is {kHitValid | slot |
@@ -50,6 +51,9 @@ struct TreeDev {
     // a record is ONE 128-byte line fetched by 16-byte loads; nullptr when absent (shading then reads data[]).  When it
     // exists the host releases `data` and `child` after the upload (both nullptr until the generic kernel asks for them).
     const uint16_t* shrec;
+    // RTO_TREE_COMPACT_RECORDS: shrec holds records only for the leaf slots a ray can hit (density > 0), in slot order;
+    // recidx[slot] = its record, kNoRecord for the others.  nullptr: shrec is indexed by the slot itself.
+    const uint32_t* recidx;
     // Quantised tree rendered WITHOUT expansion (the inputs of n3tree.cpp:279-340):
     // `data` is nullptr; per leaf slot one record of q_rec u16 values, `qrec[slot * q_rec + ...]`:
     //   [3 * q_retain] fp16 retained coefficients, (basis k, channel c) at k * 3 + c

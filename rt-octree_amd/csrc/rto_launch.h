@@ -12,10 +12,11 @@ hipError_t launch_build_nodew(const int32_t* child, const uint16_t* data, int64_
                               uint32_t* nodew, int* bad_flag, hipStream_t stream);
 
 // aligned copy of the SH coefficients (TreeDev::shrec): `rec` halves per slot = shrec_halves(basis_dim)
-hipError_t launch_build_shrec(const uint16_t* data, int64_t n_slots, int data_dim, int rec, uint16_t* out, hipStream_t stream);
+hipError_t launch_build_shrec(const uint16_t* data, int64_t n_slots, int data_dim, int rec, const uint32_t* recidx, uint16_t* out,
+                              hipStream_t stream);
 // child[] / data[] (reference layout) rebuilt from the traversal image and the aligned coefficient copy
-hipError_t launch_rebuild_reference(const uint16_t* shrec, const uint32_t* nodew, int64_t n_slots, int data_dim, int rec,
-                                    uint16_t* data, int32_t* child, hipStream_t stream);
+hipError_t launch_rebuild_reference(const uint16_t* shrec, const uint32_t* nodew, const uint32_t* recidx, int64_t n_slots, int data_dim,
+                                    int rec, uint16_t* data, int32_t* child, hipStream_t stream);
 
 // top-of-tree shortcut grid: 2^(3G) entries (TreeDev::topgrid)
 hipError_t launch_build_topgrid(const uint32_t* nodew, int G, uint2* grid, hipStream_t stream);

@@ -112,17 +112,19 @@ class N3Tree:
     """Device-resident PlenOctree.  `N3Tree(path)` = N3Tree::open + load_cuda
     (n3tree.cpp:111-154, n3tree.cu:9-41)."""
 
-    def __init__(self, path=None, device=0, quant_direct=False, compact=False, keep_reference=False):
+    def __init__(self, path=None, device=0, quant_direct=False, compact=False, keep_reference=False, compact_records=False):
         self._h = C.c_void_p(0)
         self.device = device
         self.quant_direct = bool(quant_direct)  # render a quantised tree from its codebooks (no expansion)
         self.compact = bool(compact)            # RTO_TREE_COMPACT: no aligned copy of the SH coefficients for shading
         self.keep_reference = bool(keep_reference)  # RTO_TREE_KEEP_REFERENCE: child[] / data[] stay resident
+        self.compact_records = bool(compact_records)  # RTO_TREE_COMPACT_RECORDS: coefficient records for hittable leaves only
         if path is not None:
             self.open(path)
 
     def _flags(self):
-        return (1 if self.quant_direct else 0) | (2 if self.compact else 0) | (4 if self.keep_reference else 0)
+        return ((1 if self.quant_direct else 0) | (2 if self.compact else 0) | (4 if self.keep_reference else 0)
+                | (8 if self.compact_records else 0))
 
     def open(self, path):
         self.free()
@@ -132,7 +134,8 @@ class N3Tree:
         self._refresh()
 
     @classmethod
-    def from_arrays(cls, child, data, scale, offset, data_format="", device=0, compact=False, keep_reference=False):
+    def from_arrays(cls, child, data, scale, offset, data_format="", device=0, compact=False, keep_reference=False,
+                    compact_records=False):
         """child int32 [capacity,N,N,N]; data float16 (or uint16 bits) [capacity,N,N,N,data_dim];
         scale = invradius3, offset (n3tree.cpp:257-267)."""
         child = np.ascontiguousarray(child, dtype=np.int32)
@@ -146,7 +149,7 @@ class N3Tree:
         cap, N, dd = child.shape[0], child.shape[1], data.shape[-1]
         sc = (C.c_float * 3)(*[float(x) for x in np.broadcast_to(np.asarray(scale, np.float32), (3,))])
         of = (C.c_float * 3)(*[float(x) for x in np.broadcast_to(np.asarray(offset, np.float32), (3,))])
-        t = cls(device=device, compact=compact, keep_reference=keep_reference)
+        t = cls(device=device, compact=compact, keep_reference=keep_reference, compact_records=compact_records)
         h = C.c_void_p(0)
         check(lib().rto_tree_from_arrays_ex(C.c_void_p(child.ctypes.data), C.c_void_p(data.ctypes.data), cap, N, dd,
                                             data_format.encode("ascii"), sc, of, device, t._flags(), C.byref(h)))

@@ -116,6 +116,33 @@ def test_packed_denoise_route_equals_the_fp32_maps_route(shape):
     assert torch.equal(out, ref)
 
 
+def test_packed_filter_refuses_images_of_another_extent():
+    """rto_filtering_packed is handed bare image pointers: it is told their extent and refuses one that differs from the
+    maps' -- a handle shared between contexts of different batch sizes cannot overrun the smaller one"""
+    _, fused = _nets(5)
+    dev = torch.device("cuda:0")
+    aux = torch.rand(3, 8, 40, 56, device=dev)
+    fused.reserve(3, 40, 56)  # the scratch at its final size: no allocation on the first forward
+    fused.forward_packed(aux)
+    noisy = torch.rand(3, 40, 56, 4, device=dev)
+    out = torch.empty_like(noisy)
+    fused.filter_packed(noisy, out, shape=(3, 40, 56))
+    for bad in ((1, 40, 56), (3, 56, 40), (4, 40, 56)):
+        with pytest.raises(R.RtoError) as e:
+            fused.filter_packed(noisy, out, shape=bad)
+        assert "packed maps hold 3 x 40 x 56" in str(e.value)
+    with pytest.raises(R.RtoError):  # host memory is not an image on the network's device
+        import numpy as np
+        host = np.zeros((3, 40, 56, 4), np.float32)
+        fused.filter_packed(noisy, host.ctypes.data, shape=(3, 40, 56))
+    # a smaller forward re-labels the maps: the old extent is now the wrong one
+    fused.forward_packed(aux[:1].contiguous())
+    with pytest.raises(R.RtoError):
+        fused.filter_packed(noisy, out, shape=(3, 40, 56))
+    fused.filter_packed(noisy[:1], out[:1], shape=(1, 40, 56))
+    torch.cuda.synchronize()
+
+
 def _emulate_fp16_network(compact, aux):
     """The reference's half pipeline (network.py:104-118 on a `.half()` module) in float64 with roundings at ITS points:
     fp16 input and weights, exact products and sums, + bias, ReLU6, round to fp16 after each layer.  What remains

@@ -172,6 +172,41 @@ def test_shading_from_the_aligned_copy_and_from_data_agree(basis):
 
 
 @pytest.mark.parametrize("basis", [9, 16])
+def test_compact_coefficient_records_render_the_same_pixels(basis, tmp_path):
+    """RTO_TREE_COMPACT_RECORDS: records only for the leaf slots of positive density, found through a per-slot index --
+    every kernel (fast, batched, generic after the rebuild) renders the oracle's pixels from half the resident bytes;
+    a negative sigma_thresh, under which a leaf without a record could be hit, is refused"""
+    tree = synth.make_tree(depth_limit=6, basis_dim=basis, seed=60 + basis)
+    ht, dt = make_pair(tree)
+    dc = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format, compact_records=True)
+    occupied = int(((tree.child.reshape(-1) == 0) & (tree.data[..., -1].reshape(-1).astype(np.float32) > 0)).sum())
+    rec_bytes = 64 if basis == 9 else 128
+    assert dt.device_bytes - dc.device_bytes == (tree.child.size - max(occupied, 1)) * rec_bytes - tree.child.size * 4
+    assert occupied < 0.7 * tree.child.size  # (the scene is mostly empty space: that is the point)
+    ocam, cam = cameras(80, 56, POSES[3])
+    want = oracle_frame(ht, ocam, 6, frame=4)
+    for kernel in (R.KERNEL_FAST, R.KERNEL_GENERIC):
+        aux, rgba, _ = hip_frame(dc, cam, 6, frame=4, kernel=kernel)
+        assert_bits_equal(aux, want[0], "aux kernel %d" % kernel)
+        assert_bits_equal(rgba, want[1], "rgba kernel %d" % kernel)
+    ctx = R.RenderContext(80, 56, frames=2)
+    R.launch_renderer_batch(dc, [cam, cam], R.RenderOptions(spp=6, denoise=False), ctx, rng_jumps=[4, 4])
+    for f in range(2):
+        ctx.select_frame(f)
+        assert_bits_equal(ctx.download_aux(), want[0], "batched slot %d" % f)
+    for launch in (lambda o: R.launch_renderer(dc, cam, o, ctx), lambda o: R.launch_renderer_batch(dc, [cam], o, ctx)):
+        with pytest.raises(R.RtoError) as e:
+            launch(R.RenderOptions(spp=6, denoise=False, sigma_thresh=-1.0))
+        assert "sigma_thresh must be >= 0" in str(e.value)
+    # from a file, with the flag of rto_tree_load_npz_ex
+    p = str(tmp_path / "t.npz")
+    tree.save_npz(p)
+    df = R.N3Tree(p, compact_records=True)
+    assert df.device_bytes == dc.device_bytes
+    assert_bits_equal(hip_frame(df, cam, 6, frame=4)[0], want[0], "from the file")
+
+
+@pytest.mark.parametrize("basis", [9, 16])
 def test_generic_kernel_on_a_tree_without_reference_arrays(basis):
     """the generic kernel (root-restart float descent over child[] / data[], the plain statement of the reference) on a
     tree whose upload released those arrays: they are rebuilt from the traversal image + the aligned copy on first

@@ -10,7 +10,7 @@ for SET in "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESS
            "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD" \
            "SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS"; do
   i=$((i+1))
-  rocprofv3 --pmc $SET --output-format csv -d $O/${TAG}_pmc_$i -- python3 $B > /dev/null 2> $O/${TAG}_pmc_$i.err || tail -2 $O/${TAG}_pmc_$i.err
+  timeout 300 rocprofv3 --pmc $SET --output-format csv -d $O/${TAG}_pmc_$i -- python3 $B > /dev/null 2> $O/${TAG}_pmc_$i.err || tail -2 $O/${TAG}_pmc_$i.err
 done
 python3 tools/pmc_summarize.py $O/${TAG}_pmc_summary.json $O/${TAG}_pmc_1 $O/${TAG}_pmc_2 $O/${TAG}_pmc_3 $O/${TAG}_pmc_4 | python3 -c "
 import json,sys

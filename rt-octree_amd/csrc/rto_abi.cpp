@@ -412,6 +412,8 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
     int top_levels = 0;
     if (t->fast_ok && max_depth >= 3) {
         // shortcut grid over the top levels: 2^(3G) x 8 B (2 MB at G = 6: L2-resident)
+        // (6 levels: measured again in round 3 with 7 waves per SIMD -- 5 levels 7.1-7.25 ms per 100 frames, 6: 6.88-7.0,
+        //  7 (16 MB): 6.85-6.96, 8 (134 MB): 6.93-6.99)
         top_levels = max_depth - 1 < 6 ? max_depth - 1 : 6;
         const size_t gbytes = (size_t)8 << (3 * top_levels);
         if (hipMalloc(&t->d_topgrid, gbytes) != hipSuccess) return fail(RTO_E_HIP, "hipMalloc(topgrid) failed");

@@ -480,7 +480,7 @@ def main():
 
     # frames of the last timed launch group, kept for the oracle spot check below (later passes reuse the buffers)
     spot_frames = []
-    if world == 1 and args.spot_pixels > 0 and not args.quant_direct and not args.tree:
+    if rank == 0 and args.spot_pixels > 0 and not args.quant_direct and not args.tree:  # (rank 0 checks its own frames at any N)
         lctx = lanes[last_lane][0]
         nlast = len(last_group[1])
         for slot in sorted({0, nlast // 2, nlast - 1}):

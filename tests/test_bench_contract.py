@@ -121,6 +121,7 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["frames_timed"] == 24 and d["value"] > 0
     assert d["cpu_baseline"] is None  # N == 1 only
+    assert d["parity_spot"]["mismatches"] == 0 and d["parity_spot"]["pixels_checked"] > 0  # rank 0 checks its frames at any N
     # the one collective of the path ran: 2 frames per rank gathered to rank 0, and the frame rank 1 rendered equals the
     # one rank 0 renders itself (images do not depend on N)
     fg = d["final_gather"]

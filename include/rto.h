@@ -190,7 +190,9 @@ int rto_ctx_set_kernel(rto_ctx* c, int kernel);
 /* Performance knobs; never change results.  key: "strip_rows" (single-frame kernel: tile rows per XCD
  * strip, >= 1); batched kernel: "refill" (0 = default; 100 * waves/SIMD + idle-lane threshold selects one of the A/B instantiations), "tile_order"
  * (0 = row-major tiles, 1 = centre-out), "xcd_queues" (1 = one ray queue per XCD over an image wedge
- * each, with stealing; 0 = a single queue). */
+ * each, with stealing; 0 = a single queue), "tile_major" / "tile_block" (queue order), "blocks_per_cu" (0 = as many
+ * workgroups of the persistent traversal kernel per CU as fit, else a cap 1..8: the kernel's true occupancy knob --
+ * `refill`'s waves/SIMD only sets the register budget). */
 int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value);
 /* Per-kernel HIP-event timing of the batched path: when enabled, every rto_launch_renderer_batch
  * records events before the traversal kernel, between it and the shading kernel, and after (on the

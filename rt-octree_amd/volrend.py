@@ -318,7 +318,8 @@ class RenderContext:
         return self._timer
 
     def set_tuning(self, key, value):
-        """performance knobs ("strip_rows", "refill", "tile_order", "xcd_queues", "tile_major", "tile_block"); results never change"""
+        """performance knobs ("strip_rows", "refill", "tile_order", "xcd_queues", "tile_major", "tile_block", "blocks_per_cu");
+        results never change"""
         check(lib().rto_ctx_set_tuning(self._h, key.encode("ascii"), int(value)))
 
     def kernel_timing(self, on=True):

@@ -438,6 +438,16 @@ def main():
     last_group, last_lane = work[-1], (len(work) - 1) % len(lanes)
 
     # ---------------- untimed: the reference's loop shape (one frame per launch, sync per frame) ----------------
+    # frames of the last timed launch group, kept for the oracle spot check below (later passes reuse the buffers)
+    spot_frames = []
+    if rank == 0 and args.spot_pixels > 0 and not args.quant_direct and not args.tree:  # (rank 0 checks its own frames at any N)
+        lctx = lanes[last_lane][0]
+        nlast = len(last_group[1])
+        for slot in sorted({0, nlast // 2, nlast - 1}):
+            lctx.select_frame(slot)
+            spot_frames.append((last_group[0], last_group[1][slot], lctx.download_aux(stream=lanes[last_lane][1])))
+        lctx.select_frame(0)
+
     # ---------------- untimed, N > 1: the path's one collective -- the final gather of RGBA8 frames to rank 0 ----------------
     # (rt-octree_amd/sharding.py gather_frames: one padded all_gather, RCCL over xGMI with device tensors; the same code
     #  tests/test_sharding.py runs over gloo on CPUs and, given two GPUs, over RCCL.)  K frames per rank, global frame
@@ -477,16 +487,6 @@ def main():
                           "frame_of_rank_1_rendered_on_rank_0_is_identical": same,
                           "note": "sharding.gather_frames: one padded all_gather of uint8 [K,H,W,4] per rank (host -> device -> "
                                   "RCCL -> host, untimed plumbing); the timed region has no collective"}
-
-    # frames of the last timed launch group, kept for the oracle spot check below (later passes reuse the buffers)
-    spot_frames = []
-    if rank == 0 and args.spot_pixels > 0 and not args.quant_direct and not args.tree:  # (rank 0 checks its own frames at any N)
-        lctx = lanes[last_lane][0]
-        nlast = len(last_group[1])
-        for slot in sorted({0, nlast // 2, nlast - 1}):
-            lctx.select_frame(slot)
-            spot_frames.append((last_group[0], last_group[1][slot], lctx.download_aux(stream=lanes[last_lane][1])))
-        lctx.select_frame(0)
 
     ref_loop = None
     if args.ref_loop_frames > 0 and not args.quant_direct:

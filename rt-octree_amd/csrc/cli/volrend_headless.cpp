@@ -269,7 +269,10 @@ int run_multi_gpu(int argc, char** argv, int gpus) {
 }  // namespace
 
 int main(int argc, char** argv) {
-    const Args args = parse(argc, argv);
+    Args args = parse(argc, argv);
+    // `--file tree.npz` names the tree like the first positional argument does (opts.cpp:12,36: parse_positional({"file"}));
+    // `--draw` (a GUI draw list) is accepted and ignored
+    if (args.has("file")) args.positional.insert(args.positional.begin(), args.get("file", ""));
     if (args.has("help") || args.positional.size() < 2) {
         usage();
         return args.has("help") ? 0 : 1;

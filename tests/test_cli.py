@@ -210,6 +210,9 @@ def test_cli_pose_loader_blender(tmp_path):
     for i in range(5):
         assert np.allclose(m[i], poses[i][:3, :4].T.astype(np.float32), atol=1e-6)  # column-major 4x3
     assert "Use NeRF camera convention" in r.stdout
+    # `--file` names the tree like the first positional does (opts.cpp:12,36); `--draw` is accepted and ignored
+    r2 = _run(["--file", "unused.npz", pp, "--print_poses", "-w", "400", "-h", "400", "--draw", "x.draw.npz"])
+    assert r2.returncode == 0 and r2.stdout == r.stdout
 
 
 def test_cli_gpus_flag_shards_the_poses_over_child_processes(tmp_path):

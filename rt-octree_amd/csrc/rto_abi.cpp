@@ -10,6 +10,7 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -93,7 +94,7 @@ struct rto_tree {
     // Footprint (VERDICT r2 task 8): a dense SH9 / SH16 tree that renders through the fast / batched kernels reads only
     // nodew + topgrid + shrec, so child[] / data[] are released after the upload and rebuilt from those two on the first
     // launch that selects the generic kernel (ensure_reference_arrays).  RTO_TREE_KEEP_REFERENCE keeps them resident.
-    bool reference_dropped = false;
+    std::atomic<bool> reference_dropped{false};  // (read outside rebuild_mutex: the usual double-checked test)
     int shrec_halves = 0;
     std::mutex rebuild_mutex;
 };

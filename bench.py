@@ -14,8 +14,8 @@ beside it.  Every image is bit-identical to rendering the poses one by one (test
 
 Inputs are synthetic (no dataset exists on either machine): a seeded lego-like SH16 PlenOctree of
 ~2.1 M nodes, a 200-pose blender orbit, the GuidanceNet trained by tools/train_guidance.py.
-Everything is resident in HBM before the timed region.  Frames shard across ranks (pose i -> rank
-i mod N, RNG jump-ahead per pose so every image equals the 1-GPU run); no data-path collective exists
+Everything is resident in HBM before the timed region.  Frames shard across ranks (frame g -> pose g of a 200 x N pose
+orbit -> rank g mod N, RNG jump-ahead per pose so an image does not depend on who renders it); no data-path collective exists
 or is invented -- the only collectives are the barrier and the max-reduction of the elapsed time.
 --scenes K (config C3): K different synthetic scenes; --scene-map pose (every rank holds every scene,
 frame g -> rank g mod N) or scene (scene s -> rank s mod N), or both.
@@ -163,6 +163,14 @@ C4_ARGS = ["--width", "1920", "--height", "1080", "--basis", "25", "--depth", "1
            "--cam-radius", "2.6"]
 
 
+def n_poses_for(world):
+    """Poses of the synthetic orbit.  One GPU renders the reference's 200-pose test trajectory; N ranks render an orbit N
+    times as dense, frame g -> pose g -> rank g mod N: every rank's launch groups then hold DISTINCT poses at the angular
+    spacing of the 1-GPU run (1/200 of the orbit) -- with 200 poses over 8 ranks a 100-frame group would hold every pose
+    four times, and four identical frames per launch flatter the caches (weak scaling must not get easier per GPU)."""
+    return 200 * max(1, int(world))
+
+
 def scenes_of_rank(rank, world, n_scenes, scene_map):
     """scenes a rank must hold: all of them when frames are interleaved, its own share when scenes are dealt out"""
     if n_scenes == 1 or scene_map == "pose":
@@ -210,7 +218,7 @@ def plan_only(args):
     B = max(1, min(128, args.batch))
     n_scenes = 1 if args.tree else max(1, min(8, args.scenes))
     maps = ["pose", "scene"] if n_scenes > 1 else ["pose"]
-    mine = {m: plan_groups(args.steps * B, B, rank, world, 200, n_scenes, m) for m in maps}
+    mine = {m: plan_groups(args.steps * B, B, rank, world, n_poses_for(world), n_scenes, m) for m in maps}
     plans = [mine]
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -292,7 +300,7 @@ def main():
     trees = {s: R.N3Tree(paths[s], device=local_rank, quant_direct=args.quant_direct, compact_records=args.compact_records)
              for s in sorted(need)}  # tree.npz -> device
     tree = trees[min(trees)]
-    poses = synth.orbit_poses(200, radius=args.cam_radius)
+    poses = synth.orbit_poses(n_poses_for(world), radius=args.cam_radius)
     fx = args.fx if args.fx > 0 else synth.blender_focal(W)
     cams = []
     for p in poses:

@@ -110,6 +110,16 @@ def test_bench_schedule_partitions_frames_over_ranks():
                 assert {sc for sc, _ in (b.pose_schedule(s, r, world, 200, K, m) for s in range(per_rank))} == set(b.scenes_of_rank(r, world, K, m))
                 for sc, idx in b.plan_groups(per_rank, 32, r, world, 200, K, m):
                     assert 1 <= len(idx) <= 32 and len(set(idx)) == len(idx)
+    # N ranks render an orbit N times as dense: a 100-frame launch group never holds a pose twice, and a rank's consecutive
+    # poses are as far apart as the 1-GPU run's (1/200 of the orbit)
+    for world in (1, 2, 4, 8):
+        n = b.n_poses_for(world)
+        assert n == 200 * world
+        for r in range(world):
+            for sc, idx in b.plan_groups(300, 100, r, world, n, 1, "pose"):
+                assert len(set(idx)) == len(idx) == 100 and all(p % world == r for p in idx)
+                steps = {(idx[k + 1] - idx[k]) % n for k in range(len(idx) - 1)}
+                assert steps == {world}
     # more ranks than scenes: every rank still has work
     assert b.scenes_of_rank(5, 8, 3, "scene") == [2]
 

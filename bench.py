@@ -444,6 +444,11 @@ def main():
         group(work[-1][0], work[-1][1], None, (len(work) - 1) % len(lanes))  # leave the headline route's frames in the buffers
         torch.cuda.synchronize(dev)
     last_group, last_lane = work[-1], (len(work) - 1) % len(lanes)
+    # empty-space culling: the share of 8x8 tile slots of the last launch group that was marched at all
+    try:
+        live_slots, all_slots = lanes[last_lane][0].queue_stats()
+    except Exception:
+        live_slots, all_slots = None, None
 
     # ---------------- untimed: the reference's loop shape (one frame per launch, sync per frame) ----------------
     # frames of the last timed launch group, kept for the oracle spot check below (later passes reuse the buffers)
@@ -850,6 +855,10 @@ def main():
         "measured_copy_bw": copy_gbps,
         "launches": kt["launches"], "frames_per_launch": frames_per_launch,
         "shade_kernel_avg_launch_ms": kt["shade_ms"], "thresholds_kernel_avg_launch_ms": kt["raygen_ms"],
+        "tiles_marched_frac": (live_slots / all_slots) if all_slots else None,
+        "culling_note": "8x8-pixel tiles that no culling cell of the tree projects into hold only rays that never meet density: they are "
+                        "background pixels without marching (bit-identical, tests/test_culling.py); thresholds_kernel_avg_launch_ms "
+                        "covers tile marking + queue lists + threshold draws; the ALGORITHMIC figures still price every ray",
         "units_per_frame": {k: v / count_steps for k, v in units.items()},
         "tcp": tcp,
         "valu": valu,

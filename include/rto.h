@@ -143,6 +143,11 @@ int rto_tree_load_npz(const char* path, int device, rto_tree** out);
  * dependent gather per hit leaf (measured: DESIGN.md section 3).  Launches with sigma_thresh < 0 are refused for such a
  * tree (RTO_E_UNSUPPORTED).  Ignored where no aligned copy is built (RTO_TREE_COMPACT, SH25, RGBA, quantised-direct). */
 #define RTO_TREE_COMPACT_RECORDS 8
+/* RTO_TREE_NO_CULLING: do not build the empty-space culling cells (the batched path then marches every ray, as rounds 1-2
+ * did).  By default an N == 2 tree carries the cubes (no finer than 1/128 of the volume) that contain its leaves of
+ * positive density; every batched launch projects them into its frames and skips the 8x8-pixel tiles none of them
+ * touches -- rays that provably never meet density are background pixels.  Same pixels either way. */
+#define RTO_TREE_NO_CULLING 16
 int rto_tree_load_npz_ex(const char* path, int device, int flags, rto_tree** out);
 /* Same upload from host arrays: child int32 [capacity*N^3], data fp16 bits
  * [capacity*N^3*data_dim], data_format like "SH9"/"SH16"/"RGBA" (DataFormat::parse,
@@ -190,7 +195,7 @@ int rto_ctx_set_kernel(rto_ctx* c, int kernel);
 /* Performance knobs; never change results.  key: "strip_rows" (single-frame kernel: tile rows per XCD
  * strip, >= 1); batched kernel: "refill" (0 = default; 100 * waves/SIMD + idle-lane threshold selects one of the A/B instantiations), "tile_order"
  * (0 = row-major tiles, 1 = centre-out), "xcd_queues" (1 = one ray queue per XCD over an image wedge
- * each, with stealing; 0 = a single queue), "tile_major" / "tile_block" (queue order), "blocks_per_cu" (0 = as many
+ * each, with stealing; 0 = a single queue), "tile_major" / "tile_block" (queue order), "cull" (1 = skip the tiles whose rays provably meet no density, the default; 0 = march every ray), "blocks_per_cu" (0 = as many
  * workgroups of the persistent traversal kernel per CU as fit, else a cap 1..8: the kernel's true occupancy knob --
  * `refill`'s waves/SIMD only sets the register budget). */
 int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value);
@@ -198,6 +203,10 @@ int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value);
  * records events before the traversal kernel, between it and the shading kernel, and after (on the
  * launch stream; up to 256 launches between reads).  _read synchronises on the recorded events and
  * returns the mean milliseconds per launch of each kernel, then resets the ring. */
+/* Diagnostic (synchronises the device): of the last rto_launch_renderer_batch on this context, how many 8x8-pixel tile
+ * slots (tile x frame) were marched and how many there were -- the rest were culled as provably empty (see
+ * RTO_TREE_NO_CULLING; tuning key "cull" = 0 switches the culling off per context). */
+int rto_ctx_queue_stats(rto_ctx* c, int64_t* live_tile_slots, int64_t* all_tile_slots);
 int rto_ctx_kernel_timing(rto_ctx* c, int enable);
 int rto_ctx_kernel_timing_read(rto_ctx* c, float* traverse_ms, float* shade_ms, int* launches);
 /* the same with the thresholds kernel (sample_kernel: RNG jump, SPP draws, sort for every pixel of the batch) reported too,

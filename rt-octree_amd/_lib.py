@@ -82,6 +82,7 @@ SYMBOLS = {
     "rto_ctx_rng_get": (None, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rto_ctx_set_kernel": (C.c_int, [_P, C.c_int]),
     "rto_ctx_set_tuning": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "rto_ctx_queue_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rto_ctx_kernel_timing": (C.c_int, [_P, C.c_int]),
     "rto_ctx_kernel_timing_read": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "rto_ctx_kernel_timing_read3": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),

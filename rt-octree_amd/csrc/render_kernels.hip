@@ -742,34 +742,191 @@ struct RayState {
 constexpr uint32_t kGridNext = 0xffffffffu;
 constexpr int kCamFloats = 14;  // fx, fy, transform[12]: what a ray set-up reads of a FrameDesc
 
-// position p of a ray queue -> (frame, x, y).  The queue holds `qtiles` tiles per frame, frame after
-// frame, 64 rays per 8x8 tile: tile_order[qt0 + j] (ty << 16 | tx) or, without a table, row-major
-// tile qt0 + j.  Returns false for padding (tile overhanging the image).
-RTO_DEV bool ray_pixel(uint32_t p, uint32_t qt0, uint32_t qtiles, uint32_t n_frames, bool tile_major, int tiles8_x,
-                       int width, int height, const uint32_t* __restrict__ tile_order, int& frame, int& x, int& y) {
-    int tile;
-    const int l = (int)(p & 63u);
-    const uint32_t pt = p >> 6;  // tile slot within the queue
-    if (tile_major) {  // slot = tile * n_frames + frame
-        const uint32_t t = pt / n_frames;
-        frame = (int)(pt - t * n_frames);
-        tile = (int)(qt0 + t);
-    } else {  // slot = frame * qtiles + tile
-        frame = (int)(pt / qtiles);
-        tile = (int)(qt0 + (pt - (uint32_t)frame * qtiles));
+// ------------------------------------------------------------------ empty-space culling + ray queues (round 3)
+// A ray that never meets a leaf of positive density composites nothing: its pixel is the background, its hit list empty
+// (rt_core.cuh:252-262 only ever accumulates in leaves with sigma > sigma_thresh).  73 % of the bench scene's rays are such
+// rays and a third of all march steps are theirs.  mark_tiles_kernel decides it per 8x8-pixel tile, conservatively and
+// without marching: every culling cell of the tree (TreeDev::occ_cells: world-space bounding spheres of the cubes that hold
+// the leaves of positive density, radius padded far above the float error of a sample point) is projected into every
+// frame of the batch; the tiles its projection can touch are marked.  An unmarked tile holds no ray that passes within a
+// sphere, hence no ray that visits a dense leaf: its rays are never queued, its pixels get no threshold draws.  The bound:
+// with the cell centre at camera coordinates (a, b, -d), d > 2 r, every point of the sphere lands within
+// f r / (d - r) (1 + |a| / d) pixels of the centre's pixel along x (same with b along y) -- from
+// |a'/d' - a/d| <= (r d + |a| r) / (d (d - r)).  A sphere nearer than that marks the whole frame; one behind the
+// camera nothing.  (Pixels are bit-identical with and without: tests/test_culling.py, and every parity test against the
+// oracle, which marches every ray, runs with it.)
+// One workgroup = kMarkCells cells of one frame, marked into a private copy of the frame's mask in LDS (LDS_MASK; a frame
+// of more than kMarkLdsWords * 32 tiles marks straight into memory) that is OR-ed into the frame's mask once at the end:
+// tens of thousands of cells land on a few hundred mask words, and device-scope atomics on one address serialise
+// (the first version, one global atomic per cell and tile, took 2.5 ms per 100 frames; this one 0.1).
+constexpr int kMarkCells = 2048, kMarkLdsWords = 8192;
+template <class MarkFn>
+RTO_DEV void mark_cell(const float4 cell, const FrameDesc& fd, const FrameBatch& fb, MarkFn mark);
+template <bool LDS_MASK>
+__global__ void __launch_bounds__(256) mark_tiles_kernel(const TreeDev tree, const FrameBatch fb, uint32_t* __restrict__ mask) {
+    extern __shared__ uint32_t s_mask[];
+    const FrameDesc& fd = fb.f[blockIdx.y];
+    uint32_t* const gm = mask + (size_t)blockIdx.y * fb.mask_words;
+    if (LDS_MASK) {
+        for (int i = threadIdx.x; i < fb.mask_words; i += 256) s_mask[i] = 0u;
+        __syncthreads();
     }
-    int ty, tx;
-    if (tile_order) {
-        const uint32_t code = tile_order[tile];
-        ty = (int)(code >> 16);
-        tx = (int)(code & 0xffffu);
+    for (int c = (int)blockIdx.x * kMarkCells + (int)threadIdx.x; c < tree.n_occ_cells && c < ((int)blockIdx.x + 1) * kMarkCells; c += 256)
+        if (LDS_MASK)
+            mark_cell(tree.occ_cells[c], fd, fb, [&](uint32_t w, uint32_t bits) { atomicOr(&s_mask[w], bits); });  // ds_or_b32
+        else
+            mark_cell(tree.occ_cells[c], fd, fb, [&](uint32_t w, uint32_t bits) { atomicOr(gm + w, bits); });
+    if (LDS_MASK) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < fb.mask_words; i += 256)
+            if (s_mask[i]) atomicOr(gm + i, s_mask[i]);
+    }
+}
+
+template <class MarkFn>
+RTO_DEV void mark_cell(const float4 cell, const FrameDesc& fd, const FrameBatch& fb, MarkFn mark) {
+    {
+    const float* m = fd.transform;  // columns 0..2: camera axes, column 3: centre (common.cuh:29-44)
+    const float p[3] = {cell.x - m[9], cell.y - m[10], cell.z - m[11]};
+    // camera coordinates (a, b, cc) of the cell centre: M (a, b, cc)^T = p (Cramer; M need not be orthonormal)
+    const float c12[3] = {m[4] * m[8] - m[5] * m[7], m[5] * m[6] - m[3] * m[8], m[3] * m[7] - m[4] * m[6]};
+    const float c20[3] = {m[7] * m[2] - m[8] * m[1], m[8] * m[0] - m[6] * m[2], m[6] * m[1] - m[7] * m[0]};
+    const float c01[3] = {m[1] * m[5] - m[2] * m[4], m[2] * m[3] - m[0] * m[5], m[0] * m[4] - m[1] * m[3]};
+    const float det = m[0] * c12[0] + m[1] * c12[1] + m[2] * c12[2];
+    const float inv = 1.f / det;
+    const float a = (p[0] * c12[0] + p[1] * c12[1] + p[2] * c12[2]) * inv;
+    const float b = (p[0] * c20[0] + p[1] * c20[1] + p[2] * c20[2]) * inv;
+    const float d = -(p[0] * c01[0] + p[1] * c01[1] + p[2] * c01[2]) * inv;  // depth along the viewing direction (0, 0, -1)
+    // |M^-1| <= its Frobenius norm: the sphere's radius in camera coordinates
+    const float frob = sqrtf(c12[0] * c12[0] + c12[1] * c12[1] + c12[2] * c12[2] + c20[0] * c20[0] + c20[1] * c20[1] + c20[2] * c20[2] +
+                             c01[0] * c01[0] + c01[1] * c01[1] + c01[2] * c01[2]) * fabsf(inv);
+    const float r = cell.w * frob * 1.0001f;
+    if (d <= -r) return;    // wholly behind the camera (a NaN pose falls through to "keep everything")
+    if (!(d > 2.f * r)) {   // too close for the bound: keep every tile of this frame
+        mark((uint32_t)fb.mask_words - 1u, 1u);
+        return;
+    }
+    const float xs = a / d, ys = b / d;
+    const float k = r / (d - r);
+    const float fx = fabsf(fd.fx), fy = fabsf(fd.fy);
+    const float pxc = 0.5f * fb.width + fd.fx * xs, pyc = 0.5f * fb.height - fd.fy * ys;  // volrend.cu:139-141 inverted
+    const float rx = fx * k * (1.f + fabsf(xs)) + 1.5f, ry = fy * k * (1.f + fabsf(ys)) + 1.5f;
+    const int tiles_x = (fb.width + 7) >> 3, tiles_y = (fb.height + 7) >> 3;
+    const float x0f = floorf((pxc - rx) * 0.125f), x1f = floorf((pxc + rx) * 0.125f);
+    const float y0f = floorf((pyc - ry) * 0.125f), y1f = floorf((pyc + ry) * 0.125f);
+    if (!(x1f >= 0.f && y1f >= 0.f && x0f < (float)tiles_x && y0f < (float)tiles_y)) {
+        if (!(x0f == x0f && y0f == y0f)) mark((uint32_t)fb.mask_words - 1u, 1u);  // NaN: keep everything
+        return;
+    }
+    const int x0 = x0f < 0.f ? 0 : (int)x0f, x1 = x1f >= (float)tiles_x ? tiles_x - 1 : (int)x1f;
+    const int y0 = y0f < 0.f ? 0 : (int)y0f, y1 = y1f >= (float)tiles_y ? tiles_y - 1 : (int)y1f;
+    for (int ty = y0; ty <= y1; ++ty)
+        for (int tx = x0; tx <= x1; ++tx) {
+            const uint32_t t = (uint32_t)(ty * tiles_x + tx);
+            mark(t >> 5, 1u << (t & 31u));
+        }
+    }
+}
+
+RTO_DEV bool tile_marked(const FrameBatch& fb, int frame, uint32_t tile_index) {
+    const uint32_t* fm = fb.tile_mask + (size_t)frame * fb.mask_words;
+    return ((fm[tile_index >> 5] >> (tile_index & 31u)) | fm[fb.mask_words - 1]) & 1u;
+}
+
+// Tile slot `pt` of queue k -> is it live, and its list entry {frame << 20 | ty << 10 | tx}.  The queue order: the tiles
+// tile_order[qstart[k] .. qstart[k+1]) (ty << 16 | tx; row-major tiles without a table), tile after tile -- the same tile of
+// every frame of the batch in turn (neighbouring poses see nearly the same rays through a tile) -- or frame after frame.
+RTO_DEV bool queue_slot(const FrameBatch& fb, int k, uint32_t pt, uint32_t& entry) {
+    const uint32_t qt0 = (uint32_t)fb.qstart[k], qtiles = (uint32_t)fb.qstart[k + 1] - qt0, n = (uint32_t)fb.n;
+    if (pt >= qtiles * n) return false;
+    uint32_t tile, frame;
+    if (fb.tile_major) {
+        const uint32_t t = pt / n;
+        frame = pt - t * n;
+        tile = qt0 + t;
     } else {
-        ty = tile / tiles8_x;
-        tx = tile - ty * tiles8_x;
+        frame = pt / qtiles;
+        tile = qt0 + (pt - frame * qtiles);
     }
-    x = tx * 8 + (l & 7);  // (Z-order inside the tile was tried: no fewer L1 accesses)
-    y = ty * 8 + (l >> 3);
-    return x < width && y < height;
+    const uint32_t tiles_x = (uint32_t)(fb.width + 7) >> 3;
+    uint32_t tx, ty;
+    if (fb.tile_order) {
+        const uint32_t code = fb.tile_order[tile];
+        ty = code >> 16;
+        tx = code & 0xffffu;
+    } else {
+        ty = tile / tiles_x;
+        tx = tile - ty * tiles_x;
+    }
+    entry = frame << 20 | ty << 10 | tx;
+    return tile_marked(fb, (int)frame, ty * tiles_x + tx);
+}
+
+// queue k of a compaction chunk (the chunks of a queue are consecutive: fb.qchunk)
+RTO_DEV int chunk_queue(const FrameBatch& fb, uint32_t chunk) {
+    int k = 0;
+    while (k + 1 < fb.n_queues && chunk >= (uint32_t)fb.qchunk[k + 1]) ++k;
+    return k;
+}
+
+__global__ void __launch_bounds__(kQueueChunk) queue_count_kernel(const FrameBatch fb) {
+    __shared__ uint32_t s_w[kQueueChunk / 64];
+    const int k = chunk_queue(fb, blockIdx.x);
+    uint32_t entry;
+    const bool live = queue_slot(fb, k, (blockIdx.x - (uint32_t)fb.qchunk[k]) * kQueueChunk + threadIdx.x, entry);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(live);
+    if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kQueueChunk / 64; ++w) t += s_w[w];
+        fb.chunk_count[blockIdx.x] = t;
+    }
+}
+
+// exclusive scan of the chunk counts, queue by queue (one workgroup: a few thousand chunks)
+__global__ void __launch_bounds__(256) queue_scan_kernel(const FrameBatch fb) {
+    __shared__ uint32_t s_v[256];
+    __shared__ uint32_t s_carry;
+    for (int k = 0; k < fb.n_queues; ++k) {
+        if (threadIdx.x == 0) s_carry = 0;
+        __syncthreads();
+        for (int c0 = fb.qchunk[k]; c0 < fb.qchunk[k + 1]; c0 += 256) {
+            const int c = c0 + (int)threadIdx.x;
+            const uint32_t v = c < fb.qchunk[k + 1] ? fb.chunk_count[c] : 0u;
+            s_v[threadIdx.x] = v;
+            __syncthreads();
+            for (int d = 1; d < 256; d <<= 1) {  // Hillis-Steele inclusive scan
+                const uint32_t t = threadIdx.x >= (unsigned)d ? s_v[threadIdx.x - d] : 0u;
+                __syncthreads();
+                s_v[threadIdx.x] += t;
+                __syncthreads();
+            }
+            const uint32_t carry = s_carry;
+            if (c < fb.qchunk[k + 1]) fb.chunk_base[c] = carry + s_v[threadIdx.x] - v;
+            __syncthreads();
+            if (threadIdx.x == 255) s_carry = carry + s_v[255];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) fb.qcount[k] = s_carry;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(kQueueChunk) queue_write_kernel(const FrameBatch fb) {
+    __shared__ uint32_t s_w[kQueueChunk / 64];
+    const int k = chunk_queue(fb, blockIdx.x);
+    uint32_t entry = 0;
+    const bool live = queue_slot(fb, k, (blockIdx.x - (uint32_t)fb.qchunk[k]) * kQueueChunk + threadIdx.x, entry);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(live);
+    if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (!live) return;
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += s_w[w];
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    fb.qlist[(size_t)fb.qstart[k] * (uint32_t)fb.n + fb.chunk_base[blockIdx.x] + before + rank] = entry;
 }
 
 // sample_dst (rt_core.cuh:67-193) for every pixel of the batch, at full lane utilisation: the RNG
@@ -781,6 +938,13 @@ __global__ void __launch_bounds__(256) sample_kernel(const FrameBatch fb, const 
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= SIZE) return;
     const FrameDesc& fd = fb.f[blockIdx.y];
+    if (fb.tile_mask) {  // a pixel of a culled tile: an empty hit list, no draws (its RNG stream is its own: nobody observes them)
+        const uint32_t y = idx / (uint32_t)fb.width, x = idx - y * (uint32_t)fb.width;
+        if (!tile_marked(fb, (int)blockIdx.y, (y >> 3) * ((uint32_t)(fb.width + 7) >> 3) + (x >> 3))) {
+            fd.hits[hit_index<SPP>(idx, 0u, SIZE)] = 0u;
+            return;
+        }
+    }
     Pcg32 rng;
     rng.state = fd.rng_state;
     rng.inc = fd.rng_inc;
@@ -814,7 +978,7 @@ template <int SPP, int REFILL, int WPS>
 __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, const OptDev opt, const FrameBatch fb,
                                                        unsigned long long* __restrict__ queue,
                                                        uint32_t* __restrict__ hits, const uint32_t chunk) {
-    // queue[8 + 8k]: next ray of queue k (zeroed on the stream before the launch)
+    // queue[8 + 8k]: next ray of queue k's list (zeroed on the stream before the launch)
     // LDS: [max_depth+1-top_levels][256] ancestor stack | [SPP+1][256] sorted thresholds | frame table
     extern __shared__ uint32_t s_mem[];
     const int tid = threadIdx.x;
@@ -825,6 +989,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     // per launch the table then leaves room for 8 workgroups per CU)
     float* s_cams = reinterpret_cast<float*>(s_mem + (size_t)(stack_levels + SPP + 1) * 256);
     __shared__ int s_qstart[kMaxQueues + 1];
+    __shared__ uint32_t s_qcount[kMaxQueues];  // live tile slots of each queue (queue_scan_kernel)
     static_assert(offsetof(FrameDesc, transform) == 8 && kCamFloats == 14, "s_cams copies the first 14 floats of a FrameDesc");
     for (int i = tid; i < fb.n * kCamFloats; i += 256) {  // device memory -> LDS
         const int f = i / kCamFloats;
@@ -833,24 +998,26 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
 #pragma unroll
     for (int k = 0; k <= kMaxQueues; ++k)
         if (tid == 64 + k) s_qstart[k] = fb.qstart[k];
+#pragma unroll
+    for (int k = 0; k < kMaxQueues; ++k)
+        if (tid == 128 + k) s_qcount[k] = k < fb.n_queues ? fb.qcount[k] : 0u;
     __syncthreads();
 
     const int W = fb.width, H = fb.height;
     const uint32_t SIZE = (uint32_t)W * (uint32_t)H;
     const uint32_t hstride = kHitsPixelMajor ? 1u : SIZE;  // distance between consecutive entries of one pixel
-    const int tiles8_x = (W + 7) >> 3;
     // the queue this wave draws from first: the one of the XCD it runs on (HW_REG_XCC_ID bits 3:0)
     const uint32_t n_queues = (uint32_t)fb.n_queues;
     uint32_t cur_q = n_queues > 1 ? ((uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % n_queues) : 0u;
     uint32_t q_tried = 0;            // queues found empty so far (wave-uniform)
-    uint32_t res_t0 = 0, res_tiles = 1;  // tile range of the queue the reservoir was drawn from
+    uint32_t res_off = 0;            // list offset of the queue the reservoir was drawn from (wave-uniform)
 
     // Loop-invariant scalars pinned in SGPRs: hipcc otherwise re-loads them from the kernarg segment inside the descent loop (an s_load +
     // lgkmcnt(0) round trip per level).
     typedef const __attribute__((address_space(1))) uint32_t* gptr_t;  // keep global_load (not flat_load)
     const uint32_t* nodew_p = tree.nodew;
     const uint2* topgrid_p = tree.topgrid;
-    const uint32_t* __restrict__ tile_order = fb.tile_order;
+    const uint32_t* __restrict__ qlist = fb.qlist;
     float step_size = opt.step_size, sigma_thresh = opt.sigma_thresh;
     asm volatile("" : "+s"(nodew_p), "+s"(topgrid_p), "+s"(step_size), "+s"(sigma_thresh));
     const gptr_t nodew = (gptr_t)nodew_p;
@@ -893,16 +1060,14 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                 if (res_next == res_end) {
                     for (;;) {  // own queue first, then the others in turn (wave-uniform)
                         const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane(s_qstart[cur_q]);
-                        const uint32_t t1 = (uint32_t)__builtin_amdgcn_readfirstlane(s_qstart[cur_q + 1]);
-                        const uint32_t qtotal = (t1 - t0) * 64u * (uint32_t)fb.n;
+                        const uint32_t qtotal = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_qcount[cur_q]) * 64u;  // live rays
                         unsigned long long base = 0;
                         if ((tid & 63) == 0) base = atomicAdd(queue + 8 + 8 * cur_q, (unsigned long long)kChunk);
                         const uint32_t base32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
                         if (base32 < qtotal) {  // a counter never exceeds qtotal + kChunk * waves: fits 32 bits
                             res_next = base32;
                             res_end = base32 + kChunk < qtotal ? base32 + kChunk : qtotal;
-                            res_t0 = t0;
-                            res_tiles = t1 - t0;
+                            res_off = t0 * (uint32_t)fb.n;
                             break;
                         }
                         if (++q_tried >= n_queues) {
@@ -920,8 +1085,13 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32),
                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
                     const uint32_t r = first + rank;
-                    int frame, x, y;
-                    if (rank < take && ray_pixel(r, res_t0, res_tiles, (uint32_t)fb.n, fb.tile_major != 0, tiles8_x, W, H, tile_order, frame, x, y)) {
+                    // ray r of the queue: lane (r & 63) of the live tile slot qlist[.. + (r >> 6)] = {frame, tile y, tile x}
+                    // (the lists hold marked tiles only: every ray handed out can meet density or at least crosses near it)
+                    const uint32_t entry = rank < take ? qlist[res_off + (r >> 6)] : 0u;
+                    const int frame = (int)(entry >> 20);
+                    const int x = (int)(entry & 1023u) * 8 + (int)(r & 7u);  // (Z-order inside the tile was tried: no fewer L1 accesses)
+                    const int y = (int)((entry >> 10) & 1023u) * 8 + (int)((r >> 3) & 7u);
+                    if (rank < take && x < W && y < H) {
                         const float* fd = s_cams + frame * kCamFloats;
                         CamDev cam;
                         cam.width = W;
@@ -1535,7 +1705,7 @@ hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev&
 template <int SPP, int REFILL, int WPS>
 static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                     const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
-                                    int chunk_override, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
+                                    int chunk_override, bool cull, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
     // dynamic LDS: ancestor stack + thresholds per lane, then the frame table of THIS batch (96 B per frame: a batch of
     // one does not pay for 128)
     const size_t lds = (size_t)(tree.max_depth + 1 - tree.top_levels + SPP + 1) * 256 * sizeof(uint32_t) +
@@ -1570,6 +1740,21 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
                                               : (rays_per_wave >= 2048 ? 256u : rays_per_wave >= 512 ? 128u : 64u);
     const int64_t size = (int64_t)fb.width * fb.height;
     if (ev) (void)hipEventRecord(ev[0], stream);
+    // tile marks (empty-space culling; all ones when it is off), then the ray queues as lists of the marked tile slots
+    uint32_t* mask = const_cast<uint32_t*>(fb.tile_mask);
+    const size_t mask_bytes = (size_t)fb.n * fb.mask_words * sizeof(uint32_t);
+    if (hipMemsetAsync(mask, cull ? 0 : 0xff, mask_bytes, stream) != hipSuccess) return hipErrorLaunchFailure;
+    if (cull && tree.n_occ_cells > 0) {
+        const dim3 mgrid((unsigned)((tree.n_occ_cells + kMarkCells - 1) / kMarkCells), fb.n);
+        if (fb.mask_words <= kMarkLdsWords)
+            hipLaunchKernelGGL(mark_tiles_kernel<true>, mgrid, dim3(256), (size_t)fb.mask_words * sizeof(uint32_t), stream, tree, fb, mask);
+        else
+            hipLaunchKernelGGL(mark_tiles_kernel<false>, mgrid, dim3(256), 0, stream, tree, fb, mask);
+    }
+    const unsigned n_chunks = (unsigned)fb.qchunk[fb.n_queues];
+    hipLaunchKernelGGL(queue_count_kernel, dim3(n_chunks), dim3(kQueueChunk), 0, stream, fb);
+    hipLaunchKernelGGL(queue_scan_kernel, dim3(1), dim3(256), 0, stream, fb);
+    hipLaunchKernelGGL(queue_write_kernel, dim3(n_chunks), dim3(kQueueChunk), 0, stream, fb);
     hipLaunchKernelGGL(sample_kernel<SPP>, dim3((unsigned)((size + 255) / 256), fb.n), dim3(256), 0, stream, fb, jump);
     // arm the ray queues on the launch stream (576 B): a launch never depends on how the previous one on
     // this context ended
@@ -1610,11 +1795,11 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
 template <int SPP>
 static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                    const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
-                                   int refill, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
+                                   int refill, bool cull, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
     const int chunk_override = (refill / 1000) * 64;  // tuning: refill = 1000 * tiles_per_dequeue + threshold
     refill %= 1000;
     if constexpr (SPP == 6) {  // tuning instantiations only for the benchmark configuration
-#define RTO_F(R, O) return launch_batch_impl<SPP, R, O>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, occ, ev, stream)
+#define RTO_F(R, O) return launch_batch_impl<SPP, R, O>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream)
         switch (refill) {  // A/B set kept for tools/ab_tuning.py: 100 * waves/SIMD + refill threshold
             case 808: RTO_F(8, 8);
             case 816: RTO_F(16, 8);
@@ -1635,21 +1820,21 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
     // measured with the real knob, tuning key blocks_per_cu: 1 / 2 / 3 / 4 / 5 / 6 workgroups per CU take 26.2 / 14.4 /
     // 10.6 / 8.8 / 7.8 / 7.35 ms per 100 frames -- round 2's "4 to 8 waves within 2 %" compared __launch_bounds__ hints,
     // which change the register budget, not the number of resident waves).
-    return launch_batch_impl<SPP, 32, RTO_WPS_DEFAULT>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, occ, ev, stream);
+    return launch_batch_impl<SPP, 32, RTO_WPS_DEFAULT>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream);
 }
 
 hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
-                               int refill, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
+                               int refill, bool cull, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
     switch (spp) {
-        case 1: return launch_batch_spp<1>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
-        case 2: return launch_batch_spp<2>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
-        case 3: return launch_batch_spp<3>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
-        case 4: return launch_batch_spp<4>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
-        case 6: return launch_batch_spp<6>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
-        case 8: return launch_batch_spp<8>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
-        case 16: return launch_batch_spp<16>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
-        case 32: return launch_batch_spp<32>(tree, opt, fb, jump, queue, hits, num_cus, refill, occ, ev, stream);
+        case 1: return launch_batch_spp<1>(tree, opt, fb, jump, queue, hits, num_cus, refill, cull, occ, ev, stream);
+        case 2: return launch_batch_spp<2>(tree, opt, fb, jump, queue, hits, num_cus, refill, cull, occ, ev, stream);
+        case 3: return launch_batch_spp<3>(tree, opt, fb, jump, queue, hits, num_cus, refill, cull, occ, ev, stream);
+        case 4: return launch_batch_spp<4>(tree, opt, fb, jump, queue, hits, num_cus, refill, cull, occ, ev, stream);
+        case 6: return launch_batch_spp<6>(tree, opt, fb, jump, queue, hits, num_cus, refill, cull, occ, ev, stream);
+        case 8: return launch_batch_spp<8>(tree, opt, fb, jump, queue, hits, num_cus, refill, cull, occ, ev, stream);
+        case 16: return launch_batch_spp<16>(tree, opt, fb, jump, queue, hits, num_cus, refill, cull, occ, ev, stream);
+        case 32: return launch_batch_spp<32>(tree, opt, fb, jump, queue, hits, num_cus, refill, cull, occ, ev, stream);
         default: return hipErrorInvalidValue;
     }
 }

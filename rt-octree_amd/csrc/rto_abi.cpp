@@ -86,6 +86,7 @@ struct rto_tree {
     void* d_topgrid = nullptr;
     void* d_shrec = nullptr;  // aligned copy of the SH coefficients (shading)
     void* d_recidx = nullptr; // RTO_TREE_COMPACT_RECORDS: slot -> record of d_shrec
+    void* d_occ = nullptr;    // culling cells (TreeDev::occ_cells)
     void* d_qrec = nullptr;
     void* d_qcolors = nullptr;
     void* d_qsigma = nullptr;
@@ -116,6 +117,14 @@ struct rto_ctx {
     int tile_block = 4;  // tiles per side of the blocks the wedge queues are ordered by
     uint32_t* hits = nullptr;             // [frames][hits_spp][H*W] traversal -> shading hand-off
     int hits_spp = 0;
+    // empty-space culling + ray-queue lists of the batched path (allocated with the first batch)
+    uint32_t* tile_mask = nullptr;        // [frames][mask_words]
+    uint32_t* qlist = nullptr;            // [tiles * frames] live tile slots, queue after queue
+    uint32_t* qscratch = nullptr;         // chunk_count | chunk_base | qcount
+    int mask_words = 0, q_chunks_cap = 0;
+    bool cull_on = true;
+    int last_n_queues = 0;                // of the last batched launch (rto_ctx_queue_stats)
+    int64_t last_slots = 0;
     // per-kernel event timing of the batched path (off by default)
     bool kt_on = false;
     std::vector<hipEvent_t> kt_ev;  // kKtRing quadruples
@@ -206,6 +215,62 @@ float half_to_float(uint16_t h) {
     float f;
     std::memcpy(&f, &bits, 4);
     return f;
+}
+
+// The culling cells of a tree (TreeDev::occ_cells): cubes of size >= 2^-kOccLevel that together contain every leaf of positive
+// density, as world-space bounding spheres.  `sigma(slot)` = the leaf's density.  Returns false when the node order does not
+// allow the single top-down pass (a child stored before its parent: cannot happen after the breadth-first relayout).
+template <class SigmaFn>
+bool culling_cells(const int32_t* child, int64_t capacity, const float scale[3], const float offset[3], SigmaFn sigma,
+                   std::vector<float>& out) {
+    std::vector<uint8_t> lvl((size_t)capacity, 255), has((size_t)capacity, 0);
+    std::vector<uint32_t> cx((size_t)capacity, 0), cy((size_t)capacity, 0), cz((size_t)capacity, 0);
+    lvl[0] = 0;
+    for (int64_t n = 0; n < capacity; ++n) {  // top-down: level and integer cell coordinates of every reachable node
+        if (lvl[(size_t)n] == 255) continue;
+        for (int s = 0; s < 8; ++s) {
+            const int32_t c = child[n * 8 + s];
+            if (c == 0) continue;
+            const int64_t t = n + c;
+            if (t <= n || t >= capacity || lvl[(size_t)n] >= 30) return false;
+            lvl[(size_t)t] = (uint8_t)(lvl[(size_t)n] + 1);
+            cx[(size_t)t] = cx[(size_t)n] * 2 + ((s >> 2) & 1);  // slot = x * 4 + y * 2 + z (n3tree_query.hpp:26-33)
+            cy[(size_t)t] = cy[(size_t)n] * 2 + ((s >> 1) & 1);
+            cz[(size_t)t] = cz[(size_t)n] * 2 + (s & 1);
+        }
+    }
+    for (int64_t n = capacity - 1; n >= 0; --n) {  // bottom-up: does the subtree hold a leaf of positive density?
+        if (lvl[(size_t)n] == 255) continue;
+        uint8_t h = 0;
+        for (int s = 0; s < 8 && !h; ++s) {
+            const int32_t c = child[n * 8 + s];
+            h = c ? has[(size_t)(n + c)] : (uint8_t)(sigma(n * 8 + s) > 0.f);
+        }
+        has[(size_t)n] = h;
+    }
+    out.clear();
+    const float margin = 1e-4f;  // tree units: far above the float error of cen + t * dir (~1e-6), far below a cell
+    for (int64_t n = 0; n < capacity; ++n) {
+        if (lvl[(size_t)n] == 255 || !has[(size_t)n]) continue;
+        const int ls = lvl[(size_t)n] + 1;  // the node's child slots are cubes of size 2^-ls
+        if (ls > rto::kOccLevel) continue;  // inside a cube emitted above
+        for (int s = 0; s < 8; ++s) {
+            const int32_t c = child[n * 8 + s];
+            const bool emit = c ? (ls == rto::kOccLevel && has[(size_t)(n + c)]) : sigma(n * 8 + s) > 0.f;
+            if (!emit) continue;
+            const double size = std::ldexp(1.0, -ls);
+            const uint32_t q[3] = {cx[(size_t)n] * 2 + ((s >> 2) & 1), cy[(size_t)n] * 2 + ((s >> 1) & 1), cz[(size_t)n] * 2 + (s & 1)};
+            double r2 = 0;
+            for (int i = 0; i < 3; ++i) {
+                const double ct = (q[i] + 0.5) * size;
+                out.push_back((float)((ct - offset[i]) / scale[i]));
+                const double hw = (0.5 * size + margin) / std::fabs((double)scale[i]);
+                r2 += hw * hw;
+            }
+            out.push_back((float)(std::sqrt(r2) * 1.001));
+        }
+    }
+    return true;
 }
 
 // Breadth-first node order of a tree: order[new] = old.  Children are visited in slot order, so after the
@@ -407,6 +472,27 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
             t->d_nodew = nullptr;
         } else {
             dev_bytes += (size_t)n_slots * 4;
+        }
+    }
+
+    if (t->fast_ok && !(flags & RTO_TREE_NO_CULLING)) {  // culling cells for the batched path (see TreeDev::occ_cells)
+        std::vector<float> cells;
+        bool ok;
+        if (quant) {
+            const uint16_t* qs = quant->q_sigma;
+            ok = culling_cells(child, capacity, scale, offset, [&](int64_t sl) { return half_to_float(qs[sl]); }, cells);
+        } else {
+            const size_t dd = (size_t)data_dim;
+            ok = culling_cells(child, capacity, scale, offset, [&](int64_t sl) { return half_to_float(data[(size_t)sl * dd + dd - 1]); }, cells);
+        }
+        if (ok) {
+            const size_t bytes = cells.empty() ? 16 : cells.size() * sizeof(float);
+            if (hipMalloc(&t->d_occ, bytes) != hipSuccess ||
+                (!cells.empty() && hipMemcpy(t->d_occ, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess))
+                return fail(RTO_E_HIP, "hipMalloc(culling cells) failed");
+            t->dev.occ_cells = (const float4*)t->d_occ;
+            t->dev.n_occ_cells = (int)(cells.size() / 4);
+            dev_bytes += bytes;
         }
     }
 
@@ -778,6 +864,7 @@ void rto_tree_free(rto_tree* t) {
     if (t->d_topgrid) (void)hipFree(t->d_topgrid);
     if (t->d_shrec) (void)hipFree(t->d_shrec);
     if (t->d_recidx) (void)hipFree(t->d_recidx);
+    if (t->d_occ) (void)hipFree(t->d_occ);
     for (void* p : {t->d_qrec, t->d_qcolors, t->d_qsigma})
         if (p) (void)hipFree(p);
     delete t;
@@ -921,6 +1008,8 @@ void rto_ctx_free(rto_ctx* c) {
     if (c->rgba8) (void)hipFree(c->rgba8);
     if (c->jump) (void)hipFree(c->jump);
     if (c->queue) (void)hipFree(c->queue);
+    for (void* p : {(void*)c->tile_mask, (void*)c->qlist, (void*)c->qscratch})
+        if (p) (void)hipFree(p);
     if (c->d_frames) (void)hipFree(c->d_frames);
     if (c->hits) (void)hipFree(c->hits);
     if (c->tile_order) (void)hipFree(c->tile_order);
@@ -997,6 +1086,8 @@ int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value) {
         return build_tile_tables(c);
     } else if (k == "refill") {
         c->refill = value;
+    } else if (k == "cull") {  // empty-space culling of the batched path (1 = on; same pixels either way)
+        c->cull_on = value != 0;
     } else if (k == "blocks_per_cu") {  // occupancy of the persistent traversal kernel: 0 = what fits, else a cap (1..8)
         if (value < 0 || value > 8) return set_err(RTO_E_INVALID, "blocks_per_cu must be 0..8");
         c->occ.cap = value;
@@ -1045,6 +1136,20 @@ int rto_ctx_kernel_timing_read3(rto_ctx* c, float* raygen_ms, float* traverse_ms
     if (shade_ms) *shade_ms = c->kt_count ? (float)(s / c->kt_count) : 0.f;
     if (launches) *launches = c->kt_count;
     c->kt_count = 0;
+    return RTO_OK;
+}
+
+int rto_ctx_queue_stats(rto_ctx* c, int64_t* live_tile_slots, int64_t* all_tile_slots) {
+    if (!c || !live_tile_slots || !all_tile_slots) return set_err(RTO_E_INVALID, "rto_ctx_queue_stats: null argument");
+    if (!c->qscratch || c->last_n_queues < 1) return set_err(RTO_E_INVALID, "rto_ctx_queue_stats: no batched launch yet");
+    DeviceGuard guard(c->device);
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t cnt[rto::kMaxQueues] = {0};
+    HIP_TRY(hipMemcpy(cnt, c->qscratch + 2 * (size_t)c->q_chunks_cap, sizeof(cnt), hipMemcpyDeviceToHost));
+    int64_t live = 0;
+    for (int k = 0; k < c->last_n_queues; ++k) live += cnt[k];
+    *live_tile_slots = live;
+    *all_tile_slots = c->last_slots;
     return RTO_OK;
 }
 
@@ -1220,6 +1325,42 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
             for (int k = 1; k <= rto::kMaxQueues; ++k) fb.qstart[k] = tiles;
         }
     }
+    {   // tile marks + queue lists
+        const int tiles_x = (ctx->width + 7) / 8, tiles_y = (ctx->height + 7) / 8, tiles = tiles_x * tiles_y;
+        if (tiles_x > 1023 || tiles_y > 1023)
+            return set_err(RTO_E_UNSUPPORTED, "the batched path packs tile coordinates into 10 bits: frames up to 8184 x 8184 pixels");
+        const int mask_words = (tiles + 31) / 32 + 1;
+        fb.qchunk[0] = 0;
+        for (int k = 0; k < rto::kMaxQueues; ++k) {
+            const int64_t slots = k < fb.n_queues ? (int64_t)(fb.qstart[k + 1] - fb.qstart[k]) * n : 0;
+            fb.qchunk[k + 1] = fb.qchunk[k] + (int)((slots + rto::kQueueChunk - 1) / rto::kQueueChunk);
+        }
+        const int chunks_cap = (int)(((int64_t)tiles * ctx->frames + rto::kQueueChunk - 1) / rto::kQueueChunk) + rto::kMaxQueues;
+        if (!ctx->tile_mask || ctx->mask_words != mask_words || ctx->q_chunks_cap < chunks_cap) {
+            if (ctx->tile_mask) {
+                HIP_TRY(hipDeviceSynchronize());
+                for (void* p : {(void*)ctx->tile_mask, (void*)ctx->qlist, (void*)ctx->qscratch}) HIP_TRY(hipFree(p));
+                ctx->tile_mask = ctx->qlist = ctx->qscratch = nullptr;
+            }
+            HIP_TRY(hipMalloc((void**)&ctx->tile_mask, (size_t)ctx->frames * mask_words * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void**)&ctx->qlist, (size_t)tiles * ctx->frames * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void**)&ctx->qscratch, ((size_t)2 * chunks_cap + rto::kMaxQueues) * sizeof(uint32_t)));
+            ctx->mask_words = mask_words;
+            ctx->q_chunks_cap = chunks_cap;
+        }
+        fb.tile_mask = ctx->tile_mask;
+        fb.mask_words = mask_words;
+        fb.qlist = ctx->qlist;
+        fb.chunk_count = ctx->qscratch;
+        fb.chunk_base = ctx->qscratch + ctx->q_chunks_cap;
+        fb.qcount = ctx->qscratch + 2 * (size_t)ctx->q_chunks_cap;
+    }
+    // Rays that provably never meet density are not marched (see mark_tiles_kernel): needs the tree's culling cells, a
+    // non-negative density threshold (a hit needs sigma > sigma_thresh, rt_core.cuh:252) and straight world-space rays
+    // (the NDC warp of LLFF scenes bends them: maybe_world2ndc, volrend.cu:35-56)
+    ctx->last_n_queues = fb.n_queues;
+    ctx->last_slots = (int64_t)((ctx->width + 7) / 8) * ((ctx->height + 7) / 8) * n;
+    const bool cull = ctx->cull_on && tree->dev.occ_cells && o->sigma_thresh >= 0.f && !(tree->dev.ndc_width > 0.f);
     const size_t px = frame_px(ctx);
     rto::FrameDesc frames[rto::kMaxBatch];
     fb.f = ctx->d_frames;
@@ -1251,7 +1392,7 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     if (ctx->kt_on && ctx->kt_count < kKtRing) ev = &ctx->kt_ev[(size_t)ctx->kt_count++ * 4];
     hipError_t e = rto::launch_render_batch(o->spp, tree->dev, od, fb, ctx->jump, ctx->queue,
                                             ctx->hits + (size_t)slot0 * o->spp * px,  // = fb.f[0].hits: the kernel indexes frames from here
-                                            ctx->num_cus, ctx->refill, &ctx->occ, ev, stream);
+                                            ctx->num_cus, ctx->refill, cull, &ctx->occ, ev, stream);
     if (e == hipErrorInvalidConfiguration)
         return set_err(RTO_E_UNSUPPORTED, "batched render: the traversal kernel needs (max_depth + 1 - top_levels + spp + 1) KB of LDS for its "
                                           "ancestor stack and thresholds plus 96 B per frame -- depth " + std::to_string(tree->dev.max_depth) +

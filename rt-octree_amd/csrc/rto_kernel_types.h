@@ -13,6 +13,8 @@ namespace rto {
 //   internal slot: the reference's child[] value (relative node offset, |v| < 2^30)
 //   leaf slot:     0x80000000 | fp16 bits of the slot's sigma  -> top two bits are 0b10
 constexpr uint32_t kLeafTag = 0x80000000u;
+constexpr int kQueueChunk = 256;  // tile slots per workgroup of the queue compaction
+constexpr int kOccLevel = 7;  // finest cube of the culling cells: 2^-7 of the volume (6 pixels across at 800 x 800)
 constexpr uint32_t kNoRecord = 0xffffffffu;  // TreeDev::recidx entry of a slot without a coefficient record
 
 // Bit budgets of the packed words.  A top-grid entry is {slot | level << kGridSlotBits, word}: the level is < 8 (the
@@ -62,6 +64,12 @@ struct TreeDev {
     // and per quantised basis function a 65536-entry codebook of {r, g, b, 0} fp16 (8 B entries).
     // Same bytes as quant_map + data_retained of the file, slot-major so that one hit leaf touches
     // one or two cache lines instead of one per basis function.
+    // Empty-space culling (round 3): the cubes, no finer than kOccLevel, that together contain every leaf of positive
+    // density, as bounding spheres in WORLD coordinates {x, y, z, radius} (radius = half diagonal + a margin far above the
+    // float error of a ray's sample points).  mark_tiles_kernel projects them into each frame: an 8x8-pixel tile that no
+    // sphere touches holds only rays that can never meet density -- background pixels, known without marching.
+    const float4* occ_cells;
+    int n_occ_cells;  // (0 with occ_cells != nullptr: a tree without density; occ_cells == nullptr: no culling)
     const uint16_t* qrec;
     const uint2* qcolors;  // [n_basis - q_retain][65536]
     int q_retain;
@@ -120,6 +128,19 @@ struct FrameBatch {
     // the others once that is empty.  n_queues = 1: a single queue over whole frames.
     int n_queues;
     int qstart[kMaxQueues + 1];
+    // per frame `mask_words` u32: bit t = 8x8 tile t (row-major) may hold a ray that meets density; the LAST word != 0 = keep
+    // every tile of the frame (camera too close to a cell for the projection bound).  nullptr: no culling.
+    const uint32_t* tile_mask;
+    int mask_words;
+    // The ray queues as lists (round 3): queue k = qlist[qstart[k] * n ...], qcount[k] live tile slots, each entry
+    // {frame << 20 | tile y << 10 | tile x} -- the tile slots of the queue order (tile-major or frame-major over tile_order)
+    // whose tile is marked, compacted in that order by the three queue_*_kernel launches before the traversal (in chunks of
+    // kQueueChunk slots: qchunk[k] = first chunk of queue k, chunk_count / chunk_base = the scan's scratch).
+    uint32_t* qlist;
+    uint32_t* qcount;
+    uint32_t* chunk_count;
+    uint32_t* chunk_base;
+    int qchunk[kMaxQueues + 1];
     const FrameDesc* f;  // [n] in device memory (the context's table, written on the launch stream by write_frames_kernel)
 };
 struct FrameChunk {

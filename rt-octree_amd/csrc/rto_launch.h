@@ -43,7 +43,7 @@ struct OccupancyCache {
 // shading kernel); `queue` = kQueueWords u64 (zeroed on the stream before every launch); ev = nullptr or 4 events recorded before the thresholds kernel, before / after the traversal, after the shading
 hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
-                               int refill, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream);
+                               int refill, bool cull, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream);
 
 // quant_map [nq][ns] + data_retained [nr][ns][3] -> slot-major records of `rec` u16 (TreeDev::qrec)
 hipError_t launch_pack_quant(const uint16_t* qmap, const uint16_t* retained, int64_t ns, int nr, int nq, int rec,

@@ -112,19 +112,21 @@ class N3Tree:
     """Device-resident PlenOctree.  `N3Tree(path)` = N3Tree::open + load_cuda
     (n3tree.cpp:111-154, n3tree.cu:9-41)."""
 
-    def __init__(self, path=None, device=0, quant_direct=False, compact=False, keep_reference=False, compact_records=False):
+    def __init__(self, path=None, device=0, quant_direct=False, compact=False, keep_reference=False, compact_records=False,
+                 no_culling=False):
         self._h = C.c_void_p(0)
         self.device = device
         self.quant_direct = bool(quant_direct)  # render a quantised tree from its codebooks (no expansion)
         self.compact = bool(compact)            # RTO_TREE_COMPACT: no aligned copy of the SH coefficients for shading
         self.keep_reference = bool(keep_reference)  # RTO_TREE_KEEP_REFERENCE: child[] / data[] stay resident
         self.compact_records = bool(compact_records)  # RTO_TREE_COMPACT_RECORDS: coefficient records for hittable leaves only
+        self.no_culling = bool(no_culling)  # RTO_TREE_NO_CULLING: no empty-space culling cells
         if path is not None:
             self.open(path)
 
     def _flags(self):
         return ((1 if self.quant_direct else 0) | (2 if self.compact else 0) | (4 if self.keep_reference else 0)
-                | (8 if self.compact_records else 0))
+                | (8 if self.compact_records else 0) | (16 if self.no_culling else 0))
 
     def open(self, path):
         self.free()
@@ -135,7 +137,7 @@ class N3Tree:
 
     @classmethod
     def from_arrays(cls, child, data, scale, offset, data_format="", device=0, compact=False, keep_reference=False,
-                    compact_records=False):
+                    compact_records=False, no_culling=False):
         """child int32 [capacity,N,N,N]; data float16 (or uint16 bits) [capacity,N,N,N,data_dim];
         scale = invradius3, offset (n3tree.cpp:257-267)."""
         child = np.ascontiguousarray(child, dtype=np.int32)
@@ -149,7 +151,8 @@ class N3Tree:
         cap, N, dd = child.shape[0], child.shape[1], data.shape[-1]
         sc = (C.c_float * 3)(*[float(x) for x in np.broadcast_to(np.asarray(scale, np.float32), (3,))])
         of = (C.c_float * 3)(*[float(x) for x in np.broadcast_to(np.asarray(offset, np.float32), (3,))])
-        t = cls(device=device, compact=compact, keep_reference=keep_reference, compact_records=compact_records)
+        t = cls(device=device, compact=compact, keep_reference=keep_reference, compact_records=compact_records,
+                no_culling=no_culling)
         h = C.c_void_p(0)
         check(lib().rto_tree_from_arrays_ex(C.c_void_p(child.ctypes.data), C.c_void_p(data.ctypes.data), cap, N, dd,
                                             data_format.encode("ascii"), sc, of, device, t._flags(), C.byref(h)))
@@ -318,7 +321,7 @@ class RenderContext:
         return self._timer
 
     def set_tuning(self, key, value):
-        """performance knobs ("strip_rows", "refill", "tile_order", "xcd_queues", "tile_major", "tile_block", "blocks_per_cu");
+        """performance knobs ("strip_rows", "refill", "tile_order", "xcd_queues", "tile_major", "tile_block", "blocks_per_cu", "cull");
         results never change"""
         check(lib().rto_ctx_set_tuning(self._h, key.encode("ascii"), int(value)))
 
@@ -330,6 +333,12 @@ class RenderContext:
         g, t, s, n = C.c_float(0), C.c_float(0), C.c_float(0), C.c_int(0)
         check(lib().rto_ctx_kernel_timing_read3(self._h, C.byref(g), C.byref(t), C.byref(s), C.byref(n)))
         return {"raygen_ms": g.value, "traverse_ms": t.value, "shade_ms": s.value, "launches": n.value}
+
+    def queue_stats(self):
+        """(tile slots marched, tile slots in all) of the last batched launch: the rest were culled as provably empty"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(lib().rto_ctx_queue_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def enable_stats(self, on=True):
         """Work counters for the roofline's algorithmic byte count (never in a timed run)."""

@@ -1,0 +1,112 @@
+"""Empty-space culling of the batched path (round 3): every culling cell of the tree -- a world-space bounding sphere of a
+cube that holds leaves of positive density -- is projected into every frame; 8x8-pixel tiles no sphere touches are
+neither marched nor given threshold draws.  The claim is exact: such rays never meet density, so their pixels are the
+background whatever the marcher would do (rt_core.cuh:252-262).  Checked here as bit-identity of whole frames with the
+culling on and off, for poses that stress the projection bound (camera inside the volume, grazing, looking away, off
+axis, non-square focal lengths, a non-orthonormal camera matrix), next to the oracle, which marches every ray."""
+import numpy as np
+import pytest
+
+import orc
+import rt_octree_amd as R
+from helpers import assert_bits_equal, make_pair
+from rt_octree_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _render(dt, cams, spp, cull, ctx, jumps, **optkw):
+    ctx.set_tuning("cull", int(cull))
+    ctx.rng_seed()
+    R.launch_renderer_batch(dt, cams, R.RenderOptions(spp=spp, denoise=False, **optkw), ctx, rng_jumps=jumps)
+    out = []
+    for f in range(len(cams)):
+        ctx.select_frame(f)
+        out.append((ctx.download_aux(), ctx.download_image()))
+    return out, ctx.queue_stats()
+
+
+def _poses():
+    P = list(synth.orbit_poses(12))
+    P.append(synth.look_at_c2w((0.2, 0.1, 0.3)))                      # camera inside the volume
+    P.append(synth.look_at_c2w((1.2, 1.2, 0.4)))                      # close, grazing a corner
+    P.append(synth.look_at_c2w((9.0, 0.5, 1.0)))                      # far away: the object is a few tiles
+    P.append(synth.look_at_c2w((3.0, 0.0, 1.0), target=(9.0, 0.0, 1.0)))   # looking away: the volume is behind the camera
+    P.append(synth.look_at_c2w((2.5, 2.5, 0.2), target=(0.0, 3.0, 0.0)))   # the object at the edge of the frame
+    return P
+
+
+@pytest.mark.parametrize("spp", [6, 1])
+def test_culled_frames_are_bit_identical_to_marched_ones(spp):
+    tree = synth.make_tree(depth_limit=8, basis_dim=9, seed=21, shell=2.0)
+    ht, dt = make_pair(tree)
+    W, H = 200, 136
+    poses = _poses()
+    cams = []
+    for i, p in enumerate(poses):
+        c = R.Camera(W, H, 260.0, 300.0 if i % 2 else 260.0)  # non-square pixels on every second pose
+        c.set_c2w(p)
+        cams.append(c)
+    cams[3].transform[:3] *= np.float32(1.7)   # a scaled (non-orthonormal) camera matrix: directions are normalised anyway
+    skew = np.array(cams[5].transform)
+    skew[0] += np.float32(0.2) * skew[1]       # and a sheared one
+    cams[5].transform = skew
+    ctx = R.RenderContext(W, H, frames=len(cams))
+    jumps = list(range(100, 100 + len(cams)))
+    on, (live_on, all_on) = _render(dt, cams, spp, True, ctx, jumps)
+    off, (live_off, all_off) = _render(dt, cams, spp, False, ctx, jumps)
+    assert all_on == all_off == len(cams) * 25 * 17 and live_off == all_off
+    assert live_on < 0.8 * all_on  # the orbit poses see an object in empty space
+    for f in range(len(cams)):
+        assert_bits_equal(on[f][0], off[f][0], "aux frame %d" % f)
+        assert_bits_equal(on[f][1], off[f][1], "image frame %d" % f)
+    # ... and equal to the oracle, which marches every ray, on a few of them
+    for f in (0, 12, 13, 16):
+        cam = cams[f]
+        ocam = orc.camera(W, H, cam.fx, cam.fy, np.asarray(cam.transform, np.float32).reshape(-1))
+        aux_o, _, _ = orc.render_frame(ht, ocam, orc.default_options(spp=spp), orc.rng(frame=jumps[f]))
+        assert_bits_equal(on[f][0], aux_o, "oracle frame %d" % f)
+    # the frame that looks away holds no marched tile at all; the one inside the volume keeps every tile
+    solo = R.RenderContext(W, H, frames=1)
+    _, (live, total) = _render(dt, [cams[15]], spp, True, solo, [5])
+    assert live == 0 and total == 25 * 17
+    _, (live, total) = _render(dt, [cams[12]], spp, True, solo, [5])
+    assert live == total
+
+
+def test_culling_switches_itself_off_where_its_premises_fail():
+    """a negative density threshold (a leaf of zero density could be hit) and the NDC warp (rays are not straight lines of the
+    world) march every tile; a crop box only removes rays, so it culls"""
+    tree = synth.make_tree(depth_limit=6, basis_dim=9, seed=7)
+    ht, dt = make_pair(tree)
+    W, H = 96, 64
+    cam = R.Camera(W, H, synth.blender_focal(W))
+    cam.set_c2w(synth.orbit_poses(4)[1])
+    ctx = R.RenderContext(W, H, frames=1)
+    _, (live, total) = _render(dt, [cam], 6, True, ctx, [3])
+    assert 0 < live < total
+    _, (live, _) = _render(dt, [cam], 6, True, ctx, [3], sigma_thresh=-1.0)
+    assert live == total
+    box, _ = _render(dt, [cam], 6, True, ctx, [3], render_bbox=[0.1, 0.2, 0.0, 0.9, 0.8, 0.7])
+    box_off, _ = _render(dt, [cam], 6, False, ctx, [3], render_bbox=[0.1, 0.2, 0.0, 0.9, 0.8, 0.7])
+    assert_bits_equal(box[0][0], box_off[0][0], "crop box")
+    dt.set_ndc(96.0, 64.0, 50.0)
+    _, (live, total) = _render(dt, [cam], 2, True, ctx, [3])
+    assert live == total
+    # a tree loaded without the cells marches everything
+    plain = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format, no_culling=True)
+    _, (live, total) = _render(plain, [cam], 6, True, ctx, [3])
+    assert live == total
+
+
+def test_a_tree_without_density_renders_the_background_without_marching():
+    tree = synth.make_tree(depth_limit=5, basis_dim=9, seed=3)
+    data = tree.data.copy()
+    data[..., -1] = 0
+    dt = R.N3Tree.from_arrays(tree.child, data, tree.scale, tree.offset, tree.data_format)
+    cam = R.Camera(64, 48, synth.blender_focal(64))
+    cam.set_c2w(synth.orbit_poses(4)[2])
+    ctx = R.RenderContext(64, 48, frames=1)
+    (frame,), (live, total) = _render(dt, [cam], 6, True, ctx, [0])
+    assert live == 0 and total == 8 * 6
+    assert np.all(frame[0][:3] == 1.0) and np.all(frame[0][3] == 0.0) and np.all(frame[1][..., :3] == 1.0)

@@ -433,18 +433,27 @@ RTO_DEV bool block_tile(const TileMap& tm, int b, int& tx, int& ty) {
 //   planar      [SPP][H*W]:  i * SIZE + p   (a wave's 64 hit stores go to 64 different lines once its lanes hold
 //                                            unrelated pixels)
 //   pixel-major [H*W][SPP]:  p * SPP + i   (a pixel's thresholds / hit list are one contiguous run: 24 B at SPP 6)
-// Pixel-major is the default.  Measured in ONE box (tools/ab_variants.sh), 100 frames of 800x800 SPP 6,
-// with the terminator-free lists: traversal 7.28 vs 7.34 ms, shading 1.96 vs 2.17 ms.  (An earlier comparison across two
-// boxes and two register allocations -- see the load-overlap note in render_persist -- had it 6 % behind.)
+//   split (default since round 3): entry 0 in a dense plane [H*W], entries 1.. pixel-major [H*W][SPP-1] behind it.
+//     The thresholds kernel ends the lists of a culled tile with eight 32-byte row segments instead of 64 scattered dwords
+//     (4 bytes stored at a 24-byte stride cost a 32-byte burst each: 0.66 -> 0.43 ms per 100 frames for marks + lists +
+//     thresholds).
+// Pixel-major replaced planar in round 2 (100 frames of 800x800 SPP 6 in one box: traversal 7.28 vs 7.34 ms,
+// shading 1.96 vs 2.17 ms).
 #ifdef RTO_HITS_PLANAR
-constexpr bool kHitsPixelMajor = false;
+constexpr int kHitsLayout = 0;
+#elif defined(RTO_HITS_PIXEL_MAJOR)
+constexpr int kHitsLayout = 1;
 #else
-constexpr bool kHitsPixelMajor = true;
+constexpr int kHitsLayout = 2;
 #endif
 template <int SPP>
 RTO_DEV uint32_t hit_index(uint32_t pixel, uint32_t i, uint32_t SIZE) {
-    return kHitsPixelMajor ? pixel * (uint32_t)SPP + i : i * SIZE + pixel;
+    if (kHitsLayout == 0) return i * SIZE + pixel;
+    if (kHitsLayout == 1) return pixel * (uint32_t)SPP + i;
+    return i == 0u ? pixel : SIZE + pixel * (uint32_t)(SPP - 1) + (i - 1u);
 }
+// distance between entries i and i + 1 of a pixel for i >= 1 (and for i = 0 in the first two layouts)
+RTO_DEV uint32_t hit_stride(uint32_t SIZE) { return kHitsLayout == 0 ? SIZE : 1u; }
 
 // Hit list entry: leaf slot in the low hit_slot_bits(SPP) bits, (count - 1) above, kHitValid on top (rto_kernel_types.h).
 template <int SPP>
@@ -732,7 +741,7 @@ struct RayState {
     uint32_t spp;
     uint32_t pix, piy, piz;
     int prev_lvl;   // level of the node about to be visited
-    uint32_t hoff;  // index of this pixel's next free hit entry in the hand-off buffer
+    uint32_t hoff, hnext;  // index of this pixel's next free hit entry in the hand-off buffer, and of the one behind it
     uint32_t node;  // node about to be visited; kGridNext = the top grid is visited next
     float cxy __attribute__((ext_vector_type(2)));  // cen[0], cen[1] as a register pair for the packed march arithmetic
     // _dda_unit's max(t1, t1 + invdir) per axis is t1 + (invdir > 0 ? invdir : 0): the sign of invdir is the ray's, not the
@@ -934,16 +943,21 @@ __global__ void __launch_bounds__(kQueueChunk) queue_write_kernel(const FrameBat
 // buffer slots [i][pixel] that the traversal later overwrites with the pixel's hit list.
 template <int SPP>
 __global__ void __launch_bounds__(256) sample_kernel(const FrameBatch fb, const PcgJumpEntry* __restrict__ jump) {
+    // one wave = one 8x8 tile (row-major tiles, 4 per workgroup): a culled tile's wave writes 64 empty lists and is gone --
+    // with one thread per pixel of a scanline nearly every wave held some marched pixel and paid for all the draws
     const uint32_t SIZE = (uint32_t)fb.width * (uint32_t)fb.height;
-    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
-    if (idx >= SIZE) return;
+    const uint32_t tiles_x = (uint32_t)(fb.width + 7) >> 3, tiles_y = (uint32_t)(fb.height + 7) >> 3;
+    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
+    if (tile >= tiles_x * tiles_y) return;
+    const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x, lane = threadIdx.x & 63u;
+    const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+    if (x >= (uint32_t)fb.width || y >= (uint32_t)fb.height) return;
+    const uint32_t idx = y * (uint32_t)fb.width + x;
     const FrameDesc& fd = fb.f[blockIdx.y];
-    if (fb.tile_mask) {  // a pixel of a culled tile: an empty hit list, no draws (its RNG stream is its own: nobody observes them)
-        const uint32_t y = idx / (uint32_t)fb.width, x = idx - y * (uint32_t)fb.width;
-        if (!tile_marked(fb, (int)blockIdx.y, (y >> 3) * ((uint32_t)(fb.width + 7) >> 3) + (x >> 3))) {
-            fd.hits[hit_index<SPP>(idx, 0u, SIZE)] = 0u;
-            return;
-        }
+    // a pixel of a culled tile: an empty hit list, no draws (its RNG stream is its own: nobody observes the skipped ones)
+    if (fb.tile_mask && !tile_marked(fb, (int)blockIdx.y, tile)) {
+        fd.hits[hit_index<SPP>(idx, 0u, SIZE)] = 0u;
+        return;
     }
     Pcg32 rng;
     rng.state = fd.rng_state;
@@ -1005,7 +1019,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
 
     const int W = fb.width, H = fb.height;
     const uint32_t SIZE = (uint32_t)W * (uint32_t)H;
-    const uint32_t hstride = kHitsPixelMajor ? 1u : SIZE;  // distance between consecutive entries of one pixel
+    const uint32_t hstride = hit_stride(SIZE);  // distance between consecutive entries of one pixel (behind the first)
     // the queue this wave draws from first: the one of the XCD it runs on (HW_REG_XCC_ID bits 3:0)
     const uint32_t n_queues = (uint32_t)fb.n_queues;
     uint32_t cur_q = n_queues > 1 ? ((uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % n_queues) : 0u;
@@ -1103,14 +1117,18 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                         float vdir[3];
                         ray_setup(x, y, cam, tree, rs.dir, vdir, rs.cen);
                         float tmin;
-                        rs.hoff = (uint32_t)frame * (uint32_t)SPP * SIZE + hit_index<SPP>((uint32_t)(y * W + x), 0u, SIZE);
+                        {   // where this pixel's next hit entry goes (hoff) and the one after it (hnext): hit_index
+                            const uint32_t fbase = (uint32_t)frame * (uint32_t)SPP * SIZE, pixel = (uint32_t)(y * W + x);
+                            rs.hoff = fbase + hit_index<SPP>(pixel, 0u, SIZE);
+                            rs.hnext = fbase + hit_index<SPP>(pixel, SPP > 1 ? 1u : 0u, SIZE);
+                        }
                         if (ray_enter(tree, opt, rs.dir, rs.cen, 1e9f, rs.invdir, rs.delta_scale, tmin, rs.tmax)) {
                             // sorted thresholds of this pixel (sample_kernel left them in the hand-off
                             // buffer, where the ray's hit list will overwrite them)
-                            const uint32_t* tp = hits + rs.hoff;
-                            rs.cur = __uint_as_float(tp[0]);
+                            rs.cur = __uint_as_float(hits[rs.hoff]);
+                            const uint32_t* tp = hits + rs.hnext;
 #pragma unroll
-                            for (int i = 1; i < SPP; ++i) s_dst[i * 256] = __uint_as_float(tp[(uint32_t)i * hstride]);
+                            for (int i = 1; i < SPP; ++i) s_dst[i * 256] = __uint_as_float(tp[(uint32_t)(i - 1) * hstride]);
                             s_dst[SPP * 256] = 3.402823466e+38f;
                             rs.spp = 0;
                             rs.src = 0;
@@ -1268,7 +1286,8 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                                 rs.cur = s_dst[rs.spp * 256];
                             } while (reach >= rs.cur);
                             hits[rs.hoff] = hit_pack<SPP>(slot, cnt);
-                            rs.hoff += hstride;  // (the next free entry of this pixel's list)
+                            rs.hoff = rs.hnext;  // (the next free entry of this pixel's list)
+                            rs.hnext += hstride;
                             if (rs.spp == (uint32_t)SPP) rs.tmax = -1.f;  // the last threshold: the ray ends
                         }
                         rs.src = reach;
@@ -1465,7 +1484,33 @@ __global__ void __launch_bounds__(256, RTO_SHADE_WPS) shade_kernel(const TreeDev
         n[p] = 0;
         if (idx < SIZE) {
             bool open = true;
-            if (kHitsPixelMajor) {  // the whole list is one contiguous run: fetch it, then find its end
+            if (kHitsLayout == 2) {  // the first entry from its dense plane, the run behind it
+#ifdef RTO_SHADE_LAZY_LIST
+                // (fetching the run only for a pixel whose first entry is valid saves 20 bytes per empty pixel and costs a
+                //  dependent round trip per wave: 2.03 instead of 1.95 ms per 100 frames)
+                uint32_t raw[SPP];
+                raw[0] = fd.hits[idx];
+#pragma unroll
+                for (int i = 1; i < SPP; ++i) raw[i] = 0u;
+                if (raw[0] & kHitValid) {
+                    const uint32_t* hp = fd.hits + SIZE + idx * (SPP - 1);
+#pragma unroll
+                    for (int i = 1; i < SPP; ++i) raw[i] = hp[i - 1];
+                }
+#else
+                uint32_t raw[SPP];
+                raw[0] = fd.hits[idx];
+                const uint32_t* hp = fd.hits + SIZE + idx * (SPP - 1);
+#pragma unroll
+                for (int i = 1; i < SPP; ++i) raw[i] = hp[i - 1];
+#endif
+#pragma unroll
+                for (int i = 0; i < SPP; ++i) {
+                    open = open && (raw[i] & kHitValid) != 0u;
+                    h[p][i] = open ? raw[i] : 0u;
+                    n[p] += open ? 1u : 0u;
+                }
+            } else if (kHitsLayout == 1) {  // the whole list is one contiguous run: fetch it, then find its end
                 const uint32_t* hp = fd.hits + idx * SPP;
                 uint32_t raw[SPP];
 #pragma unroll
@@ -1755,7 +1800,7 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
     hipLaunchKernelGGL(queue_count_kernel, dim3(n_chunks), dim3(kQueueChunk), 0, stream, fb);
     hipLaunchKernelGGL(queue_scan_kernel, dim3(1), dim3(256), 0, stream, fb);
     hipLaunchKernelGGL(queue_write_kernel, dim3(n_chunks), dim3(kQueueChunk), 0, stream, fb);
-    hipLaunchKernelGGL(sample_kernel<SPP>, dim3((unsigned)((size + 255) / 256), fb.n), dim3(256), 0, stream, fb, jump);
+    hipLaunchKernelGGL(sample_kernel<SPP>, dim3((unsigned)((tiles / fb.n + 3) / 4), fb.n), dim3(256), 0, stream, fb, jump);
     // arm the ray queues on the launch stream (576 B): a launch never depends on how the previous one on
     // this context ended
     if (hipMemsetAsync(queue, 0, kQueueWords * sizeof(unsigned long long), stream) != hipSuccess) return hipErrorLaunchFailure;

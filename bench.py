@@ -662,7 +662,7 @@ def main():
                             "note": "frac = SQ_INSTS_VALU / (SIMDs x kernel clocks) over the rate the traversal's instruction stream sustains "
                                     "with no memory in the way: the larger of the asm probe's figure for its opcode mix at 8 waves per "
                                     "SIMD (0.290, profiles/r3_valu_calibration.json, counters on the probe itself) and the traversal "
-                                    "loop's own with both gathers stubbed (0.321, profiles/r3_i_stubbed_loads_pmc.json). "
+                                    "loop's own with both gathers stubbed (0.321, profiles/r3_j_stubbed_loads_pmc.json). "
                                     "A SIMD issues ~0.45 instructions per clock in all: plain add / mul / fma / logic opcodes at "
                                     "0.41-0.45, every other VALU opcode (3-operand, shifts left, min / max, conversions, compares, "
                                     "packed, SGPR operand) at 0.235-0.245, SALU instructions out of the same budget"}

@@ -52,7 +52,7 @@ def main():
             "source": "profiles/r3_valu_calibration.json: asm probe, 8 waves per SIMD, SQ_INSTS_VALU / (SQ_BUSY_CYCLES / 32) / 1024 SIMDs"}
         # the traversal loop itself with both gathers stubbed (-DRTO_STUB_LOADS): what ITS instruction stream sustains with no
         # memory in the way; the ceiling quoted is the larger of the two
-        stub = os.path.join(ROOT, "profiles", "r3_i_stubbed_loads_pmc.json")
+        stub = os.path.join(ROOT, "profiles", "r3_j_stubbed_loads_pmc.json")
         vc = doc["valu_ceiling"]
         vc["ceiling_insts_per_clk_per_simd"] = vc["traversal_mix_insts_per_clk_per_simd"]
         if os.path.exists(stub):

@@ -107,6 +107,9 @@ def parse_args(argv=None):
     ap.add_argument("--plan-only", action="store_true",
                     help="no GPU work: join the process group (gloo), print every rank's frame plan as JSON and exit -- "
                          "pins the rank / scene / pose / RNG-jump bookkeeping of a multi-GPU run on a CPU box")
+    ap.add_argument("--net-cull", type=int, default=1, help="A/B: 0 = run GuidanceNet on every tile")
+    ap.add_argument("--no-filter-cull", action="store_true",
+                    help="A/B: filter every tile, also those that see only culled (background) render tiles")
     ap.add_argument("--fp32-maps", action="store_true",
                     help="hand the GuidanceNet maps to the factorised filter as fp32 planes (the reference's tensors) instead "
                          "of the packed fp16 values the network actually produces: same pixels, twice the bytes")
@@ -367,10 +370,12 @@ def main():
         if denoise:
             lctx.select_frame(0)
             if packed_route and not exact:  # GuidanceNet -> fp16 maps in the handle's scratch -> factorised filter
-                lnet.forward_packed(laux[:n], stream=lstream, squares_implied=True)
+                # (network / filter tiles that see only culled = background render tiles are filled, not computed: same bits)
+                marks = None if args.no_filter_cull else lctx.tile_marks()
+                lnet.forward_packed(laux[:n], stream=lstream, squares_implied=True, cull=marks if args.net_cull else None)
                 if ev:
                     ev[2].record(lstream)
-                lnet.filter_packed(lctx.noisy_ptr, lctx.image_ptr, stream=lstream, shape=(n, H, W))
+                lnet.filter_packed(lctx.noisy_ptr, lctx.image_ptr, stream=lstream, shape=(n, H, W), cull=marks)
             else:
                 with torch.no_grad(), torch.cuda.stream(lstream):
                     wm, gm = lnet(laux[:n], stream=lstream, squares_implied=True) if not args.torch_net else lnet(laux[:n])

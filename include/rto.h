@@ -207,6 +207,12 @@ int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value);
  * slots (tile x frame) were marched and how many there were -- the rest were culled as provably empty (see
  * RTO_TREE_NO_CULLING; tuning key "cull" = 0 switches the culling off per context). */
 int rto_ctx_queue_stats(rto_ctx* c, int64_t* live_tile_slots, int64_t* all_tile_slots);
+/* The tile marks the last rto_launch_renderer_batch left on the device: frames x words_per_frame uint32 (bit t of a frame's
+ * words = 8x8 tile t, row-major, may hold a ray that meets density; bit 0 of the frame's last word = treat every tile as
+ * marked).  An unmarked tile's pixels are exactly the background: colour = *background, alpha 0.  Valid (stream-ordered
+ * after that launch) until the next launch on the context; RTO_E_INVALID when the last launch was a single-frame one.
+ * Frame f of the marks is context slot first_slot + f.  For rto_filtering_packed_culled. */
+int rto_ctx_tile_marks(const rto_ctx* c, const uint32_t** marks, int* words_per_frame, int* first_slot, int* frames, float* background);
 int rto_ctx_kernel_timing(rto_ctx* c, int enable);
 int rto_ctx_kernel_timing_read(rto_ctx* c, float* traverse_ms, float* shade_ms, int* launches);
 /* the same with the thresholds kernel (sample_kernel: RNG jump, SPP draws, sort for every pixel of the batch) reported too,
@@ -319,6 +325,20 @@ int rto_guidance_net_forward_ex(const rto_guidance_net* net, void* stream, const
 int rto_guidance_net_forward_packed(rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W, int flags);
 int rto_guidance_net_reserve(rto_guidance_net* net, int n, int H, int W);
 int rto_filtering_packed(const rto_guidance_net* net, void* stream, const float* img_in, float* img_out, int n, int H, int W);
+/* rto_filtering_packed that does not filter where there is nothing to filter: a 32x32 output tile whose inputs (its 40x40
+ * staged pixels and the 5x5 aux neighbourhood behind each of their map values) all lie inside the frame and in unmarked tiles
+ * of `tile_marks` (rto_ctx_tile_marks of the launch that rendered img_in and the network's aux; frame f of the marks = image
+ * f) reads only background pixels and the network's background maps.  Every such tile computes the same 32x32 values; the
+ * handle measures them once per `background` by running the two kernels on a synthetic background frame (the first call
+ * with a new brightness synchronises `stream`) and copies them instead.  Output = rto_filtering_packed bit for bit.
+ * tile_marks == NULL: rto_filtering_packed.
+ * rto_guidance_net_forward_packed_culled is the same idea one stage earlier: a 32x8 tile of the network whose 36x12 input
+ * pixels all lie inside the frame and in unmarked tiles is filled with the network's background output (8 fp16 values,
+ * measured on the same synthetic frame) instead of being computed.  Maps = rto_guidance_net_forward_packed's bit for bit. */
+int rto_guidance_net_forward_packed_culled(rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W, int flags,
+                                           const uint32_t* tile_marks, int words_per_frame, float background);
+int rto_filtering_packed_culled(rto_guidance_net* net, void* stream, const float* img_in, float* img_out, int n, int H, int W,
+                                const uint32_t* tile_marks, int words_per_frame, float background);
 void rto_guidance_net_free(rto_guidance_net* net);
 
 /* ---- profiling aid ---- */

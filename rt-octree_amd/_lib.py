@@ -83,6 +83,7 @@ SYMBOLS = {
     "rto_ctx_set_kernel": (C.c_int, [_P, C.c_int]),
     "rto_ctx_set_tuning": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "rto_ctx_queue_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "rto_ctx_tile_marks": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "rto_ctx_kernel_timing": (C.c_int, [_P, C.c_int]),
     "rto_ctx_kernel_timing_read": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "rto_ctx_kernel_timing_read3": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
@@ -104,6 +105,8 @@ SYMBOLS = {
     "rto_guidance_net_forward_ex": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int]),
     "rto_guidance_net_forward_packed": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rto_filtering_packed": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
+    "rto_guidance_net_forward_packed_culled": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_float]),
+    "rto_filtering_packed_culled": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_float]),
     "rto_guidance_net_reserve": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "rto_guidance_net_free": (None, [_P]),
     "rto_probe_gather": (C.c_int, [C.c_uint64, C.c_int]),

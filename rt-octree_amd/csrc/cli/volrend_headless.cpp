@@ -54,7 +54,7 @@ struct Args {
 const std::map<std::string, std::string> kShort = {{"w", "width"},      {"h", "height"},     {"s", "step_size"},
                                                    {"e", "stop_thresh"}, {"a", "sigma_thresh"}, {"o", "write_images"},
                                                    {"i", "intrin"},      {"r", "reverse_yz"}};
-const char* kFlags[] = {"reverse_yz", "write_buffer", "help", "print_poses", "quant_direct", "torch_net", "fast_filter", "rank_report", "compact_records"};
+const char* kFlags[] = {"reverse_yz", "write_buffer", "help", "print_poses", "quant_direct", "torch_net", "fast_filter", "rank_report", "compact_records", "no_denoise_cull"};
 
 bool is_flag(const std::string& k) {
     for (const char* f : kFlags)
@@ -125,6 +125,8 @@ void usage() {
         "  --quant_direct     render a quantised tree.npz from its codebooks (no expansion to dense fp16)\n"
         "  --compact_records  keep SH coefficient records for the leaves of positive density only (half the footprint of a\n"
         "                     dense SH9 / SH16 tree, same pixels, slower shading)\n"
+        "  --no_denoise_cull  with --fast_filter and a batch: run GuidanceNet and the filter on every tile, also those that see\n"
+        "                     only background (default: such tiles are filled with the kernels' background output; same pixels)\n"
         "  --print_poses      parse the poses, print them (column-major 4x3) and exit\n");
 }
 
@@ -413,21 +415,31 @@ int main(int argc, char** argv) {
 
     // Denoiser::denoise (denoiser.cpp:31-61) for the n frames in context slots 0..n-1 (the selected slot must be 0 for
     // n > 1).  Fused network + --fast_filter: the maps stay packed fp16 between the two kernels (same pixels as fp32 maps).
-    auto denoise_n = [&](int n, bool timed) -> int {
+    // after_batch: the frames are those of the rto_launch_renderer_batch just issued -- its tile marks tell both kernels which
+    // of their tiles see nothing but background (filled, not computed: same bits; --no_denoise_cull computes them all)
+    const bool denoise_cull = !args.has("no_denoise_cull");
+    auto denoise_n = [&](int n, bool timed, bool after_batch = false) -> int {
         const float *w = nullptr, *g = nullptr;
         int L = 0;
         int rc = RTO_OK;
+        const uint32_t* marks = nullptr;
+        int mark_words = 0, mark_slot = 0, mark_frames = 0;
+        float mark_bg = 0.f;
+        if (after_batch && denoise_cull &&
+            (rto_ctx_tile_marks(ctx, &marks, &mark_words, &mark_slot, &mark_frames, &mark_bg) != RTO_OK || mark_slot != 0 || mark_frames < n))
+            marks = nullptr;
         if (timed) rto_timer_start(ctx, RTO_T_TORCH);
         const bool packed = denoiser->fused() && filter_mode == RTO_FILTER_FACTORISED;
         if (packed)
-            rc = rto_guidance_net_forward_packed(denoiser->fused_handle(), stream, rto_ctx_aux(ctx), n, height, width,
-                                                 RTO_NET_AUX_SQUARES_IMPLIED);
+            rc = rto_guidance_net_forward_packed_culled(denoiser->fused_handle(), stream, rto_ctx_aux(ctx), n, height, width,
+                                                        RTO_NET_AUX_SQUARES_IMPLIED, marks, mark_words, mark_bg);
         else
             denoiser->forward(rto_ctx_aux(ctx), n, height, width, &w, &g, &L);
         if (timed) rto_timer_stop(ctx, RTO_T_TORCH);
         if (rc != RTO_OK) return rc;
         if (timed) rto_timer_start(ctx, RTO_T_FILTER);
-        rc = packed ? rto_filtering_packed(denoiser->fused_handle(), stream, rto_ctx_noisy(ctx), rto_ctx_image(ctx), n, height, width)
+        rc = packed ? rto_filtering_packed_culled(denoiser->fused_handle(), stream, rto_ctx_noisy(ctx), rto_ctx_image(ctx), n, height, width,
+                                                  marks, mark_words, mark_bg)
                     : rto_filtering_batch_mode(stream, w, g, L, height, width, n, rto_ctx_noisy(ctx), rto_ctx_image(ctx), filter_mode);
         if (timed) rto_timer_stop(ctx, RTO_T_FILTER);
         return rc;
@@ -481,7 +493,7 @@ int main(int argc, char** argv) {
             rto_timer_start(ctx, RTO_T_RENDER);
             CHECK_RTO(rto_launch_renderer_batch(tree, cams.data(), jumps.data(), n, &options, ctx, stream));
             rto_timer_stop(ctx, RTO_T_RENDER);
-            if (options.denoise) CHECK_RTO(denoise_n(n, true));
+            if (options.denoise) CHECK_RTO(denoise_n(n, true, true));
             CHECK_RTO(rto_timer_record(ctx, options.denoise));
             rendered += (size_t)n;
             if (out_dir.empty()) continue;

@@ -271,6 +271,15 @@ __global__ void __launch_bounds__(256, 2) filter_backward(const float4* __restri
 // Guard: E must not underflow inside a window.  GuidanceNet ends in ReLU6, so g lies in [0, 6]; for
 // arbitrary maps a tile whose in-image range of g_l exceeds 80 takes the per-pixel-maximum route below
 // (workgroup-uniform branch, taps read from global memory: slow, correct).
+// Empty-space culling carried into the filter (round 3): the render context's tile marks (FrameBatch::tile_mask: bit t = the
+// 8x8 render tile t may hold a ray that meets density; last word = keep the whole frame) and the filter's output for a pixel
+// whose whole neighbourhood is background.  mask == nullptr: off.
+struct FilterCull {
+    const uint32_t* mask;
+    int mask_words, tiles_x;
+    const float4* fill;  // [kFastH][kFastW]: the output tile of a workgroup that sees only background
+};
+constexpr int kMapHalo = 2;  // a GuidanceNet map value depends on the 5x5 aux pixels around it (two 3x3 convolutions)
 constexpr int kFastW = 32, kFastH = 32, kFastRows = 4;  // outputs per workgroup; rows per thread
 
 template <int S, int SW>
@@ -343,8 +352,37 @@ __global__ void __launch_bounds__(256, 3) filter_fast(const float* __restrict__ 
                                                      const float* __restrict__ guidance,  // [n][L][H][W]
                                                      const float4* __restrict__ img_in,   // [n][H][W]
                                                      float4* __restrict__ img_out,        // [n][H][W]
-                                                     int H, int W) {
+                                                     int H, int W, const FilterCull cull) {
     constexpr int SW = kFastW + 2 * L, SH = kFastH + 2 * L, NE = SW * SH;
+    if (cull.mask) {
+        // A workgroup whose staged region (outputs + halo), grown by the network's receptive field, lies inside the image and
+        // inside culled render tiles reads nothing but background pixels and the network's background maps.  Its arithmetic
+        // is then the same as that of any other such workgroup, thread for thread: the output tile is the one this very
+        // kernel produced once on a synthetic background image (FilterCull::fill).
+        constexpr int RW = SW + 2 * kMapHalo, RH = SH + 2 * kMapHalo;
+        const int rx0 = (int)blockIdx.x * kFastW - L - kMapHalo, ry0 = (int)blockIdx.y * kFastH - L - kMapHalo;
+        bool skip = rx0 >= 0 && ry0 >= 0 && rx0 + RW <= W && ry0 + RH <= H;  // (workgroup-uniform)
+        if (skip) {
+            const uint32_t* fm = cull.mask + (size_t)blockIdx.z * cull.mask_words;
+            const int tx0 = rx0 >> 3, ty0 = ry0 >> 3, nx = ((rx0 + RW - 1) >> 3) - tx0 + 1, ny = ((ry0 + RH - 1) >> 3) - ty0 + 1;
+            int any = 0;
+            if ((int)threadIdx.x < nx * ny) {
+                const int ty = ty0 + (int)threadIdx.x / nx, tx = tx0 + (int)threadIdx.x % nx;
+                const uint32_t t = (uint32_t)(ty * cull.tiles_x + tx);
+                any = (int)(((fm[t >> 5] >> (t & 31u)) | fm[cull.mask_words - 1]) & 1u);
+            }
+            skip = !__syncthreads_or(any);
+        }
+        if (skip) {
+            const int lx = threadIdx.x & (kFastW - 1), ry = threadIdx.x / kFastW;
+            float4* out = img_out + (int64_t)blockIdx.z * H * W;
+#pragma unroll
+            for (int r = 0; r < kFastRows; ++r)
+                out[(int64_t)(blockIdx.y * kFastH + ry * kFastRows + r) * W + blockIdx.x * kFastW + lx] =
+                    cull.fill[(ry * kFastRows + r) * kFastW + lx];
+            return;
+        }
+    }
     constexpr int PER = (NE + 255) / 256;  // staged elements per thread
     extern __shared__ float4 s_dyn[];
     float4* s_rgb = s_dyn;       // [SH][SW] noisy tile, 0 outside the image
@@ -488,11 +526,16 @@ __global__ void __launch_bounds__(256, 3) filter_fast(const float* __restrict__ 
 }
 
 hipError_t launch_filter_fast_packed(const void* packed_maps, int H, int W, int n, const float* img_in, float* img_out,
-                                     hipStream_t stream) {
+                                     const uint32_t* tile_mask, int mask_words, const float* fill_tile, hipStream_t stream) {
     const dim3 grid((W + kFastW - 1) / kFastW, (H + kFastH - 1) / kFastH, n), block(256);
     const size_t lds = (size_t)2 * (kFastW + 8) * (kFastH + 8) * sizeof(float4);
+    FilterCull cull;
+    cull.mask = tile_mask;
+    cull.mask_words = mask_words;
+    cull.tiles_x = (W + 7) / 8;
+    cull.fill = reinterpret_cast<const float4*>(fill_tile);
     hipLaunchKernelGGL((filter_fast<4, true>), grid, block, lds, stream, reinterpret_cast<const float*>(packed_maps),
-                       (const float*)nullptr, reinterpret_cast<const float4*>(img_in), reinterpret_cast<float4*>(img_out), H, W);
+                       (const float*)nullptr, reinterpret_cast<const float4*>(img_in), reinterpret_cast<float4*>(img_out), H, W, cull);
     return hipGetLastError();
 }
 
@@ -504,7 +547,7 @@ hipError_t launch_filter_fast(const float* weight, const float* guidance, int L,
 #define RTO_FFAST(LL)                                                                                              \
     case LL: {                                                                                                     \
         const size_t lds = (size_t)2 * (kFastW + 2 * LL) * (kFastH + 2 * LL) * sizeof(float4);                     \
-        hipLaunchKernelGGL((filter_fast<LL, false>), grid, block, lds, stream, weight, guidance, in4, out4, H, W);          \
+        hipLaunchKernelGGL((filter_fast<LL, false>), grid, block, lds, stream, weight, guidance, in4, out4, H, W, FilterCull{nullptr, 0, 0, nullptr}); \
     } break;
     switch (L) {
         RTO_FFAST(1) RTO_FFAST(2) RTO_FFAST(3) RTO_FFAST(4) RTO_FFAST(5) RTO_FFAST(6)

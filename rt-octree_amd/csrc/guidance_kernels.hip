@@ -47,6 +47,15 @@ constexpr int kCIn = 8;           // aux channels (render_context.hpp:23)
 
 __device__ __forceinline__ float relu6(float x) { return fminf(fmaxf(x, 0.f), 6.f); }
 
+// Empty-space culling carried into the network (round 3; PACK route): the render context's tile marks (FrameBatch::tile_mask)
+// and the network's output for a pixel whose 5x5 aux neighbourhood is background -- 8 fp16 values, measured once by this
+// kernel on a synthetic background frame.  mask == nullptr: off.
+struct NetCull {
+    const uint32_t* mask;
+    int mask_words, tiles_x;
+    uint4 fill;
+};
+
 // C1 = mid channels (multiple of 16, <= 64), L = kernel levels (2L <= 16)
 // SQ: the aux planes 4..7 are the squares of planes 0..3 (what the renderer writes, volrend.cu:195-202:
 // a[4 + c] = out[c] * out[c], one fp32 multiply): read only planes 0..3 and square them here -- the same fp32
@@ -62,7 +71,7 @@ __global__ void __launch_bounds__(256, 4) guidance_fused(const float* __restrict
                                                        const float* __restrict__ b2,     // [16]
                                                        float* __restrict__ weight_out,   // [n][L][H][W]
                                                        float* __restrict__ guidance_out, // [n][L][H][W]
-                                                       int H, int W) {
+                                                       int H, int W, const NetCull cull) {
     constexpr int IW = kGW + 4, IH = kGH + 4;  // input tile with halo 2
     constexpr int AW = kGW + 2, AH = kGH + 2;  // layer-1 activation tile with halo 1
     constexpr int NT1 = C1 / 16;               // output-channel tiles of layer 1
@@ -98,6 +107,41 @@ __global__ void __launch_bounds__(256, 4) guidance_fused(const float* __restrict
     guidance_out += (int64_t)blockIdx.z * L * HW;
 
     const int col = lane & 15, kg = lane >> 4;  // MFMA lane roles: pixel (B/C column), k-group / row block
+
+    // Tiles of the strip whose input region (tile + halo 2) lies inside the image and in culled render tiles read nothing
+    // but background: every output pixel is cull.fill.  Bit ts of `skip_tiles`; workgroup-uniform.
+    uint32_t skip_tiles = 0;
+    if (PACK && cull.mask) {
+        __shared__ uint32_t s_live;
+        if (tid == 0) s_live = 0;
+        __syncthreads();
+        constexpr int RX = (IW + 7) / 8 + 1, RY = (IH + 7) / 8 + 1;  // render tiles an input region can touch, per axis
+        static_assert(kStrip * RX * RY <= 256, "one thread per (strip tile, render tile)");
+        if (tid < kStrip * RX * RY) {
+            const int ts = tid / (RX * RY), sub = tid - ts * (RX * RY), sy = sub / RX, sx = sub - sy * RX;
+            const int x0 = (tx_first + ts) * kGW - 2, ry0 = y0 - 2;
+            bool live = false;
+            if (tx_first + ts < tiles_x) {
+                if (x0 < 0 || ry0 < 0 || x0 + IW > W || ry0 + IH > H) {
+                    live = true;  // the zero padding is not background
+                } else {
+                    const int tx = (x0 >> 3) + sx, ty = (ry0 >> 3) + sy;
+                    if (tx <= ((x0 + IW - 1) >> 3) && ty <= ((ry0 + IH - 1) >> 3)) {
+                        const uint32_t* fm = cull.mask + (size_t)blockIdx.z * cull.mask_words;
+                        const uint32_t t = (uint32_t)(ty * cull.tiles_x + tx);
+                        live = (((fm[t >> 5] >> (t & 31u)) | fm[cull.mask_words - 1]) & 1u) != 0;
+                    }
+                }
+            }
+            if (live) atomicOr(&s_live, 1u << ts);
+        }
+        __syncthreads();
+        skip_tiles = (uint32_t)__builtin_amdgcn_readfirstlane((int)~s_live);
+    }
+    auto next_live = [&](int ts) {  // first tile >= ts of the strip that has to be computed (kStrip: none)
+        while (ts < kStrip && tx_first + ts < tiles_x && ((skip_tiles >> ts) & 1u)) ++ts;
+        return (ts < kStrip && tx_first + ts < tiles_x) ? ts : kStrip;
+    };
 
     // Weights first: their loads overlap stage A instead of stalling the first MFMAs of each layer.
     half8 wa[NT1][3];
@@ -139,13 +183,18 @@ __global__ void __launch_bounds__(256, 4) guidance_fused(const float* __restrict
     unsigned long long st[8];
     st[0] = __builtin_amdgcn_s_memtime();
 #endif
-    fetch(tx_first * kGW);
+    if (PACK && cull.mask) {  // the skipped tiles first (interior tiles: every pixel of them is inside the image)
+        for (int ts = 0; ts < kStrip && tx_first + ts < tiles_x; ++ts)
+            if ((skip_tiles >> ts) & 1u)
+                reinterpret_cast<uint4*>(weight_out)[(int64_t)(y0 + (tid >> 5)) * W + (tx_first + ts) * kGW + (tid & 31)] = cull.fill;
+    }
+    int ts_live = next_live(0);
+    if (ts_live < kStrip) fetch((tx_first + ts_live) * kGW);
 
 #pragma nounroll
-    for (int ts = 0; ts < kStrip; ++ts) {
-    const int tile_x = tx_first + ts;
-    if (tile_x >= tiles_x) break;  // workgroup-uniform
-    const int x0 = tile_x * kGW;
+    while (ts_live < kStrip) {  // (workgroup-uniform)
+    const int x0 = (tx_first + ts_live) * kGW;
+    ts_live = next_live(ts_live + 1);
     const bool tile_interior = x0 >= 1 && x0 + kGW + 1 <= W && y0 >= 1 && y0 + kGH + 1 <= H;  // layer-1 region inside the image
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -162,13 +211,13 @@ __global__ void __launch_bounds__(256, 4) guidance_fused(const float* __restrict
         }
     }
 #ifdef RTO_NET_DBG_STAMP
-    if (ts == 0) st[1] = __builtin_amdgcn_s_memtime();
+    if (x0 == tx_first * kGW) st[1] = __builtin_amdgcn_s_memtime();
 #endif
     __syncthreads();  // s_in complete; every wave is also done with stage C of the previous tile (s_act is free)
 #ifdef RTO_NET_DBG_STAMP
-    if (ts == 0) st[2] = __builtin_amdgcn_s_memtime();
+    if (x0 == tx_first * kGW) st[2] = __builtin_amdgcn_s_memtime();
 #endif
-    if (ts + 1 < kStrip && tile_x + 1 < tiles_x) fetch(x0 + kGW);  // next tile's input: in flight during stages B and C
+    if (ts_live < kStrip) fetch((tx_first + ts_live) * kGW);  // next computed tile's input: in flight during stages B and C
 
 
     // ---- stage B: layer 1 on the AH x AW region
@@ -247,11 +296,11 @@ __global__ void __launch_bounds__(256, 4) guidance_fused(const float* __restrict
             layer1(std::false_type{});
     }
 #ifdef RTO_NET_DBG_STAMP
-    if (ts == 0) st[3] = __builtin_amdgcn_s_memtime();
+    if (x0 == tx_first * kGW) st[3] = __builtin_amdgcn_s_memtime();
 #endif
     __syncthreads();
 #ifdef RTO_NET_DBG_STAMP
-    if (ts == 0) st[4] = __builtin_amdgcn_s_memtime();
+    if (x0 == tx_first * kGW) st[4] = __builtin_amdgcn_s_memtime();
 #endif
 
     // ---- stage C: layer 2 on the kGH x kGW tile, softmax, stores
@@ -323,7 +372,7 @@ __global__ void __launch_bounds__(256, 4) guidance_fused(const float* __restrict
         }
     }
 #ifdef RTO_NET_DBG_STAMP
-    if (ts == 0) {
+    if (x0 == tx_first * kGW) {
         st[5] = __builtin_amdgcn_s_memtime();
         if ((blockIdx.x == 3 || blockIdx.x == 11) && (blockIdx.y == 40 || blockIdx.y == 41) && blockIdx.z == 2 && lane == 0)
             printf("blk %d,%d wave %d: fetch+wait+cvt %llu | sync %llu | B %llu | sync %llu | C %llu | start %llu\n", blockIdx.x, blockIdx.y, wave,
@@ -337,14 +386,20 @@ __global__ void __launch_bounds__(256, 4) guidance_fused(const float* __restrict
 
 hipError_t launch_guidance_net(const float* aux, const void* w1, const void* w2, const float* b2, int c1,
                                int levels, int n, int H, int W, float* weight_out, float* guidance_out,
-                               bool squares_implied, hipStream_t stream) {
+                               bool squares_implied, const uint32_t* tile_mask, int mask_words, const uint32_t* fill_k,
+                               hipStream_t stream) {
     if (c1 != 32 || levels != 4) return hipErrorInvalidValue;  // the reference configuration (blender.txt:21-25)
     const int tiles_x = (W + kGW - 1) / kGW;
     const dim3 grid((tiles_x + kStrip - 1) / kStrip, (H + kGH - 1) / kGH, n), block(256);
     const bool pack = guidance_out == nullptr;  // weight_out is then the packed fp16 buffer [n][H][W][8]
+    NetCull cull;
+    cull.mask = pack && fill_k ? tile_mask : nullptr;
+    cull.mask_words = mask_words;
+    cull.tiles_x = (W + 7) / 8;
+    cull.fill = cull.mask ? make_uint4(fill_k[0], fill_k[1], fill_k[2], fill_k[3]) : make_uint4(0u, 0u, 0u, 0u);
 #define RTO_NET(SQ, PK)                                                                                                   \
     hipLaunchKernelGGL((guidance_fused<32, 4, SQ, PK>), grid, block, 0, stream, aux, (const _Float16*)w1, (const _Float16*)w2,     \
-                       b2, weight_out, guidance_out, H, W)
+                       b2, weight_out, guidance_out, H, W, cull)
     if (pack) {
         if (squares_implied) RTO_NET(true, true); else RTO_NET(false, true);
     } else {

@@ -125,6 +125,8 @@ struct rto_ctx {
     bool cull_on = true;
     int last_n_queues = 0;                // of the last batched launch (rto_ctx_queue_stats)
     int64_t last_slots = 0;
+    int marks_n = 0, marks_slot0 = 0;     // frames whose tile marks the last launch left in tile_mask (0: none), their first slot
+    float marks_bg = 0.f;                 // ... and the background brightness of that launch
     // per-kernel event timing of the batched path (off by default)
     bool kt_on = false;
     std::vector<hipEvent_t> kt_ev;  // kKtRing quadruples
@@ -1153,6 +1155,18 @@ int rto_ctx_queue_stats(rto_ctx* c, int64_t* live_tile_slots, int64_t* all_tile_
     return RTO_OK;
 }
 
+int rto_ctx_tile_marks(const rto_ctx* c, const uint32_t** marks, int* words_per_frame, int* first_slot, int* frames, float* background) {
+    if (!c || !marks || !words_per_frame || !first_slot || !frames || !background)
+        return set_err(RTO_E_INVALID, "rto_ctx_tile_marks: null argument");
+    if (c->marks_n < 1 || !c->tile_mask) return set_err(RTO_E_INVALID, "rto_ctx_tile_marks: the last launch on this context was not a batched one");
+    *marks = c->tile_mask;
+    *words_per_frame = c->mask_words;
+    *first_slot = c->marks_slot0;
+    *frames = c->marks_n;
+    *background = c->marks_bg;
+    return RTO_OK;
+}
+
 int rto_ctx_enable_stats(rto_ctx* c, int enable) {
     if (!c) return set_err(RTO_E_INVALID, "rto_ctx_enable_stats: null context");
     DeviceGuard guard(c->device);
@@ -1234,6 +1248,7 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
         fo.stats = ctx->stats;
     }
 
+    ctx->marks_n = 0;  // (the per-frame kernels mark no tiles)
     hipError_t e = rto::launch_render(kernel, o->spp, tree->dev, cd, od, ctx->rng, ctx->jump, fo, ctx->strip_rows, stream);
     if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("render launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
@@ -1390,6 +1405,7 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     HIP_TRY(rto::launch_write_frames(frames, n, ctx->d_frames, stream));
     hipEvent_t* ev = nullptr;
     if (ctx->kt_on && ctx->kt_count < kKtRing) ev = &ctx->kt_ev[(size_t)ctx->kt_count++ * 4];
+    ctx->marks_n = 0;
     hipError_t e = rto::launch_render_batch(o->spp, tree->dev, od, fb, ctx->jump, ctx->queue,
                                             ctx->hits + (size_t)slot0 * o->spp * px,  // = fb.f[0].hits: the kernel indexes frames from here
                                             ctx->num_cus, ctx->refill, cull, &ctx->occ, ev, stream);
@@ -1400,6 +1416,9 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
                                           " frames exceeds what the device grants a workgroup; render fewer samples per launch or "
                                           "frame by frame with the generic kernel (rto_ctx_set_kernel)");
     if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("batched render launch failed: ") + hipGetErrorString(e));
+    ctx->marks_n = n;
+    ctx->marks_slot0 = slot0;
+    ctx->marks_bg = o->background_brightness;
     return RTO_OK;
 }
 

@@ -1,6 +1,8 @@
 // rto_guidance_abi.cpp -- C ABI of the fused GuidanceNet forward (include/rto.h, guidance_kernels.hip).
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -17,6 +19,12 @@ struct rto_guidance_net {
     void* packed = nullptr;      // scratch of the packed route: fp16 [n][H][W][8]
     size_t packed_bytes = 0;
     int packed_n = 0, packed_h = 0, packed_w = 0;  // what the scratch currently holds
+    // rto_filtering_packed_culled: the filter's output tile over pure background of brightness fill_bg (see ensure_fill_tile)
+    std::mutex fill_mu;
+    float* fill_tile = nullptr;  // device [32][32][4]
+    uint32_t fill_k[4] = {0, 0, 0, 0};  // ... and the network's 8 fp16 outputs for a pixel whose neighbourhood is background
+    float fill_bg = 0.f;
+    bool fill_valid = false;
 };
 
 namespace {
@@ -95,7 +103,7 @@ int rto_guidance_net_forward_ex(const rto_guidance_net* net, void* stream, const
         return fail(RTO_E_INVALID, "rto_guidance_net_forward: bad argument");
     DeviceScope scope(net->device);
     const hipError_t e = rto::launch_guidance_net(aux, net->w1, net->w2, net->b2, net->c1, net->levels, n, H, W,
-                                                  weight_map, guidance_map, (flags & RTO_NET_AUX_SQUARES_IMPLIED) != 0,
+                                                  weight_map, guidance_map, (flags & RTO_NET_AUX_SQUARES_IMPLIED) != 0, nullptr, 0, nullptr,
                                                   (hipStream_t)stream);
     if (e != hipSuccess) return fail(RTO_E_HIP, std::string("GuidanceNet launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
@@ -132,20 +140,40 @@ int rto_guidance_net_reserve(rto_guidance_net* net, int n, int H, int W) {
     return reserve_packed(net, n, H, W);
 }
 
-int rto_guidance_net_forward_packed(rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W, int flags) {
+static int ensure_fill_tile(rto_guidance_net* net, float bg, hipStream_t stream);
+static int check_marks(const char* who, const rto_guidance_net* net, const uint32_t* tile_marks, int words_per_frame, int H, int W) {
+    const int tiles = ((W + 7) / 8) * ((H + 7) / 8);
+    if (words_per_frame != (tiles + 31) / 32 + 1)
+        return fail(RTO_E_INVALID, std::string(who) + ": the tile marks are not those of a " + std::to_string(H) + " x " + std::to_string(W) +
+                                       " frame (rto_ctx_tile_marks)");
+    if (pointer_device(tile_marks) != net->device)
+        return fail(RTO_E_INVALID, std::string(who) + ": the tile marks are not memory of the network's device");
+    return RTO_OK;
+}
+
+int rto_guidance_net_forward_packed_culled(rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W, int flags,
+                                           const uint32_t* tile_marks, int words_per_frame, float background) {
     if (!net || !aux || n < 1 || H < 1 || W < 1) return fail(RTO_E_INVALID, "rto_guidance_net_forward_packed: bad argument");
     if (pointer_device(aux) != net->device)
         return fail(RTO_E_INVALID, "rto_guidance_net_forward_packed: aux is not memory of the network's device");
     DeviceScope scope(net->device);
     if (const int rc = reserve_packed(net, n, H, W)) return rc;
+    if (tile_marks) {
+        if (const int rc = check_marks("rto_guidance_net_forward_packed_culled", net, tile_marks, words_per_frame, H, W)) return rc;
+        if (const int rc = ensure_fill_tile(net, background, (hipStream_t)stream)) return rc;
+    }
     const hipError_t e = rto::launch_guidance_net(aux, net->w1, net->w2, net->b2, net->c1, net->levels, n, H, W,
                                                   (float*)net->packed, nullptr, (flags & RTO_NET_AUX_SQUARES_IMPLIED) != 0,
-                                                  (hipStream_t)stream);
+                                                  tile_marks, words_per_frame, tile_marks ? net->fill_k : nullptr, (hipStream_t)stream);
     if (e != hipSuccess) return fail(RTO_E_HIP, std::string("GuidanceNet launch failed: ") + hipGetErrorString(e));
     net->packed_n = n;
     net->packed_h = H;
     net->packed_w = W;
     return RTO_OK;
+}
+
+int rto_guidance_net_forward_packed(rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W, int flags) {
+    return rto_guidance_net_forward_packed_culled(net, stream, aux, n, H, W, flags, nullptr, 0, 0.f);
 }
 
 int rto_filtering_packed(const rto_guidance_net* net, void* stream, const float* img_in, float* img_out, int n, int H, int W) {
@@ -161,7 +189,76 @@ int rto_filtering_packed(const rto_guidance_net* net, void* stream, const float*
         return fail(RTO_E_INVALID, "rto_filtering_packed: the images are not memory of the network's device");
     DeviceScope scope(net->device);
     const hipError_t e = rto::launch_filter_fast_packed(net->packed, net->packed_h, net->packed_w, net->packed_n, img_in, img_out,
-                                                        (hipStream_t)stream);
+                                                        nullptr, 0, nullptr, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(RTO_E_HIP, std::string("filter launch failed: ") + hipGetErrorString(e));
+    return RTO_OK;
+}
+
+// The output tile of a filter workgroup that sees nothing but background: run the two real kernels once on a synthetic
+// 96 x 96 background frame (aux = what write_pixel stores for a ray that meets nothing: colour = bg, alpha = 0) and keep
+// the tile of the centre workgroup, whose staged region + the network's receptive field lie inside the frame.  Any other
+// such workgroup executes the same instructions on the same values, thread for thread.
+static int ensure_fill_tile(rto_guidance_net* net, float bg, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(net->fill_mu);
+    if (net->fill_valid && std::memcmp(&net->fill_bg, &bg, sizeof(float)) == 0) return RTO_OK;
+    constexpr int S = 3 * rto::kFilterFillSide, T = rto::kFilterFillSide;
+    const size_t px = (size_t)S * S;
+    std::vector<float> aux(8 * px, 0.f), img(4 * px);
+    for (size_t i = 0; i < px; ++i) {
+        for (int c = 0; c < 3; ++c) {
+            aux[c * px + i] = bg;
+            aux[(4 + c) * px + i] = bg * bg;
+            img[4 * i + c] = bg;
+        }
+        img[4 * i + 3] = 1.f;
+    }
+    float *d_aux = nullptr, *d_img = nullptr, *d_out = nullptr;
+    void* d_maps = nullptr;
+    auto cleanup = [&] {
+        for (void* p : {(void*)d_aux, (void*)d_img, (void*)d_out, d_maps})
+            if (p) (void)hipFree(p);
+    };
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) { return (e = r) == hipSuccess; };
+    if (!net->fill_tile && !ok(hipMalloc((void**)&net->fill_tile, (size_t)T * T * 4 * sizeof(float))))
+        return fail(RTO_E_HIP, std::string("fill tile: ") + hipGetErrorString(e));
+    if (!ok(hipMalloc((void**)&d_aux, aux.size() * sizeof(float))) || !ok(hipMalloc((void**)&d_img, img.size() * sizeof(float))) ||
+        !ok(hipMalloc((void**)&d_out, img.size() * sizeof(float))) || !ok(hipMalloc(&d_maps, px * 8 * sizeof(uint16_t))) ||
+        !ok(hipMemcpyAsync(d_aux, aux.data(), aux.size() * sizeof(float), hipMemcpyHostToDevice, stream)) ||
+        !ok(hipMemcpyAsync(d_img, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, stream)) ||
+        !ok(rto::launch_guidance_net(d_aux, net->w1, net->w2, net->b2, net->c1, net->levels, 1, S, S, (float*)d_maps, nullptr, false, nullptr, 0, nullptr, stream)) ||
+        !ok(rto::launch_filter_fast_packed(d_maps, S, S, 1, d_img, d_out, nullptr, 0, nullptr, stream)) ||
+        !ok(hipMemcpy2DAsync(net->fill_tile, (size_t)T * 4 * sizeof(float), d_out + ((size_t)T * S + T) * 4, (size_t)S * 4 * sizeof(float),
+                             (size_t)T * 4 * sizeof(float), T, hipMemcpyDeviceToDevice, stream)) ||
+        !ok(hipMemcpyAsync(net->fill_k, (const char*)d_maps + ((size_t)(S / 2) * S + S / 2) * 16, 16, hipMemcpyDeviceToHost, stream)) ||
+        !ok(hipStreamSynchronize(stream))) {
+        cleanup();
+        net->fill_valid = false;
+        return fail(RTO_E_HIP, std::string("fill tile: ") + hipGetErrorString(e));
+    }
+    cleanup();
+    net->fill_bg = bg;
+    net->fill_valid = true;
+    return RTO_OK;
+}
+
+int rto_filtering_packed_culled(rto_guidance_net* net, void* stream, const float* img_in, float* img_out, int n, int H, int W,
+                                const uint32_t* tile_marks, int words_per_frame, float background) {
+    if (!tile_marks) return rto_filtering_packed(net, stream, img_in, img_out, n, H, W);
+    if (!net || !img_in || !img_out || img_in == img_out) return fail(RTO_E_INVALID, "rto_filtering_packed_culled: bad argument");
+    if (!net->packed || net->packed_n < 1)
+        return fail(RTO_E_INVALID, "rto_filtering_packed_culled: no packed maps (call rto_guidance_net_forward_packed first)");
+    if (n != net->packed_n || H != net->packed_h || W != net->packed_w)
+        return fail(RTO_E_INVALID, "rto_filtering_packed_culled: " + std::to_string(n) + " x " + std::to_string(H) + " x " + std::to_string(W) +
+                                       " images, but the packed maps hold " + std::to_string(net->packed_n) + " x " +
+                                       std::to_string(net->packed_h) + " x " + std::to_string(net->packed_w));
+    if (const int rc = check_marks("rto_filtering_packed_culled", net, tile_marks, words_per_frame, H, W)) return rc;
+    if (pointer_device(img_out) != net->device || pointer_device(img_in) != net->device)
+        return fail(RTO_E_INVALID, "rto_filtering_packed_culled: the images are not memory of the network's device");
+    DeviceScope scope(net->device);
+    if (const int rc = ensure_fill_tile(net, background, (hipStream_t)stream)) return rc;
+    const hipError_t e = rto::launch_filter_fast_packed(net->packed, net->packed_h, net->packed_w, net->packed_n, img_in, img_out,
+                                                        tile_marks, words_per_frame, net->fill_tile, (hipStream_t)stream);
     if (e != hipSuccess) return fail(RTO_E_HIP, std::string("filter launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
 }
@@ -170,6 +267,7 @@ void rto_guidance_net_free(rto_guidance_net* net) {
     if (!net) return;
     DeviceScope scope(net->device);
     if (net->packed) (void)hipFree(net->packed);
+    if (net->fill_tile) (void)hipFree(net->fill_tile);
     if (net->w1) (void)hipFree(net->w1);
     if (net->w2) (void)hipFree(net->w2);
     if (net->b2) (void)hipFree(net->b2);

@@ -211,22 +211,39 @@ class FusedGuidanceNet:
         from ._lib import check, lib
         check(lib().rto_guidance_net_reserve(self._h, int(n), int(H), int(W)))
 
-    def forward_packed(self, aux, stream=None, squares_implied=False):
-        """the network, its 8 fp16 output channels kept packed in the handle's scratch (rto_guidance_net_forward_packed)"""
+    def forward_packed(self, aux, stream=None, squares_implied=False, cull=None):
+        """the network, its 8 fp16 output channels kept packed in the handle's scratch (rto_guidance_net_forward_packed).
+        cull = RenderContext.tile_marks() of the launch that rendered aux (frames in order): network tiles whose inputs are
+        all background get the network's background output without being computed (same bits)"""
         from ._lib import check, lib
         n, c, H, W = aux.shape
         assert c == 8 and aux.dtype == torch.float32 and aux.is_contiguous()
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
-        check(lib().rto_guidance_net_forward_packed(self._h, V._stream_ptr(s), aux.data_ptr(), n, H, W, 1 if squares_implied else 0))
+        marks, words, bg = (None, 0, 0.0)
+        if cull is not None:
+            marks, words, _slot0, frames, bg = cull
+            if frames < n:
+                raise ValueError("forward_packed: %d frames but tile marks of %d" % (n, frames))
+        check(lib().rto_guidance_net_forward_packed_culled(self._h, V._stream_ptr(s), aux.data_ptr(), n, H, W, 1 if squares_implied else 0,
+                                                           marks, int(words), float(bg)))
         self._packed_shape = (n, H, W)
 
-    def filter_packed(self, img_in, img_out, stream=None, shape=None):
+    def filter_packed(self, img_in, img_out, stream=None, shape=None, cull=None):
         """factorised filter on the packed maps of the last forward_packed: img_in / img_out device pointers or tensors
-        of `shape` = (n, H, W) images (default: the extent of that forward; the library refuses any other)"""
+        of `shape` = (n, H, W) images (default: the extent of that forward; the library refuses any other).
+        cull = RenderContext.tile_marks() of the launch that rendered img_in (images = the marks' frames, in order): tiles
+        that see only background are copied, not filtered (rto_filtering_packed_culled; same bits)"""
         from ._lib import check, lib
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
         n, H, W = shape if shape is not None else self._packed_shape
-        check(lib().rto_filtering_packed(self._h, V._stream_ptr(s), V._dev_ptr(img_in), V._dev_ptr(img_out), int(n), int(H), int(W)))
+        if cull is None:
+            check(lib().rto_filtering_packed(self._h, V._stream_ptr(s), V._dev_ptr(img_in), V._dev_ptr(img_out), int(n), int(H), int(W)))
+            return
+        marks, words, _slot0, frames, bg = cull
+        if frames < n:
+            raise ValueError("filter_packed: %d images but tile marks of %d frames" % (n, frames))
+        check(lib().rto_filtering_packed_culled(self._h, V._stream_ptr(s), V._dev_ptr(img_in), V._dev_ptr(img_out), int(n), int(H), int(W),
+                                                marks, int(words), float(bg)))
 
     def __del__(self):
         try:

@@ -340,6 +340,14 @@ class RenderContext:
         check(lib().rto_ctx_queue_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def tile_marks(self):
+        """(device pointer, words per frame, first slot, frames, background) of the tile marks the last batched launch left
+        (rto_ctx_tile_marks) -- what FusedGuidanceNet.filter_packed(cull=...) takes; None after a single-frame launch"""
+        p, w, s0, n, bg = C.c_void_p(None), C.c_int(0), C.c_int(0), C.c_int(0), C.c_float(0)
+        if lib().rto_ctx_tile_marks(self._h, C.byref(p), C.byref(w), C.byref(s0), C.byref(n), C.byref(bg)) != 0:
+            return None
+        return p.value, w.value, s0.value, n.value, bg.value
+
     def enable_stats(self, on=True):
         """Work counters for the roofline's algorithmic byte count (never in a timed run)."""
         check(lib().rto_ctx_enable_stats(self._h, int(bool(on))))

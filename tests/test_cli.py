@@ -186,6 +186,25 @@ def test_cli_fast_filter_route(tmp_path):
     assert changed < 0.002 * 3 * 96 * 72 * 4  # a handful of LSB flips at most
 
 
+@pytest.mark.gpu
+def test_cli_denoise_cull_same_pngs(tmp_path):
+    """the batched --fast_filter loop fills the GuidanceNet / filter tiles that see only culled render tiles: same PNG
+    bytes as with --no_denoise_cull, on frames large enough to hold such tiles"""
+    from PIL import Image
+    tree, tp, poses, pp = _scene(tmp_path, n=3)
+    tsp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ts_ref_format.ts")
+    op = synth.write_opt_json(str(tmp_path / "opt.json"))
+    outs = {}
+    for name, extra in (("cull", []), ("all", ["--no_denoise_cull"])):
+        out = str(tmp_path / name)
+        r = _run([tp, pp, "--options", op, "--ts_module", tsp, "-w", "400", "-h", "304", "-o", out, "--warmup", "1", "--fast_filter"] + extra)
+        assert r.returncode == 0, r.stderr
+        outs[name] = [np.array(Image.open(os.path.join(out, "r_%d.png" % i))) for i in range(3)]
+    for i in range(3):
+        assert np.array_equal(outs["cull"][i], outs["all"][i]), i
+        assert (outs["cull"][i][..., :3] != 255).any()
+
+
 def _parse_poses(out):
     lines = [l for l in out.splitlines() if l and not l.startswith("INFO")]
     head = lines[0].split()

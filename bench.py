@@ -376,9 +376,16 @@ def main():
                 if ev:
                     ev[2].record(lstream)
                 lnet.filter_packed(lctx.noisy_ptr, lctx.image_ptr, stream=lstream, shape=(n, H, W), cull=marks)
+            elif not args.torch_net:  # fp32 weight / guidance planes (the reference's tensors); exact: the bit-exact filter
+                marks = None if args.no_filter_cull else lctx.tile_marks()
+                wm, gm = lnet(laux[:n], stream=lstream, squares_implied=True, cull=marks if args.net_cull else None)
+                if ev:
+                    ev[2].record(lstream)
+                lnet.filter_planes(wm, gm, lctx.noisy_ptr, lctx.image_ptr, mode=R.FILTER_EXACT if exact else filter_mode,
+                                   stream=lstream, cull=marks)
             else:
                 with torch.no_grad(), torch.cuda.stream(lstream):
-                    wm, gm = lnet(laux[:n], stream=lstream, squares_implied=True) if not args.torch_net else lnet(laux[:n])
+                    wm, gm = lnet(laux[:n])
                 if ev:
                     ev[2].record(lstream)
                 R.filtering(lstream, wm, gm, lctx.noisy_ptr, lctx.image_ptr, mode=R.FILTER_EXACT if exact else filter_mode)
@@ -522,10 +529,11 @@ def main():
             if denoise:
                 lctx.select_frame(0)
                 if packed_route:
-                    lnet.forward_packed(laux[:1], stream=lstream, squares_implied=True)
+                    marks = None if args.no_filter_cull else lctx.tile_marks()  # (None after the single-frame kernels)
+                    lnet.forward_packed(laux[:1], stream=lstream, squares_implied=True, cull=marks if args.net_cull else None)
                     if evs:
                         evs[2].record(lstream)
-                    lnet.filter_packed(lctx.noisy_ptr, lctx.image_ptr, stream=lstream, shape=(1, H, W))
+                    lnet.filter_packed(lctx.noisy_ptr, lctx.image_ptr, stream=lstream, shape=(1, H, W), cull=marks)
                 else:
                     with torch.no_grad(), torch.cuda.stream(lstream):
                         wm, gm = lnet(laux[:1], stream=lstream, squares_implied=True) if not args.torch_net else lnet(laux[:1])
@@ -540,7 +548,12 @@ def main():
                 return None
             return compact.half().to(dev) if args.torch_net else denoiser.FusedGuidanceNet(compact, device=local_rank)
 
-        one = R.RenderContext(W, H, device=local_rank, frames=1)
+        def tune(c):
+            for kv in filter(None, args.tuning.split(",")):
+                c.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
+            return c
+
+        one = tune(R.RenderContext(W, H, device=local_rank, frames=1))
         one_aux = torch.as_tensor(one.batch_views()[0], device=dev)
         one_net = lane_net()
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -572,7 +585,7 @@ def main():
         if D > 1:
             plane = [(one, stream, one_net, one_aux)]
             for _ in range(1, D):
-                c2 = R.RenderContext(W, H, device=local_rank, frames=1)
+                c2 = tune(R.RenderContext(W, H, device=local_rank, frames=1))
                 plane.append((c2, torch.cuda.Stream(dev), lane_net(), torch.as_tensor(c2.batch_views()[0], device=dev)))
             done = [torch.cuda.Event() for _ in range(D)]
             npipe = max(nf, 4 * D)

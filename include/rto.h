@@ -335,6 +335,13 @@ int rto_filtering_packed(const rto_guidance_net* net, void* stream, const float*
  * rto_guidance_net_forward_packed_culled is the same idea one stage earlier: a 32x8 tile of the network whose 36x12 input
  * pixels all lie inside the frame and in unmarked tiles is filled with the network's background output (8 fp16 values,
  * measured on the same synthetic frame) instead of being computed.  Maps = rto_guidance_net_forward_packed's bit for bit. */
+/* The two stages on fp32 weight / guidance planes (the reference's tensors; RTO_FILTER_EXACT = the bit-exact route) with the
+ * same tile skipping: the maps must be this network's output for the aux of the launch the marks belong to.  Outputs =
+ * rto_guidance_net_forward_ex / rto_filtering_batch_mode bit for bit.  tile_marks == NULL: those functions. */
+int rto_guidance_net_forward_culled(rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W, float* weight_map,
+                                    float* guidance_map, int flags, const uint32_t* tile_marks, int words_per_frame, float background);
+int rto_filtering_culled(rto_guidance_net* net, void* stream, const float* weight_map, const float* guidance_map, int H, int W, int n,
+                         const float* img_in, float* img_out, int mode, const uint32_t* tile_marks, int words_per_frame, float background);
 int rto_guidance_net_forward_packed_culled(rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W, int flags,
                                            const uint32_t* tile_marks, int words_per_frame, float background);
 int rto_filtering_packed_culled(rto_guidance_net* net, void* stream, const float* img_in, float* img_out, int n, int H, int W,

@@ -105,6 +105,8 @@ SYMBOLS = {
     "rto_guidance_net_forward_ex": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int]),
     "rto_guidance_net_forward_packed": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rto_filtering_packed": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
+    "rto_guidance_net_forward_culled": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int, C.c_float]),
+    "rto_filtering_culled": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int, C.c_float]),
     "rto_guidance_net_forward_packed_culled": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_float]),
     "rto_filtering_packed_culled": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_float]),
     "rto_guidance_net_reserve": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),

@@ -99,6 +99,36 @@ RTO_DEV void filter_level(const float* __restrict__ g, const float4* __restrict_
     }
 }
 
+// Empty-space culling carried into the filter (round 3): the render context's tile marks (FrameBatch::tile_mask: bit t = the
+// 8x8 render tile t may hold a ray that meets density; last word = keep the whole frame) and the filter's output tile for a
+// workgroup whose whole neighbourhood is background.  mask == nullptr: off.
+struct FilterCull {
+    const uint32_t* mask;
+    int mask_words, tiles_x;
+    const float4* fill;  // [tile height][tile width]: the output tile of a workgroup that sees only background
+};
+constexpr int kMapHalo = 2;  // a GuidanceNet map value depends on the 5x5 aux pixels around it (two 3x3 convolutions)
+
+// A workgroup whose staged region (outputs + halo, RW x RH pixels from (rx0, ry0)), grown by the network's receptive field,
+// lies inside the image and inside culled render tiles reads nothing but background pixels and the network's background
+// maps.  Its arithmetic is then the same as that of any other such workgroup, thread for thread: the output tile is the one
+// the same kernel produced once on a synthetic background image (FilterCull::fill).  Workgroup-uniform; every thread calls.
+template <int SW, int SH>
+__device__ __forceinline__ bool sees_only_background(const FilterCull& cull, int sx0, int sy0, int H, int W) {
+    constexpr int RW = SW + 2 * kMapHalo, RH = SH + 2 * kMapHalo;
+    const int rx0 = sx0 - kMapHalo, ry0 = sy0 - kMapHalo;
+    if (!(rx0 >= 0 && ry0 >= 0 && rx0 + RW <= W && ry0 + RH <= H)) return false;  // (the zero padding is not background)
+    const uint32_t* fm = cull.mask + (size_t)blockIdx.z * cull.mask_words;
+    const int tx0 = rx0 >> 3, ty0 = ry0 >> 3, nx = ((rx0 + RW - 1) >> 3) - tx0 + 1, ny = ((ry0 + RH - 1) >> 3) - ty0 + 1;
+    int any = 0;
+    if ((int)threadIdx.x < nx * ny) {
+        const int ty = ty0 + (int)threadIdx.x / nx, tx = tx0 + (int)threadIdx.x % nx;
+        const uint32_t t = (uint32_t)(ty * cull.tiles_x + tx);
+        any = (int)(((fm[t >> 5] >> (t & 31u)) | fm[cull.mask_words - 1]) & 1u);
+    }
+    return !__syncthreads_or(any);
+}
+
 // SAVE: the training forward (Filtering::forward with requires_grad, filtering.cu:596-665) -- the same
 // pass, also storing rgb_filtered [n][L][H][W] (float4), max_map and inv_kernel_sum [n][L][H][W]
 template <int L, bool SAVE>
@@ -107,8 +137,16 @@ __global__ void __launch_bounds__(256, 4) filter_fused(const float* __restrict__
                                                         const float4* __restrict__ img_in,   // [n][H][W]
                                                         float4* __restrict__ img_out,        // [n][H][W]
                                                         int H, int W, float4* __restrict__ rgb_filtered,
-                                                        float* __restrict__ max_map, float* __restrict__ inv_kernel_sum) {
+                                                        float* __restrict__ max_map, float* __restrict__ inv_kernel_sum,
+                                                        const FilterCull cull) {
     constexpr int TW = kFiltW + 2 * L, TH = kFiltH + 2 * L;
+    if (!SAVE && cull.mask) {
+        if (sees_only_background<TW, TH>(cull, (int)blockIdx.x * kFiltW - L, (int)blockIdx.y * kFiltH - L, H, W)) {
+            const int lx = threadIdx.x & (kFiltW - 1), ly = threadIdx.x / kFiltW;
+            img_out[((int64_t)blockIdx.z * H + blockIdx.y * kFiltH + ly) * W + blockIdx.x * kFiltW + lx] = cull.fill[ly * kFiltW + lx];
+            return;
+        }
+    }
     __shared__ float4 s_rgb[TH * TW];
     __shared__ float s_g[L][TH * TW];
 
@@ -271,15 +309,6 @@ __global__ void __launch_bounds__(256, 2) filter_backward(const float4* __restri
 // Guard: E must not underflow inside a window.  GuidanceNet ends in ReLU6, so g lies in [0, 6]; for
 // arbitrary maps a tile whose in-image range of g_l exceeds 80 takes the per-pixel-maximum route below
 // (workgroup-uniform branch, taps read from global memory: slow, correct).
-// Empty-space culling carried into the filter (round 3): the render context's tile marks (FrameBatch::tile_mask: bit t = the
-// 8x8 render tile t may hold a ray that meets density; last word = keep the whole frame) and the filter's output for a pixel
-// whose whole neighbourhood is background.  mask == nullptr: off.
-struct FilterCull {
-    const uint32_t* mask;
-    int mask_words, tiles_x;
-    const float4* fill;  // [kFastH][kFastW]: the output tile of a workgroup that sees only background
-};
-constexpr int kMapHalo = 2;  // a GuidanceNet map value depends on the 5x5 aux pixels around it (two 3x3 convolutions)
 constexpr int kFastW = 32, kFastH = 32, kFastRows = 4;  // outputs per workgroup; rows per thread
 
 template <int S, int SW>
@@ -355,24 +384,7 @@ __global__ void __launch_bounds__(256, 3) filter_fast(const float* __restrict__ 
                                                      int H, int W, const FilterCull cull) {
     constexpr int SW = kFastW + 2 * L, SH = kFastH + 2 * L, NE = SW * SH;
     if (cull.mask) {
-        // A workgroup whose staged region (outputs + halo), grown by the network's receptive field, lies inside the image and
-        // inside culled render tiles reads nothing but background pixels and the network's background maps.  Its arithmetic
-        // is then the same as that of any other such workgroup, thread for thread: the output tile is the one this very
-        // kernel produced once on a synthetic background image (FilterCull::fill).
-        constexpr int RW = SW + 2 * kMapHalo, RH = SH + 2 * kMapHalo;
-        const int rx0 = (int)blockIdx.x * kFastW - L - kMapHalo, ry0 = (int)blockIdx.y * kFastH - L - kMapHalo;
-        bool skip = rx0 >= 0 && ry0 >= 0 && rx0 + RW <= W && ry0 + RH <= H;  // (workgroup-uniform)
-        if (skip) {
-            const uint32_t* fm = cull.mask + (size_t)blockIdx.z * cull.mask_words;
-            const int tx0 = rx0 >> 3, ty0 = ry0 >> 3, nx = ((rx0 + RW - 1) >> 3) - tx0 + 1, ny = ((ry0 + RH - 1) >> 3) - ty0 + 1;
-            int any = 0;
-            if ((int)threadIdx.x < nx * ny) {
-                const int ty = ty0 + (int)threadIdx.x / nx, tx = tx0 + (int)threadIdx.x % nx;
-                const uint32_t t = (uint32_t)(ty * cull.tiles_x + tx);
-                any = (int)(((fm[t >> 5] >> (t & 31u)) | fm[cull.mask_words - 1]) & 1u);
-            }
-            skip = !__syncthreads_or(any);
-        }
+        const bool skip = sees_only_background<SW, SH>(cull, (int)blockIdx.x * kFastW - L, (int)blockIdx.y * kFastH - L, H, W);
         if (skip) {
             const int lx = threadIdx.x & (kFastW - 1), ry = threadIdx.x / kFastW;
             float4* out = img_out + (int64_t)blockIdx.z * H * W;
@@ -541,13 +553,20 @@ hipError_t launch_filter_fast_packed(const void* packed_maps, int H, int W, int 
 
 hipError_t launch_filter_fast(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
                               float* img_out, hipStream_t stream) {
+    return launch_filter_fast_culled(weight, guidance, L, H, W, n, img_in, img_out, nullptr, 0, nullptr, stream);
+}
+
+hipError_t launch_filter_fast_culled(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
+                                     float* img_out, const uint32_t* tile_mask, int mask_words, const float* fill_tile,
+                                     hipStream_t stream) {
+    const FilterCull cull{tile_mask, mask_words, (W + 7) / 8, reinterpret_cast<const float4*>(fill_tile)};
     const dim3 grid((W + kFastW - 1) / kFastW, (H + kFastH - 1) / kFastH, n), block(256);
     const float4* in4 = reinterpret_cast<const float4*>(img_in);
     float4* out4 = reinterpret_cast<float4*>(img_out);
 #define RTO_FFAST(LL)                                                                                              \
     case LL: {                                                                                                     \
         const size_t lds = (size_t)2 * (kFastW + 2 * LL) * (kFastH + 2 * LL) * sizeof(float4);                     \
-        hipLaunchKernelGGL((filter_fast<LL, false>), grid, block, lds, stream, weight, guidance, in4, out4, H, W, FilterCull{nullptr, 0, 0, nullptr}); \
+        hipLaunchKernelGGL((filter_fast<LL, false>), grid, block, lds, stream, weight, guidance, in4, out4, H, W, cull); \
     } break;
     switch (L) {
         RTO_FFAST(1) RTO_FFAST(2) RTO_FFAST(3) RTO_FFAST(4) RTO_FFAST(5) RTO_FFAST(6)
@@ -557,15 +576,32 @@ hipError_t launch_filter_fast(const float* weight, const float* guidance, int L,
     return hipGetLastError();
 }
 
+static hipError_t launch_filter_impl(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
+                                     float* img_out, float* rgb_filtered, float* max_map, float* inv_kernel_sum,
+                                     const FilterCull& cull, hipStream_t stream);
+
 hipError_t launch_filter(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
                          float* img_out, hipStream_t stream) {
-    return launch_filter_train(weight, guidance, L, H, W, n, img_in, img_out, nullptr, nullptr, nullptr, stream);
+    return launch_filter_impl(weight, guidance, L, H, W, n, img_in, img_out, nullptr, nullptr, nullptr, FilterCull{nullptr, 0, 0, nullptr}, stream);
+}
+
+hipError_t launch_filter_culled(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
+                                float* img_out, const uint32_t* tile_mask, int mask_words, const float* fill_tile, hipStream_t stream) {
+    return launch_filter_impl(weight, guidance, L, H, W, n, img_in, img_out, nullptr, nullptr, nullptr,
+                              FilterCull{tile_mask, mask_words, (W + 7) / 8, reinterpret_cast<const float4*>(fill_tile)}, stream);
 }
 
 // rgb_filtered == nullptr: inference forward; else all three save arrays are written too
 hipError_t launch_filter_train(const float* weight, const float* guidance, int L, int H, int W, int n,
                                const float* img_in, float* img_out, float* rgb_filtered, float* max_map,
                                float* inv_kernel_sum, hipStream_t stream) {
+    return launch_filter_impl(weight, guidance, L, H, W, n, img_in, img_out, rgb_filtered, max_map, inv_kernel_sum,
+                              FilterCull{nullptr, 0, 0, nullptr}, stream);
+}
+
+static hipError_t launch_filter_impl(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
+                                     float* img_out, float* rgb_filtered, float* max_map, float* inv_kernel_sum,
+                                     const FilterCull& cull, hipStream_t stream) {
     const dim3 grid((W + kFiltW - 1) / kFiltW, (H + kFiltH - 1) / kFiltH, n), block(256);
     const float4* in4 = reinterpret_cast<const float4*>(img_in);
     float4* out4 = reinterpret_cast<float4*>(img_out);
@@ -574,10 +610,10 @@ hipError_t launch_filter_train(const float* weight, const float* guidance, int L
     case LL:                                                                                                           \
         if (rgb_filtered)                                                                                              \
             hipLaunchKernelGGL((filter_fused<LL, true>), grid, block, 0, stream, weight, guidance, in4, out4, H, W, rf4, \
-                               max_map, inv_kernel_sum);                                                               \
+                               max_map, inv_kernel_sum, cull);                                                         \
         else                                                                                                           \
             hipLaunchKernelGGL((filter_fused<LL, false>), grid, block, 0, stream, weight, guidance, in4, out4, H, W,    \
-                               (float4*)nullptr, (float*)nullptr, (float*)nullptr);                                    \
+                               (float4*)nullptr, (float*)nullptr, (float*)nullptr, cull);                              \
         break;
     switch (L) {  // kernel_apply filtering.cu:338-367 supports SUPPORT 1..6
         RTO_FILT(1) RTO_FILT(2) RTO_FILT(3) RTO_FILT(4) RTO_FILT(5) RTO_FILT(6)

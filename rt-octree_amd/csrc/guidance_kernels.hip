@@ -53,7 +53,8 @@ __device__ __forceinline__ float relu6(float x) { return fminf(fmaxf(x, 0.f), 6.
 struct NetCull {
     const uint32_t* mask;
     int mask_words, tiles_x;
-    uint4 fill;
+    uint4 fill;      // PACK: the 8 fp16 outputs of a pixel whose 5x5 aux neighbourhood is background
+    float planes[8]; // otherwise: the same as 4 softmax weights + 4 guidance values
 };
 
 // C1 = mid channels (multiple of 16, <= 64), L = kernel levels (2L <= 16)
@@ -111,7 +112,7 @@ __global__ void __launch_bounds__(256, 4) guidance_fused(const float* __restrict
     // Tiles of the strip whose input region (tile + halo 2) lies inside the image and in culled render tiles read nothing
     // but background: every output pixel is cull.fill.  Bit ts of `skip_tiles`; workgroup-uniform.
     uint32_t skip_tiles = 0;
-    if (PACK && cull.mask) {
+    if (cull.mask) {
         __shared__ uint32_t s_live;
         if (tid == 0) s_live = 0;
         __syncthreads();
@@ -183,10 +184,20 @@ __global__ void __launch_bounds__(256, 4) guidance_fused(const float* __restrict
     unsigned long long st[8];
     st[0] = __builtin_amdgcn_s_memtime();
 #endif
-    if (PACK && cull.mask) {  // the skipped tiles first (interior tiles: every pixel of them is inside the image)
+    if (cull.mask) {  // the skipped tiles first (interior tiles: every pixel of them is inside the image)
         for (int ts = 0; ts < kStrip && tx_first + ts < tiles_x; ++ts)
-            if ((skip_tiles >> ts) & 1u)
-                reinterpret_cast<uint4*>(weight_out)[(int64_t)(y0 + (tid >> 5)) * W + (tx_first + ts) * kGW + (tid & 31)] = cull.fill;
+            if ((skip_tiles >> ts) & 1u) {
+                const int64_t pix = (int64_t)(y0 + (tid >> 5)) * W + (tx_first + ts) * kGW + (tid & 31);
+                if (PACK) {
+                    reinterpret_cast<uint4*>(weight_out)[pix] = cull.fill;
+                } else {
+#pragma unroll
+                    for (int l = 0; l < L; ++l) {
+                        weight_out[l * HW + pix] = cull.planes[l];
+                        guidance_out[l * HW + pix] = cull.planes[4 + l];
+                    }
+                }
+            }
     }
     int ts_live = next_live(0);
     if (ts_live < kStrip) fetch((tx_first + ts_live) * kGW);
@@ -387,16 +398,17 @@ __global__ void __launch_bounds__(256, 4) guidance_fused(const float* __restrict
 hipError_t launch_guidance_net(const float* aux, const void* w1, const void* w2, const float* b2, int c1,
                                int levels, int n, int H, int W, float* weight_out, float* guidance_out,
                                bool squares_implied, const uint32_t* tile_mask, int mask_words, const uint32_t* fill_k,
-                               hipStream_t stream) {
+                               const float* fill_planes, hipStream_t stream) {
     if (c1 != 32 || levels != 4) return hipErrorInvalidValue;  // the reference configuration (blender.txt:21-25)
     const int tiles_x = (W + kGW - 1) / kGW;
     const dim3 grid((tiles_x + kStrip - 1) / kStrip, (H + kGH - 1) / kGH, n), block(256);
     const bool pack = guidance_out == nullptr;  // weight_out is then the packed fp16 buffer [n][H][W][8]
     NetCull cull;
-    cull.mask = pack && fill_k ? tile_mask : nullptr;
+    cull.mask = (pack ? fill_k != nullptr : fill_planes != nullptr) ? tile_mask : nullptr;
     cull.mask_words = mask_words;
     cull.tiles_x = (W + 7) / 8;
-    cull.fill = cull.mask ? make_uint4(fill_k[0], fill_k[1], fill_k[2], fill_k[3]) : make_uint4(0u, 0u, 0u, 0u);
+    cull.fill = cull.mask && pack ? make_uint4(fill_k[0], fill_k[1], fill_k[2], fill_k[3]) : make_uint4(0u, 0u, 0u, 0u);
+    for (int i = 0; i < 8; ++i) cull.planes[i] = cull.mask && !pack ? fill_planes[i] : 0.f;
 #define RTO_NET(SQ, PK)                                                                                                   \
     hipLaunchKernelGGL((guidance_fused<32, 4, SQ, PK>), grid, block, 0, stream, aux, (const _Float16*)w1, (const _Float16*)w2,     \
                        b2, weight_out, guidance_out, H, W, cull)

@@ -123,6 +123,7 @@ struct rto_ctx {
     uint32_t* qscratch = nullptr;         // chunk_count | chunk_base | qcount
     int mask_words = 0, q_chunks_cap = 0;
     bool cull_on = true;
+    bool frame_via_batch = false;
     int last_n_queues = 0;                // of the last batched launch (rto_ctx_queue_stats)
     int64_t last_slots = 0;
     int marks_n = 0, marks_slot0 = 0;     // frames whose tile marks the last launch left in tile_mask (0: none), their first slot
@@ -1090,6 +1091,8 @@ int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value) {
         c->refill = value;
     } else if (k == "cull") {  // empty-space culling of the batched path (1 = on; same pixels either way)
         c->cull_on = value != 0;
+    } else if (k == "frame_via_batch") {  // rto_launch_renderer as a batch of one (culling + tile marks); same pixels
+        c->frame_via_batch = value != 0;
     } else if (k == "blocks_per_cu") {  // occupancy of the persistent traversal kernel: 0 = what fits, else a cap (1..8)
         if (value < 0 || value > 8) return set_err(RTO_E_INVALID, "blocks_per_cu must be 0..8");
         c->occ.cap = value;
@@ -1220,6 +1223,9 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
     if (kernel == RTO_KERNEL_FAST && !fast_here)
         return set_err(RTO_E_UNSUPPORTED, "fast kernel needs an N == 2 tree of depth <= 24 whose leaf slots fit 31 - ceil(log2 spp) bits "
                                           "(2^28 slots at spp <= 8, 2^26 at spp 32: a hit entry is {valid bit, count - 1, slot})");
+
+    if (kernel == RTO_KERNEL_FAST && ctx->frame_via_batch && ctx->kernel == RTO_KERNEL_AUTO && !ctx->stats_on)
+        return launch_batch_at(tree, cam, nullptr, 1, o, ctx, stream_, ctx->sel);
 
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");

@@ -21,7 +21,8 @@ struct rto_guidance_net {
     int packed_n = 0, packed_h = 0, packed_w = 0;  // what the scratch currently holds
     // rto_filtering_packed_culled: the filter's output tile over pure background of brightness fill_bg (see ensure_fill_tile)
     std::mutex fill_mu;
-    float* fill_tile = nullptr;  // device [32][32][4]
+    float* fill_tile = nullptr;  // device [32][32][4] (factorised filter) then [8][32][4] (exact filter)
+    float fill_planes[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // the background maps as fp32 planes hold them: 4 softmax weights, 4 guidance values
     uint32_t fill_k[4] = {0, 0, 0, 0};  // ... and the network's 8 fp16 outputs for a pixel whose neighbourhood is background
     float fill_bg = 0.f;
     bool fill_valid = false;
@@ -103,7 +104,7 @@ int rto_guidance_net_forward_ex(const rto_guidance_net* net, void* stream, const
         return fail(RTO_E_INVALID, "rto_guidance_net_forward: bad argument");
     DeviceScope scope(net->device);
     const hipError_t e = rto::launch_guidance_net(aux, net->w1, net->w2, net->b2, net->c1, net->levels, n, H, W,
-                                                  weight_map, guidance_map, (flags & RTO_NET_AUX_SQUARES_IMPLIED) != 0, nullptr, 0, nullptr,
+                                                  weight_map, guidance_map, (flags & RTO_NET_AUX_SQUARES_IMPLIED) != 0, nullptr, 0, nullptr, nullptr,
                                                   (hipStream_t)stream);
     if (e != hipSuccess) return fail(RTO_E_HIP, std::string("GuidanceNet launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
@@ -164,7 +165,7 @@ int rto_guidance_net_forward_packed_culled(rto_guidance_net* net, void* stream, 
     }
     const hipError_t e = rto::launch_guidance_net(aux, net->w1, net->w2, net->b2, net->c1, net->levels, n, H, W,
                                                   (float*)net->packed, nullptr, (flags & RTO_NET_AUX_SQUARES_IMPLIED) != 0,
-                                                  tile_marks, words_per_frame, tile_marks ? net->fill_k : nullptr, (hipStream_t)stream);
+                                                  tile_marks, words_per_frame, tile_marks ? net->fill_k : nullptr, nullptr, (hipStream_t)stream);
     if (e != hipSuccess) return fail(RTO_E_HIP, std::string("GuidanceNet launch failed: ") + hipGetErrorString(e));
     net->packed_n = n;
     net->packed_h = H;
@@ -212,25 +213,36 @@ static int ensure_fill_tile(rto_guidance_net* net, float bg, hipStream_t stream)
         }
         img[4 * i + 3] = 1.f;
     }
-    float *d_aux = nullptr, *d_img = nullptr, *d_out = nullptr;
+    float *d_aux = nullptr, *d_img = nullptr, *d_out = nullptr, *d_w = nullptr, *d_g = nullptr;
     void* d_maps = nullptr;
     auto cleanup = [&] {
-        for (void* p : {(void*)d_aux, (void*)d_img, (void*)d_out, d_maps})
+        for (void* p : {(void*)d_aux, (void*)d_img, (void*)d_out, d_maps, (void*)d_w, (void*)d_g})
             if (p) (void)hipFree(p);
     };
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { return (e = r) == hipSuccess; };
-    if (!net->fill_tile && !ok(hipMalloc((void**)&net->fill_tile, (size_t)T * T * 4 * sizeof(float))))
+    constexpr int TE = rto::kFilterExactFillH, YE = (S / 2 / TE) * TE;  // the exact filter's tile: 32 x 8; its row in the frame
+    if (!net->fill_tile && !ok(hipMalloc((void**)&net->fill_tile, (size_t)(T + TE) * T * 4 * sizeof(float))))
         return fail(RTO_E_HIP, std::string("fill tile: ") + hipGetErrorString(e));
     if (!ok(hipMalloc((void**)&d_aux, aux.size() * sizeof(float))) || !ok(hipMalloc((void**)&d_img, img.size() * sizeof(float))) ||
         !ok(hipMalloc((void**)&d_out, img.size() * sizeof(float))) || !ok(hipMalloc(&d_maps, px * 8 * sizeof(uint16_t))) ||
         !ok(hipMemcpyAsync(d_aux, aux.data(), aux.size() * sizeof(float), hipMemcpyHostToDevice, stream)) ||
         !ok(hipMemcpyAsync(d_img, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, stream)) ||
-        !ok(rto::launch_guidance_net(d_aux, net->w1, net->w2, net->b2, net->c1, net->levels, 1, S, S, (float*)d_maps, nullptr, false, nullptr, 0, nullptr, stream)) ||
+        !ok(rto::launch_guidance_net(d_aux, net->w1, net->w2, net->b2, net->c1, net->levels, 1, S, S, (float*)d_maps, nullptr, false, nullptr, 0, nullptr, nullptr, stream)) ||
         !ok(rto::launch_filter_fast_packed(d_maps, S, S, 1, d_img, d_out, nullptr, 0, nullptr, stream)) ||
         !ok(hipMemcpy2DAsync(net->fill_tile, (size_t)T * 4 * sizeof(float), d_out + ((size_t)T * S + T) * 4, (size_t)S * 4 * sizeof(float),
                              (size_t)T * 4 * sizeof(float), T, hipMemcpyDeviceToDevice, stream)) ||
         !ok(hipMemcpyAsync(net->fill_k, (const char*)d_maps + ((size_t)(S / 2) * S + S / 2) * 16, 16, hipMemcpyDeviceToHost, stream)) ||
+        // the same through fp32 planes and the exact filter (rto_guidance_net_forward_culled / rto_filtering_culled)
+        !ok(hipMalloc((void**)&d_w, 4 * px * sizeof(float))) || !ok(hipMalloc((void**)&d_g, 4 * px * sizeof(float))) ||
+        !ok(rto::launch_guidance_net(d_aux, net->w1, net->w2, net->b2, net->c1, net->levels, 1, S, S, d_w, d_g, false, nullptr, 0, nullptr, nullptr, stream)) ||
+        !ok(rto::launch_filter(d_w, d_g, net->levels, S, S, 1, d_img, d_out, stream)) ||
+        !ok(hipMemcpy2DAsync(net->fill_tile + (size_t)T * T * 4, (size_t)T * 4 * sizeof(float), d_out + ((size_t)YE * S + T) * 4,
+                             (size_t)S * 4 * sizeof(float), (size_t)T * 4 * sizeof(float), TE, hipMemcpyDeviceToDevice, stream)) ||
+        !ok(hipMemcpy2DAsync(net->fill_planes, sizeof(float), d_w + (size_t)(S / 2) * S + S / 2, px * sizeof(float), sizeof(float), 4,
+                             hipMemcpyDeviceToHost, stream)) ||
+        !ok(hipMemcpy2DAsync(net->fill_planes + 4, sizeof(float), d_g + (size_t)(S / 2) * S + S / 2, px * sizeof(float), sizeof(float), 4,
+                             hipMemcpyDeviceToHost, stream)) ||
         !ok(hipStreamSynchronize(stream))) {
         cleanup();
         net->fill_valid = false;
@@ -259,6 +271,43 @@ int rto_filtering_packed_culled(rto_guidance_net* net, void* stream, const float
     if (const int rc = ensure_fill_tile(net, background, (hipStream_t)stream)) return rc;
     const hipError_t e = rto::launch_filter_fast_packed(net->packed, net->packed_h, net->packed_w, net->packed_n, img_in, img_out,
                                                         tile_marks, words_per_frame, net->fill_tile, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(RTO_E_HIP, std::string("filter launch failed: ") + hipGetErrorString(e));
+    return RTO_OK;
+}
+
+int rto_guidance_net_forward_culled(rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W, float* weight_map,
+                                    float* guidance_map, int flags, const uint32_t* tile_marks, int words_per_frame, float background) {
+    if (!tile_marks) return rto_guidance_net_forward_ex(net, stream, aux, n, H, W, weight_map, guidance_map, flags);
+    if (!net || !aux || !weight_map || !guidance_map || n < 1 || H < 1 || W < 1)
+        return fail(RTO_E_INVALID, "rto_guidance_net_forward_culled: bad argument");
+    if (const int rc = check_marks("rto_guidance_net_forward_culled", net, tile_marks, words_per_frame, H, W)) return rc;
+    DeviceScope scope(net->device);
+    if (const int rc = ensure_fill_tile(net, background, (hipStream_t)stream)) return rc;
+    const hipError_t e = rto::launch_guidance_net(aux, net->w1, net->w2, net->b2, net->c1, net->levels, n, H, W, weight_map, guidance_map,
+                                                  (flags & RTO_NET_AUX_SQUARES_IMPLIED) != 0, tile_marks, words_per_frame, nullptr,
+                                                  net->fill_planes, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(RTO_E_HIP, std::string("GuidanceNet launch failed: ") + hipGetErrorString(e));
+    return RTO_OK;
+}
+
+int rto_filtering_culled(rto_guidance_net* net, void* stream, const float* weight_map, const float* guidance_map, int H, int W, int n,
+                         const float* img_in, float* img_out, int mode, const uint32_t* tile_marks, int words_per_frame, float background) {
+    if (!net) return fail(RTO_E_INVALID, "rto_filtering_culled: null network handle");
+    if (!tile_marks) return rto_filtering_batch_mode(stream, weight_map, guidance_map, net->levels, H, W, n, img_in, img_out, mode);
+    if (!weight_map || !guidance_map || !img_in || !img_out || img_in == img_out || H < 1 || W < 1 || n < 1)
+        return fail(RTO_E_INVALID, "rto_filtering_culled: bad argument");
+    if (mode != RTO_FILTER_EXACT && mode != RTO_FILTER_FACTORISED) return fail(RTO_E_INVALID, "rto_filtering_culled: unknown mode");
+    if (const int rc = check_marks("rto_filtering_culled", net, tile_marks, words_per_frame, H, W)) return rc;
+    if (pointer_device(img_out) != net->device || pointer_device(img_in) != net->device)
+        return fail(RTO_E_INVALID, "rto_filtering_culled: the images are not memory of the network's device");
+    DeviceScope scope(net->device);
+    if (const int rc = ensure_fill_tile(net, background, (hipStream_t)stream)) return rc;
+    constexpr size_t kExactTile = (size_t)rto::kFilterFillSide * rto::kFilterFillSide * 4;
+    const hipError_t e = mode == RTO_FILTER_EXACT
+                             ? rto::launch_filter_culled(weight_map, guidance_map, net->levels, H, W, n, img_in, img_out, tile_marks,
+                                                         words_per_frame, net->fill_tile + kExactTile, (hipStream_t)stream)
+                             : rto::launch_filter_fast_culled(weight_map, guidance_map, net->levels, H, W, n, img_in, img_out, tile_marks,
+                                                              words_per_frame, net->fill_tile, (hipStream_t)stream);
     if (e != hipSuccess) return fail(RTO_E_HIP, std::string("filter launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
 }

@@ -61,10 +61,19 @@ hipError_t launch_filter(const float* weight, const float* guidance, int L, int 
 hipError_t launch_filter_fast(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
                               float* img_out, hipStream_t stream);
 
+constexpr int kFilterFillSide = 32;
+// launch_filter / launch_filter_fast with the tile skipping described below (launch_filter_fast_packed); the fill tiles are
+// [kFilterExactFillH][kFilterFillSide][4] and [kFilterFillSide][kFilterFillSide][4] floats
+constexpr int kFilterExactFillH = 8;
+hipError_t launch_filter_culled(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
+                                float* img_out, const uint32_t* tile_mask, int mask_words, const float* fill_tile, hipStream_t stream);
+hipError_t launch_filter_fast_culled(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
+                                     float* img_out, const uint32_t* tile_mask, int mask_words, const float* fill_tile,
+                                     hipStream_t stream);
+
 // ... on the GuidanceNet kernel's packed fp16 maps [n][H][W][8] (4 logits + 4 guidance values), L = 4.
 // tile_mask != nullptr: the render context's tile marks of these n frames (FrameBatch::tile_mask); a workgroup whose inputs
 // all lie in unmarked (culled = background) tiles copies fill_tile ([32][32][4] floats) instead of filtering
-constexpr int kFilterFillSide = 32;
 hipError_t launch_filter_fast_packed(const void* packed_maps, int H, int W, int n, const float* img_in, float* img_out,
                                      const uint32_t* tile_mask, int mask_words, const float* fill_tile, hipStream_t stream);
 
@@ -82,6 +91,6 @@ hipError_t launch_filter_backward(const float* grad_out, const float* img_in, co
 hipError_t launch_guidance_net(const float* aux, const void* w1, const void* w2, const float* b2, int c1,
                                int levels, int n, int H, int W, float* weight_out, float* guidance_out,
                                bool squares_implied, const uint32_t* tile_mask, int mask_words, const uint32_t* fill_k,
-                               hipStream_t stream);
+                               const float* fill_planes, hipStream_t stream);
 
 }  // namespace rto

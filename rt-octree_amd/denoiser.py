@@ -190,9 +190,10 @@ class FusedGuidanceNet:
         self._h = h
         self._out = {}
 
-    def __call__(self, aux, stream=None, squares_implied=False):
+    def __call__(self, aux, stream=None, squares_implied=False, cull=None):
         """squares_implied: aux planes 4..7 are the fp32 squares of planes 0..3 (the renderer's aux buffer): the
-        kernel reads half the bytes, results are bit-identical"""
+        kernel reads half the bytes, results are bit-identical.  cull = RenderContext.tile_marks() of the launch that
+        rendered aux: tiles whose inputs are all background get the background maps without being computed (same bits)"""
         from ._lib import check, lib
         n, c, H, W = aux.shape
         assert c == 8 and aux.dtype == torch.float32 and aux.is_contiguous()
@@ -202,9 +203,28 @@ class FusedGuidanceNet:
                               torch.empty((n, self.levels, H, W), device=self.device))
         wm, gm = self._out[key]
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
-        check(lib().rto_guidance_net_forward_ex(self._h, V._stream_ptr(s), aux.data_ptr(), n, H, W, wm.data_ptr(), gm.data_ptr(),
-                                                1 if squares_implied else 0))
+        marks, words, bg = (None, 0, 0.0)
+        if cull is not None:
+            marks, words, _slot0, frames, bg = cull
+            if frames < n:
+                raise ValueError("GuidanceNet: %d frames but tile marks of %d" % (n, frames))
+        check(lib().rto_guidance_net_forward_culled(self._h, V._stream_ptr(s), aux.data_ptr(), n, H, W, wm.data_ptr(), gm.data_ptr(),
+                                                    1 if squares_implied else 0, marks, int(words), float(bg)))
         return wm, gm
+
+    def filter_planes(self, weight_map, guidance_map, img_in, img_out, mode=V.FILTER_EXACT, stream=None, cull=None):
+        """volrend.filtering on this network's fp32 maps [n, L, H, W], skipping the filter tiles that see only culled render
+        tiles (cull = RenderContext.tile_marks(); rto_filtering_culled; same bits).  cull=None: volrend.filtering"""
+        from ._lib import check, lib
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        n, L, H, W = (int(x) for x in guidance_map.shape)
+        marks, words, bg = (None, 0, 0.0)
+        if cull is not None:
+            marks, words, _slot0, frames, bg = cull
+            if frames < n:
+                raise ValueError("filter_planes: %d images but tile marks of %d frames" % (n, frames))
+        check(lib().rto_filtering_culled(self._h, V._stream_ptr(s), V._dev_ptr(weight_map), V._dev_ptr(guidance_map), H, W, n,
+                                         V._dev_ptr(img_in), V._dev_ptr(img_out), int(mode), marks, int(words), float(bg)))
 
     def reserve(self, n, H, W):
         """size the packed-map scratch up front (growing it later synchronises the device once)"""

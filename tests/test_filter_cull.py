@@ -73,6 +73,23 @@ def test_culled_filter_is_bit_identical(scene, W, H, bg, radius):
     torch.cuda.synchronize()
     assert_bits_equal(images(ctx, n).cpu().numpy(), plain.cpu().numpy(), "both stages culled, %dx%d bg %g" % (W, H, bg))
     net.forward_packed(aux[:n], squares_implied=True)
+    # the fp32-plane routes (the reference's tensors): maps with tile skipping == maps without; exact and factorised filters
+    wm, gm = (t.clone() for t in net(aux[:n], squares_implied=True))
+    wm_c, gm_c = net(aux[:n], squares_implied=True, cull=marks)
+    torch.cuda.synchronize()
+    assert_bits_equal(wm_c.cpu().numpy(), wm.cpu().numpy(), "weight planes, culled network")
+    assert_bits_equal(gm_c.cpu().numpy(), gm.cpu().numpy(), "guidance planes, culled network")
+    R.filtering(None, wm, gm, ctx.noisy_ptr, ctx.image_ptr, mode=R.FILTER_EXACT)
+    torch.cuda.synchronize()
+    plain_exact = images(ctx, n)
+    torch.as_tensor(ctx.batch_views()[2], device="cuda:0").fill_(-7.0)
+    net.filter_planes(wm, gm, ctx.noisy_ptr, ctx.image_ptr, mode=R.FILTER_EXACT, cull=marks)
+    torch.cuda.synchronize()
+    assert_bits_equal(images(ctx, n).cpu().numpy(), plain_exact.cpu().numpy(), "exact filter, culled")
+    torch.as_tensor(ctx.batch_views()[2], device="cuda:0").fill_(-7.0)
+    net.filter_planes(wm, gm, ctx.noisy_ptr, ctx.image_ptr, mode=R.FILTER_FAST, cull=marks)
+    torch.cuda.synchronize()
+    assert_bits_equal(images(ctx, n).cpu().numpy(), plain.cpu().numpy(), "factorised filter on fp32 planes, culled")
     if W == 800:
         # the frames do hold workgroups that were copied (else this test proves nothing): workgroup (1, 1) of frame 0 sees only
         # sky -- a poisoned input pixel inside it changes what the plain filter writes there, and not what the culled one does
@@ -85,6 +102,9 @@ def test_culled_filter_is_bit_identical(scene, W, H, bg, radius):
         net.filter_packed(ctx.noisy_ptr, ctx.image_ptr, shape=(n, H, W))
         torch.cuda.synchronize()
         assert not torch.equal(images(ctx, n)[0, 40:56, 40:56], plain[0, 40:56, 40:56])
+        net.filter_planes(wm, gm, ctx.noisy_ptr, ctx.image_ptr, mode=R.FILTER_EXACT, cull=marks)
+        torch.cuda.synchronize()
+        assert torch.equal(images(ctx, n), plain_exact)  # (the exact filter skipped that workgroup as well)
         # the same for the network: a poisoned aux value inside a skipped network tile does not reach the maps
         noisy[0, 48, 48, :3] = bg
         aux[0, 0, 48, 48] = 0.5

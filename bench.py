@@ -679,8 +679,10 @@ def main():
                             "lanes_per_valu_inst": pj.get("lanes_per_valu_inst"),
                             "note": "frac = SQ_INSTS_VALU / (SIMDs x kernel clocks) over the rate the traversal's instruction stream sustains "
                                     "with no memory in the way: the larger of the asm probe's figure for its opcode mix at 8 waves per "
-                                    "SIMD (0.290, profiles/r3_valu_calibration.json, counters on the probe itself) and the traversal "
-                                    "loop's own with both gathers stubbed (0.321, profiles/r3_j_stubbed_loads_pmc.json). "
+                                    "SIMD (%.3f, profiles/r3_valu_calibration.json, counters on the probe itself) and the traversal "
+                                    "loop's own with both gathers stubbed (%.3f, %s). " % (
+                                        vc.get("traversal_mix_insts_per_clk_per_simd") or 0.0, vc.get("stubbed_loop_insts_per_clk_per_simd") or 0.0,
+                                        vc.get("stubbed_loop_source", "no stubbed-loop pass committed")) +
                                     "A SIMD issues ~0.45 instructions per clock in all: plain add / mul / fma / logic opcodes at "
                                     "0.41-0.45, every other VALU opcode (3-operand, shifts left, min / max, conversions, compares, "
                                     "packed, SGPR operand) at 0.235-0.245, SALU instructions out of the same budget"}

@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "rto_launch.h"
+#include "rto_denoise_launch.h"
 
 #pragma clang fp contract(off)
 

@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "rto_launch.h"
+#include "rto_denoise_launch.h"
 
 namespace rto {
 

@@ -19,6 +19,7 @@
 #include "host/n3tree_host.h"
 #include "rto.h"
 #include "rto_launch.h"
+#include "rto_denoise_launch.h"
 
 namespace {
 

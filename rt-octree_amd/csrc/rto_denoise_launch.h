@@ -1,0 +1,53 @@
+// rto_denoise_launch.h -- host-callable launchers of the denoise stage's gfx950 kernels (filter_kernels.hip,
+// guidance_kernels.hip).  Apart from rto_launch.h so that the render kernels' code id (bench.py kernel_code_id) changes with
+// the render kernels only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace rto {
+
+// denoiser/extension/filtering.cu:108-228,440-470: L levels, support = level + 1
+// n images per launch: weight/guidance [n][L][H][W], img_in/img_out [n][H][W][4]
+hipError_t launch_filter(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
+                         float* img_out, hipStream_t stream);
+
+// the same filter with the exponentials factorised out of the taps (filter_kernels.hip filter_fast): the
+// tolerance path, ~1e-6 relative to launch_filter
+hipError_t launch_filter_fast(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
+                              float* img_out, hipStream_t stream);
+
+constexpr int kFilterFillSide = 32;
+// launch_filter / launch_filter_fast with the tile skipping described below (launch_filter_fast_packed); the fill tiles are
+// [kFilterExactFillH][kFilterFillSide][4] and [kFilterFillSide][kFilterFillSide][4] floats
+constexpr int kFilterExactFillH = 8;
+hipError_t launch_filter_culled(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
+                                float* img_out, const uint32_t* tile_mask, int mask_words, const float* fill_tile, hipStream_t stream);
+hipError_t launch_filter_fast_culled(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
+                                     float* img_out, const uint32_t* tile_mask, int mask_words, const float* fill_tile,
+                                     hipStream_t stream);
+
+// ... on the GuidanceNet kernel's packed fp16 maps [n][H][W][8] (4 logits + 4 guidance values), L = 4.
+// tile_mask != nullptr: the render context's tile marks of these n frames (FrameBatch::tile_mask); a workgroup whose inputs
+// all lie in unmarked (culled = background) tiles copies fill_tile ([32][32][4] floats) instead of filtering
+hipError_t launch_filter_fast_packed(const void* packed_maps, int H, int W, int n, const float* img_in, float* img_out,
+                                     const uint32_t* tile_mask, int mask_words, const float* fill_tile, hipStream_t stream);
+
+// training side: forward that also saves rgb_filtered [n][L][H][W][4], max_map / inv_kernel_sum
+// [n][L][H][W] (filtering.cu:205-216), and the backward (filtering.cu:230-301) in gather form
+hipError_t launch_filter_train(const float* weight, const float* guidance, int L, int H, int W, int n,
+                               const float* img_in, float* img_out, float* rgb_filtered, float* max_map,
+                               float* inv_kernel_sum, hipStream_t stream);
+hipError_t launch_filter_backward(const float* grad_out, const float* img_in, const float* weight, const float* guidance,
+                                  const float* rgb_filtered, const float* max_map, const float* inv_kernel_sum, int L,
+                                  int H, int W, int n, float* grad_weight, float* grad_guidance, hipStream_t stream);
+
+// fused compact GuidanceNet (guidance_kernels.hip): w1 fp16 [c1][96], w2 fp16 [16][9*c1], b2 [16];
+// guidance_out == nullptr: weight_out receives the packed fp16 maps [n][H][W][8] instead
+hipError_t launch_guidance_net(const float* aux, const void* w1, const void* w2, const float* b2, int c1,
+                               int levels, int n, int H, int W, float* weight_out, float* guidance_out,
+                               bool squares_implied, const uint32_t* tile_mask, int mask_words, const uint32_t* fill_k,
+                               const float* fill_planes, hipStream_t stream);
+
+}  // namespace rto

@@ -8,6 +8,7 @@
 
 #include "rto.h"
 #include "rto_launch.h"
+#include "rto_denoise_launch.h"
 
 extern "C" const char* rto_last_error(void);
 

@@ -52,14 +52,17 @@ def main():
             "source": "profiles/r3_valu_calibration.json: asm probe, 8 waves per SIMD, SQ_INSTS_VALU / (SQ_BUSY_CYCLES / 32) / 1024 SIMDs"}
         # the traversal loop itself with both gathers stubbed (-DRTO_STUB_LOADS): what ITS instruction stream sustains with no
         # memory in the way; the ceiling quoted is the larger of the two
-        stub = os.path.join(ROOT, "profiles", "r3_j_stubbed_loads_pmc.json")
+        import glob
+        stubs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r3_*_stubbed_loads_pmc.json")))  # (the latest bundle's)
+        stub = stubs[-1] if stubs else ""
         vc = doc["valu_ceiling"]
         vc["ceiling_insts_per_clk_per_simd"] = vc["traversal_mix_insts_per_clk_per_simd"]
-        if os.path.exists(stub):
+        if stub and os.path.exists(stub):
             k = json.load(open(stub))["kernels"].get("render_persist", {})
             if "SQ_INSTS_VALU" in k and ("SQ_BUSY_CYCLES" in k or "GRBM_GUI_ACTIVE" in k):
                 clk = k["SQ_BUSY_CYCLES"]["mean"] / 32.0 if "SQ_BUSY_CYCLES" in k else k["GRBM_GUI_ACTIVE"]["mean"] / 8.0
                 vc["stubbed_loop_insts_per_clk_per_simd"] = k["SQ_INSTS_VALU"]["mean"] / 1024.0 / clk
+                vc["stubbed_loop_source"] = os.path.relpath(stub, ROOT)
                 vc["ceiling_insts_per_clk_per_simd"] = max(vc["ceiling_insts_per_clk_per_simd"], vc["stubbed_loop_insts_per_clk_per_simd"])
     code_id = bench.kernel_code_id()
     for spec in sys.argv[3:]:

@@ -955,8 +955,10 @@ __global__ void __launch_bounds__(256) sample_kernel(const FrameBatch fb, const 
     const uint32_t idx = y * (uint32_t)fb.width + x;
     const FrameDesc& fd = fb.f[blockIdx.y];
     // a pixel of a culled tile: an empty hit list, no draws (its RNG stream is its own: nobody observes the skipped ones)
-    if (fb.tile_mask && !tile_marked(fb, (int)blockIdx.y, tile)) {
+    if (fb.tile_mask && !tile_marked(fb, (int)blockIdx.y, tile)) {  // (shade_kernel reads the marks, not a list)
+#ifdef RTO_SHADE_NO_MARKS
         fd.hits[hit_index<SPP>(idx, 0u, SIZE)] = 0u;
+#endif
         return;
     }
     Pcg32 rng;
@@ -1478,11 +1480,32 @@ __global__ void __launch_bounds__(256, RTO_SHADE_WPS) shade_kernel(const TreeDev
     uint32_t h[P][SPP];
     uint32_t n[P];
     uint32_t mine = 0;
+    // A pixel of a culled tile has no hit list (nobody wrote one: sample_kernel, render_persist): it is read off the tile
+    // marks, a few hundred cached words per frame, instead of 4 * SPP bytes per pixel of stale memory -- two thirds of the
+    // pixels of the bench scene.  (x, y) of the wave's first pixel by one wave-uniform division, the lanes' by carries.
+#ifdef RTO_SHADE_NO_MARKS  // (A/B: the culled tiles' pixels carry an explicit empty list instead)
+    const uint32_t* fmask = nullptr;
+#else
+    const uint32_t* fmask = fb.tile_mask ? fb.tile_mask + (size_t)frame * fb.mask_words : nullptr;
+#endif
+    const uint32_t keep_all = fmask ? fmask[fb.mask_words - 1] & 1u : 1u;
+    const int tiles_x = (W + 7) >> 3;
+    const int wy0 = (int)(wave_px0 / W), wx0 = (int)(wave_px0 - (int64_t)wy0 * W);
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const int64_t idx = wave_px0 + p * 64 + lane;
         n[p] = 0;
-        if (idx < SIZE) {
+        bool live = idx < SIZE;
+        if (live && !keep_all) {
+            int x = wx0 + p * 64 + lane, y = wy0;
+            while (x >= W) {
+                x -= W;
+                ++y;
+            }
+            const uint32_t t = (uint32_t)((y >> 3) * tiles_x + (x >> 3));
+            live = ((fmask[t >> 5] >> (t & 31u)) & 1u) != 0u;
+        }
+        if (live) {
             bool open = true;
             if (kHitsLayout == 2) {  // the first entry from its dense plane, the run behind it
 #ifdef RTO_SHADE_LAZY_LIST

@@ -1,10 +1,11 @@
 #!/bin/bash
 ROOT=$PWD; OUT=$ROOT/gpurun_out; mkdir -p $OUT
-timeout 900 python -m pytest tests/test_culling.py tests/test_render_parity.py tests/test_baseline_workload.py tests/test_filter_cull.py -x -q -m gpu 2>&1 | grep -v "^INFO" | tail -n 3
-bash tools/ab_bench_variants.sh 3 2>&1 | tee $OUT/ab_shade_marks.txt
-for f in rt-octree_amd/lib_ab/librto_0.so rt-octree_amd/lib_ab/librto_1.so; do
-RTO_LIB=$PWD/$f timeout 300 python3 bench.py --c4 --steps 4 --warmup 1 --cpu-frames 0 --psnr-frames 0 --ref-loop-frames 0 --no-exact-pass --spot-pixels 0 2>/dev/null | python3 -c "
+B="--steps 8 --warmup 2 --cpu-frames 0 --psnr-frames 0 --ref-loop-frames 0 --no-exact-pass --spot-pixels 0"
+for i in 1 2; do
+  for st in 1 2 3; do
+    timeout 300 python bench.py $B --streams $st 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); r=d['roofline']
-print('c4 $f value %.0f persist %.3f shade %.3f thr %.3f'%(d['value'], r['avg_launch_ms'], r['shade_kernel_avg_launch_ms'], r['thresholds_kernel_avg_launch_ms']))" | tee -a $OUT/ab_shade_marks.txt
+print('streams $st value %.0f ms/step %.3f persist %.3f shade %.3f'%(d['value'], d['ms_per_step'], r['avg_launch_ms'], r['shade_kernel_avg_launch_ms']))" | tee -a $OUT/streams_ab.txt
+  done
 done

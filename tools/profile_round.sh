@@ -13,9 +13,7 @@ for C in $CFGS; do
     c4) A="--c4" ; STEPS=2 ;;
   esac
   B="bench.py $A --cpu-frames 0 --psnr-frames 0 --ref-loop-frames 0 --spot-pixels 0 --no-exact-pass --steps $STEPS --warmup 1"
-  # the plain bench line of the configuration (C2: the full default line with CPU baseline and PSNR)
-  if [ $C = c2 ]; then python3 bench.py > $O/${TAG}_bench_c2.json 2> $O/${TAG}_bench_c2.err
-  else python3 bench.py $A --cpu-frames 0 --psnr-frames 16 > $O/${TAG}_bench_$C.json 2> $O/${TAG}_bench_$C.err; fi
+  # (the plain bench lines: tools/bench_lines.sh, once the counters of this run are installed)
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_${C}_trace -- python3 $B > $O/${TAG}_${C}_bench_under_rocprof.json 2>/dev/null
   cp $(find $O/${TAG}_${C}_trace -name '*kernel_stats.csv' | head -1) $O/${TAG}_${C}_kernel_stats.csv
   i=0

@@ -62,6 +62,15 @@ public:
 private:
     const std::string& s_;
     size_t p_ = 0;
+    int depth_ = 0;  // of containers being parsed: bounded, the parser recurses per level
+    static constexpr int kMaxDepth = 256;
+    struct Nest {
+        Parser& p;
+        explicit Nest(Parser& q) : p(q) {
+            if (++p.depth_ > kMaxDepth) p.fail("nested too deeply");
+        }
+        ~Nest() { --p.depth_; }
+    };
 
     [[noreturn]] void fail(const char* what) const {
         throw std::runtime_error(std::string("json: ") + what + " at offset " + std::to_string(p_));
@@ -84,6 +93,7 @@ private:
         auto v = std::make_shared<Value>();
         const char c = s_[p_];
         if (c == '{') {
+            const Nest nest(*this);
             v->kind = Value::Object;
             ++p_;
             ws();
@@ -111,6 +121,7 @@ private:
                 fail("',' or '}' expected");
             }
         } else if (c == '[') {
+            const Nest nest(*this);
             v->kind = Value::Array;
             ++p_;
             ws();

@@ -54,6 +54,7 @@ std::string DataFormat::to_string() const {  // n3tree.cpp:80-101
 namespace {
 
 double scalar_as_double(const NpyArray& a, size_t i) {
+    if (i >= a.num_vals()) throw std::runtime_error("tree.npz: array of " + std::to_string(a.num_vals()) + " values read at index " + std::to_string(i));
     if (a.kind == 'f' && a.word_size == 4) return a.as<float>()[i];
     if (a.kind == 'f' && a.word_size == 8) return a.as<double>()[i];
     if (a.kind == 'i' && a.word_size == 8) return (double)a.as<int64_t>()[i];

@@ -7,6 +7,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <fstream>
@@ -89,6 +90,7 @@ NpyArray parse_npy(const uint8_t* b, size_t n, std::shared_ptr<std::vector<uint8
         }
     }
     a.data = b + hoff + hlen;
+    if (a.word_size > 256) fail("bad descr '" + descr + "'");
     {  // element count and byte size with overflow checks (a crafted shape must not wrap around)
         size_t vals = 1;
         for (size_t d : a.shape) {
@@ -100,6 +102,16 @@ NpyArray parse_npy(const uint8_t* b, size_t n, std::shared_ptr<std::vector<uint8
     }
     if (a.nbytes > n - (hoff + hlen)) fail("truncated .npy payload");
     a.owned = std::move(owner);
+    // A stored zip member starts wherever its local header ends (np.savez aligns the payload inside the .npy only), so a
+    // mapped payload is usually NOT aligned for its element type.  Typed reads of such a pointer are undefined behaviour --
+    // and a real fault once a compiler vectorises the reading loop with aligned loads after peeling "up to alignment".
+    // Such a member is copied into aligned storage (what the reference's cnpy does for every array); aligned ones stay mapped.
+    const size_t align = a.kind == 'U' ? 4 : (a.word_size >= 8 ? 8 : a.word_size >= 4 ? 4 : a.word_size >= 2 ? 2 : 1);
+    if (a.nbytes && reinterpret_cast<uintptr_t>(a.data) % align != 0) {
+        auto copy = std::make_shared<std::vector<uint8_t>>(a.data, a.data + a.nbytes);
+        a.data = copy->data();
+        a.owned = std::move(copy);
+    }
     return a;
 }
 
@@ -141,38 +153,48 @@ void NpzFile::open(const std::string& path) {
         // ZIP64: locator sits right before the EOCD
         if (eocd < 20 || rd32(map_ + eocd - 20) != 0x07064b50u) fail("zip64 locator missing");
         const uint64_t e64 = rd64(map_ + eocd - 20 + 8);
-        if (e64 + 56 > size_ || rd32(map_ + e64) != 0x06064b50u) fail("zip64 EOCD missing");
+        if (e64 > size_ || size_ - e64 < 56 || rd32(map_ + e64) != 0x06064b50u) fail("zip64 EOCD missing");
         n_entries = rd64(map_ + e64 + 32);
         cd_size = rd64(map_ + e64 + 40);
         cd_off = rd64(map_ + e64 + 48);
     }
-    if (cd_off + cd_size > size_) fail("central directory out of range");
+    if (cd_size > size_ || cd_off > size_ - cd_size) fail("central directory out of range");
 
     size_t p = (size_t)cd_off;
     for (uint64_t i = 0; i < n_entries; ++i) {
-        if (p + 46 > size_ || rd32(map_ + p) != 0x02014b50u) fail("bad central directory entry");
+        if (p > size_ || size_ - p < 46 || rd32(map_ + p) != 0x02014b50u) fail("bad central directory entry");
         const uint16_t method = rd16(map_ + p + 10);
         uint64_t csize = rd32(map_ + p + 20), usize = rd32(map_ + p + 24);
         const uint16_t nlen = rd16(map_ + p + 28), xlen = rd16(map_ + p + 30), clen = rd16(map_ + p + 32);
         uint64_t lho = rd32(map_ + p + 42);
+        if (size_ - p - 46 < (size_t)nlen + xlen + clen) fail("central directory entry runs past the end of the file");
         std::string name(reinterpret_cast<const char*>(map_ + p + 46), nlen);
         // ZIP64 extended information (header id 1): fields present only for saturated values, in order
         const uint8_t* x = map_ + p + 46 + nlen;
         for (size_t q = 0; q + 4 <= xlen;) {
             const uint16_t id = rd16(x + q), sz = rd16(x + q + 2);
+            if (q + 4 + sz > xlen) fail("bad extra field of '" + name + "'");
             if (id == 1) {
                 size_t r = q + 4;
-                if (usize == 0xffffffffu) { usize = rd64(x + r); r += 8; }
-                if (csize == 0xffffffffu) { csize = rd64(x + r); r += 8; }
-                if (lho == 0xffffffffu) { lho = rd64(x + r); r += 8; }
+                const size_t end = q + 4 + sz;
+                auto take = [&](uint64_t& v) {
+                    if (r + 8 > end) fail("bad zip64 extra field of '" + name + "'");
+                    v = rd64(x + r);
+                    r += 8;
+                };
+                if (usize == 0xffffffffu) take(usize);
+                if (csize == 0xffffffffu) take(csize);
+                if (lho == 0xffffffffu) take(lho);
             }
             q += 4 + sz;
         }
         p += 46 + (size_t)nlen + xlen + clen;
 
-        if (lho + 30 > size_ || rd32(map_ + lho) != 0x04034b50u) fail("bad local header for '" + name + "'");
+        if (lho > size_ || size_ - lho < 30 || rd32(map_ + lho) != 0x04034b50u) fail("bad local header for '" + name + "'");
         const size_t doff = (size_t)lho + 30 + rd16(map_ + lho + 26) + rd16(map_ + lho + 28);
-        if (doff + csize > size_) fail("member '" + name + "' out of range");
+        if (doff > size_ || csize > size_ - doff) fail("member '" + name + "' out of range");
+        // (deflate expands at most ~1032 : 1: a larger claim is a corrupt size field, not a reason to allocate it)
+        if (method == 8 && usize / 1100 > csize + 1) fail("member '" + name + "' claims an impossible inflated size");
 
         // numpy appends ".npy" to every key
         if (name.size() > 4 && name.compare(name.size() - 4, 4, ".npy") == 0) name.resize(name.size() - 4);

@@ -68,8 +68,11 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(LIB_PATH)
+        # RTO_ORC_LIB: another build of the same source (tools/sanitize/run.sh loads one instrumented with ASan + UBSan)
+        alt = os.environ.get("RTO_ORC_LIB")
+        if not alt:
+            build()
+        L = C.CDLL(alt or LIB_PATH)
         L.orc_pcg32_next_uint.restype = C.c_uint32
         L.orc_pcg32_next_float.restype = C.c_float
         L.orc_pcg32_advance.argtypes = [C.POINTER(Pcg32), C.c_int64]

@@ -178,6 +178,7 @@ int rto_ctx_create(int width, int height, int device, rto_ctx** out);
 int rto_ctx_create_batch(int width, int height, int frames, int device, rto_ctx** out);
 int rto_ctx_frames(const rto_ctx* c);
 int rto_ctx_select_frame(rto_ctx* c, int frame);
+int rto_ctx_selected_frame(const rto_ctx* c);
 void rto_ctx_free(rto_ctx* c);
 int rto_ctx_width(const rto_ctx* c);
 int rto_ctx_height(const rto_ctx* c);
@@ -346,6 +347,12 @@ int rto_guidance_net_forward_packed_culled(rto_guidance_net* net, void* stream, 
                                            const uint32_t* tile_marks, int words_per_frame, float background);
 int rto_filtering_packed_culled(rto_guidance_net* net, void* stream, const float* img_in, float* img_out, int n, int H, int W,
                                 const uint32_t* tile_marks, int words_per_frame, float background);
+/* Denoiser::denoise (denoiser.cpp:31-61) in one call, for the n frames of `ctx` from its selected slot on: the network on the
+ * context's aux buffer, the filter from its noisy buffer into its image buffer.  mode RTO_FILTER_FACTORISED: packed fp16
+ * maps + factorised filter (the throughput route); RTO_FILTER_EXACT: fp32 planes (a scratch the handle owns, 32 B per
+ * pixel) + the bit-exact filter.  When the frames are those of the last rto_launch_renderer_batch on `ctx` its tile marks
+ * are used (the *_culled calls above); after a single-frame launch the plain kernels run.  Same results either way. */
+int rto_denoise(rto_guidance_net* net, rto_ctx* ctx, int n, int mode, void* stream);
 void rto_guidance_net_free(rto_guidance_net* net);
 
 /* ---- profiling aid ---- */

@@ -109,6 +109,8 @@ SYMBOLS = {
     "rto_filtering_culled": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int, C.c_float]),
     "rto_guidance_net_forward_packed_culled": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_float]),
     "rto_filtering_packed_culled": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_float]),
+    "rto_denoise": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "rto_ctx_selected_frame": (C.c_int, [_P]),
     "rto_guidance_net_reserve": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "rto_guidance_net_free": (None, [_P]),
     "rto_probe_gather": (C.c_int, [C.c_uint64, C.c_int]),

@@ -1034,6 +1034,7 @@ float* rto_ctx_aux(rto_ctx* c) { return c ? c->aux + (size_t)c->sel * RTO_AUX_CH
 float* rto_ctx_noisy(rto_ctx* c) { return c ? c->noisy + (size_t)c->sel * 4 * frame_px(c) : nullptr; }
 float* rto_ctx_image(rto_ctx* c) { return c ? c->image + (size_t)c->sel * 4 * frame_px(c) : nullptr; }
 int rto_ctx_frames(const rto_ctx* c) { return c ? c->frames : 0; }
+int rto_ctx_selected_frame(const rto_ctx* c) { return c ? c->sel : 0; }
 int rto_ctx_select_frame(rto_ctx* c, int frame) {
     if (!c || frame < 0 || frame >= c->frames) return set_err(RTO_E_INVALID, "rto_ctx_select_frame: frame out of range");
     c->sel = frame;

@@ -27,6 +27,8 @@ struct rto_guidance_net {
     uint32_t fill_k[4] = {0, 0, 0, 0};  // ... and the network's 8 fp16 outputs for a pixel whose neighbourhood is background
     float fill_bg = 0.f;
     bool fill_valid = false;
+    float* planes = nullptr;  // rto_denoise(EXACT): weight + guidance planes, 2 x [n][4][H][W]
+    size_t planes_bytes = 0;
 };
 
 namespace {
@@ -313,11 +315,47 @@ int rto_filtering_culled(rto_guidance_net* net, void* stream, const float* weigh
     return RTO_OK;
 }
 
+int rto_denoise(rto_guidance_net* net, rto_ctx* ctx, int n, int mode, void* stream) {
+    if (!net || !ctx || n < 1) return fail(RTO_E_INVALID, "rto_denoise: bad argument");
+    if (mode != RTO_FILTER_EXACT && mode != RTO_FILTER_FACTORISED) return fail(RTO_E_INVALID, "rto_denoise: unknown mode");
+    const int W = rto_ctx_width(ctx), H = rto_ctx_height(ctx), sel = rto_ctx_selected_frame(ctx);
+    if (sel + n > rto_ctx_frames(ctx))
+        return fail(RTO_E_INVALID, "rto_denoise: " + std::to_string(n) + " frames from slot " + std::to_string(sel) + " of a context of " +
+                                       std::to_string(rto_ctx_frames(ctx)));
+    const float* aux = rto_ctx_aux(ctx);
+    const float* noisy = rto_ctx_noisy(ctx);
+    float* image = rto_ctx_image(ctx);
+    // the tile marks of the launch that rendered these frames, if it was a batched one over exactly these slots
+    const uint32_t* marks = nullptr;
+    int words = 0, first = 0, frames = 0;
+    float bg = 0.f;
+    if (rto_ctx_tile_marks(ctx, &marks, &words, &first, &frames, &bg) != RTO_OK || first != sel || frames < n) marks = nullptr;
+    if (mode == RTO_FILTER_FACTORISED) {
+        if (const int rc = rto_guidance_net_forward_packed_culled(net, stream, aux, n, H, W, RTO_NET_AUX_SQUARES_IMPLIED, marks, words, bg)) return rc;
+        return rto_filtering_packed_culled(net, stream, noisy, image, n, H, W, marks, words, bg);
+    }
+    const size_t plane_floats = (size_t)n * net->levels * H * W;
+    {
+        DeviceScope scope(net->device);
+        if (net->planes_bytes < 2 * plane_floats * sizeof(float)) {
+            if (net->planes && (hipDeviceSynchronize() != hipSuccess || hipFree(net->planes) != hipSuccess)) return fail(RTO_E_HIP, "hipFree failed");
+            net->planes = nullptr;
+            net->planes_bytes = 0;
+            if (hipMalloc((void**)&net->planes, 2 * plane_floats * sizeof(float)) != hipSuccess) return fail(RTO_E_HIP, "hipMalloc(map planes) failed");
+            net->planes_bytes = 2 * plane_floats * sizeof(float);
+        }
+    }
+    float *wm = net->planes, *gm = net->planes + plane_floats;
+    if (const int rc = rto_guidance_net_forward_culled(net, stream, aux, n, H, W, wm, gm, RTO_NET_AUX_SQUARES_IMPLIED, marks, words, bg)) return rc;
+    return rto_filtering_culled(net, stream, wm, gm, H, W, n, noisy, image, RTO_FILTER_EXACT, marks, words, bg);
+}
+
 void rto_guidance_net_free(rto_guidance_net* net) {
     if (!net) return;
     DeviceScope scope(net->device);
     if (net->packed) (void)hipFree(net->packed);
     if (net->fill_tile) (void)hipFree(net->fill_tile);
+    if (net->planes) (void)hipFree(net->planes);
     if (net->w1) (void)hipFree(net->w1);
     if (net->w2) (void)hipFree(net->w2);
     if (net->b2) (void)hipFree(net->b2);

@@ -212,6 +212,14 @@ class FusedGuidanceNet:
                                                     1 if squares_implied else 0, marks, int(words), float(bg)))
         return wm, gm
 
+    def denoise(self, ctx, n=1, mode=V.FILTER_FAST, stream=None):
+        """Denoiser::denoise (denoiser.cpp:31-61) in one call for the n frames of `ctx` from its selected slot on
+        (rto_denoise): network on ctx.aux, filter ctx.noisy -> ctx.image; uses the tile marks of the batched launch that
+        rendered them when there was one"""
+        from ._lib import check, lib
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        check(lib().rto_denoise(self._h, ctx._h, int(n), int(mode), V._stream_ptr(s)))
+
     def filter_planes(self, weight_map, guidance_map, img_in, img_out, mode=V.FILTER_EXACT, stream=None, cull=None):
         """volrend.filtering on this network's fp32 maps [n, L, H, W], skipping the filter tiles that see only culled render
         tiles (cull = RenderContext.tile_marks(); rto_filtering_culled; same bits).  cull=None: volrend.filtering"""

@@ -309,10 +309,13 @@ class RenderContext:
 
     def batch_views(self):
         """zero-copy views over ALL frame slots: aux [F,8,H,W], noisy [F,H,W,4], image [F,H,W,4]"""
+        sel = lib().rto_ctx_selected_frame(self._h)  # (the selection is the caller's: left as found)
         self.select_frame(0)
         F, H, W = self.frames, self.height, self.width
-        return (_DevArray(self.aux_ptr, (F, AUX_CHANNELS, H, W), self), _DevArray(self.noisy_ptr, (F, H, W, 4), self),
-                _DevArray(self.image_ptr, (F, H, W, 4), self))
+        views = (_DevArray(self.aux_ptr, (F, AUX_CHANNELS, H, W), self), _DevArray(self.noisy_ptr, (F, H, W, 4), self),
+                 _DevArray(self.image_ptr, (F, H, W, 4), self))
+        self.select_frame(sel)
+        return views
 
     def set_kernel(self, kernel):
         check(lib().rto_ctx_set_kernel(self._h, int(kernel)))

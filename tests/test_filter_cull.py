@@ -162,3 +162,44 @@ def test_refuses_foreign_marks(scene):
     with pytest.raises(ValueError):
         net.filter_packed(ctx.noisy_ptr, ctx.image_ptr, shape=(n, H, W), cull=(p, words, s0, 1, bg))
     ctx.free()
+
+
+@pytest.mark.parametrize("mode", ["fast", "exact"])
+def test_one_call_denoise_equals_the_separate_calls(scene, mode):
+    """rto_denoise (Denoiser::denoise in one call) == network + filter called separately, after a batched launch (tile
+    marks used) and after a single-frame launch into a later slot (no marks)"""
+    dt, net = scene
+    W, H, n = 400, 304, 4
+    cams = cams_for(W, H, n)
+    opt = R.RenderOptions(spp=6, denoise=True)
+    ctx = R.RenderContext(W, H, frames=n)
+    ctx.rng_seed()
+    R.launch_renderer_batch(dt, cams, opt, ctx)
+    aux = torch.as_tensor(ctx.batch_views()[0], device="cuda:0")
+    fmode = R.FILTER_FAST if mode == "fast" else R.FILTER_EXACT
+    ctx.select_frame(0)
+    if mode == "fast":
+        net.forward_packed(aux[:n], squares_implied=True)
+        net.filter_packed(ctx.noisy_ptr, ctx.image_ptr, shape=(n, H, W))
+    else:
+        wm, gm = net(aux[:n], squares_implied=True)
+        R.filtering(None, wm, gm, ctx.noisy_ptr, ctx.image_ptr, mode=R.FILTER_EXACT)
+    torch.cuda.synchronize()
+    want = images(ctx, n)
+    torch.as_tensor(ctx.batch_views()[2], device="cuda:0").fill_(-7.0)
+    net.denoise(ctx, n, fmode)
+    torch.cuda.synchronize()
+    assert_bits_equal(images(ctx, n).cpu().numpy(), want.cpu().numpy(), "rto_denoise after a batched launch, " + mode)
+    # a single frame into slot 2: no marks, same pixels as slot 2 of the batch (same camera, same RNG jump)
+    ctx.select_frame(2)
+    ctx.rng_seed()
+    ctx.rng_advance(2 << 32)
+    R.launch_renderer(dt, cams[2], opt, ctx)
+    assert ctx.tile_marks() is None
+    torch.as_tensor(ctx.batch_views()[2], device="cuda:0")[2].fill_(-7.0)
+    net.denoise(ctx, 1, fmode)
+    torch.cuda.synchronize()
+    assert_bits_equal(images(ctx, n)[2].cpu().numpy(), want[2].cpu().numpy(), "rto_denoise after a single-frame launch, " + mode)
+    with pytest.raises(R.RtoError, match="frames from slot"):
+        net.denoise(ctx, 3, fmode)  # slot 2 + 3 frames > 4
+    ctx.free()

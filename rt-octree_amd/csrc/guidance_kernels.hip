@@ -66,8 +66,17 @@ struct NetCull {
 // softmax logits, then the 4 guidance values -- instead of fp32 weight_map / guidance_map planes.  16 B per pixel
 // instead of 32, nothing lost: the reference's `.float()` (network.py:112) only widens those fp16 values, and the
 // consumer (filter_fast<L, true>) applies softmax_weights() below to the logits itself.
+// Launch bounds per instantiation: with all 8 aux planes in flight (SQ = false) the kernel needs 134 VGPRs; bounded to 128
+// (4 workgroups per CU) it spilled 2-4 of them to scratch.  Besides the cost, a process that had run such a kernel then got
+// different bits from rto_filtering (filter_fused, which has no scratch at all) in a quarter of its runs WHEN OTHER PROCESSES
+// SHARED THE GPU (tools/contention_determinism.py, profiles/r3_contention_determinism.txt; nothing of the kind alone on the
+// GPU, and the traversal kernel's spills do not cause it).  Whatever the mechanism below this library is, no kernel of the
+// denoise stage uses scratch now (tests/test_codegen.py).  -DRTO_NET_SQ0_WG=4 rebuilds the old bound for that experiment.
+#ifndef RTO_NET_SQ0_WG
+#define RTO_NET_SQ0_WG 3
+#endif
 template <int C1, int L, bool SQ, bool PACK>
-__global__ void __launch_bounds__(256, 4) guidance_fused(const float* __restrict__ aux,    // [n][8][H][W]
+__global__ void __launch_bounds__(256, SQ ? 4 : RTO_NET_SQ0_WG) guidance_fused(const float* __restrict__ aux,    // [n][8][H][W]
                                                        const _Float16* __restrict__ w1,  // [C1][96]   k = tap*8 + ci; k = 72: bias
                                                        const _Float16* __restrict__ w2,  // [16][9*C1] k = tap*C1 + ci
                                                        const float* __restrict__ b2,     // [16]

@@ -67,3 +67,21 @@ def test_the_valu_probe_loops_hold_exactly_the_instructions_they_claim(tmp_path)
         assert len(valu) == want, (name, len(valu), want)
         other = [ln for ln in loop if not ln.startswith("v_")]
         assert len([ln for ln in other if ln.startswith(("s_add_i32", "s_cmp", "s_cbranch"))]) == 3, (name, other[-4:])
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
+def test_no_kernel_of_the_denoise_stage_uses_scratch(tmp_path):
+    """Round 3 (tools/contention_determinism.py, profiles/r3_contention_determinism.txt): with several processes on one
+    GPU, a process that had run a GuidanceNet instantiation with register spills got different bits from the bit-exact
+    filter in a quarter of its runs.  The spills are gone (launch bounds per instantiation); this keeps them gone for
+    every kernel of guidance_kernels.hip and filter_kernels.hip."""
+    for src in ("guidance_kernels.hip", "filter_kernels.hip"):
+        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math",
+                            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", "--cuda-device-only",
+                            "-Rpass-analysis=kernel-resource-usage", os.path.join(CSRC, src), "-o", str(tmp_path / (src + ".o"))],
+                           check=True, capture_output=True, text=True, timeout=900)
+        names = re.findall(r"Function Name: (\S+)", r.stderr)
+        scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+        assert len(names) == len(scratch) and len(names) >= 4, (src, len(names), len(scratch))
+        bad = [(n, s) for n, s in zip(names, scratch) if s != 0]
+        assert not bad, "kernels of %s with a private segment: %s" % (src, bad)

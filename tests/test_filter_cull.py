@@ -203,3 +203,64 @@ def test_one_call_denoise_equals_the_separate_calls(scene, mode):
     with pytest.raises(R.RtoError, match="frames from slot"):
         net.denoise(ctx, 3, fmode)  # slot 2 + 3 frames > 4
     ctx.free()
+
+
+def _cull_seeds():
+    import os
+    spec = os.environ.get("RTO_FUZZ_SEEDS", "")
+    if ":" in spec:
+        a, b = spec.split(":")
+        return range(int(a), int(b))
+    return range(12)
+
+
+@pytest.mark.parametrize("seed", _cull_seeds())
+def test_random_frames_culled_denoise_is_bit_identical(scene, seed):
+    """random frame sizes, backgrounds, batch sizes and cameras (orbiting, far, inside the volume, looking past the model):
+    both denoise routes with the tile marks == without, bit for bit"""
+    dt, net = scene
+    rs = np.random.RandomState(500 + seed)
+    W, H = int(rs.randint(40, 520)), int(rs.randint(40, 420))
+    n = int(rs.randint(1, 5))
+    fx = float(rs.uniform(0.6, 2.5) * W)
+    cams = []
+    for _ in range(n):
+        mode = rs.rand()
+        if mode < 0.15:
+            pos = rs.uniform(-0.6, 0.6, 3)
+        elif mode < 0.4:
+            pos = rs.randn(3)
+            pos = pos / np.linalg.norm(pos) * rs.uniform(7, 15)
+        else:
+            pos = rs.randn(3)
+            pos = pos / np.linalg.norm(pos) * rs.uniform(2.5, 5.0)
+        target = rs.uniform(-0.4, 0.4, 3) if rs.rand() < 0.75 else rs.uniform(-3, 3, 3)
+        c = R.Camera(W, H, fx, fx)
+        c.set_c2w(synth.look_at_c2w(pos, target))
+        cams.append(c)
+    bg = float(rs.choice([1.0, 0.0, rs.rand()]))
+    opt = R.RenderOptions(spp=int(rs.choice([1, 4, 6])), denoise=True, background_brightness=bg)
+    ctx = R.RenderContext(W, H, frames=n)
+    ctx.rng_seed()
+    R.launch_renderer_batch(dt, cams, opt, ctx, rng_jumps=[int(rs.randint(0, 300)) for _ in range(n)])
+    marks = ctx.tile_marks()
+    aux = torch.as_tensor(ctx.batch_views()[0], device="cuda:0")
+    ctx.select_frame(0)
+    net.forward_packed(aux[:n], squares_implied=True)
+    net.filter_packed(ctx.noisy_ptr, ctx.image_ptr, shape=(n, H, W))
+    torch.cuda.synchronize()
+    plain = images(ctx, n)
+    wm, gm = (t.clone() for t in net(aux[:n], squares_implied=True))
+    R.filtering(None, wm, gm, ctx.noisy_ptr, ctx.image_ptr, mode=R.FILTER_EXACT)
+    torch.cuda.synchronize()
+    plain_exact = images(ctx, n)
+    net.denoise(ctx, n, R.FILTER_FAST)
+    torch.cuda.synchronize()
+    assert_bits_equal(images(ctx, n).cpu().numpy(), plain.cpu().numpy(), "seed %d packed route %dx%d n %d bg %g" % (seed, W, H, n, bg))
+    net.denoise(ctx, n, R.FILTER_EXACT)
+    torch.cuda.synchronize()
+    assert_bits_equal(images(ctx, n).cpu().numpy(), plain_exact.cpu().numpy(), "seed %d exact route %dx%d n %d bg %g" % (seed, W, H, n, bg))
+    wm_c, gm_c = net(aux[:n], squares_implied=True, cull=marks)
+    torch.cuda.synchronize()
+    assert torch.equal(wm_c, wm) and torch.equal(gm_c, gm)
+    ctx.free()

@@ -49,7 +49,17 @@ def _scene(seed):
     return tree, W, H, fx, poses, opt, int(rs.randint(0, 300))
 
 
-@pytest.mark.parametrize("seed", range(32))
+def _seeds():
+    """32 scenes by default; RTO_FUZZ_SEEDS="first:last" widens the sweep for a soak run (tools/fuzz_soak.sh)"""
+    import os
+    spec = os.environ.get("RTO_FUZZ_SEEDS", "")
+    if ":" in spec:
+        a, b = spec.split(":")
+        return range(int(a), int(b))
+    return range(32)
+
+
+@pytest.mark.parametrize("seed", _seeds())
 def test_random_scene_all_kernels_bit_exact(seed):
     tree, W, H, fx, poses, optkw, frame0 = _scene(seed)
     ht = orc.HostTree(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)

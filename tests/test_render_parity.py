@@ -1,6 +1,8 @@
 """HIP render path (through the C ABI) vs the CPU oracle: bit-exact fp32 aux planes, RGBA32F image
 and RGBA8 bytes on the same seeded inputs.  Tolerance: none (0 ulp) -- both sides evaluate the same
 IEEE expression sequence with the shared deterministic logf/expf definition (DESIGN.md "Math")."""
+import os
+
 import numpy as np
 import pytest
 
@@ -475,6 +477,7 @@ def test_batched_launches_repeat_bit_for_bit(small_tree_sh16):
     assert len(seen) == 1
 
 
+@pytest.mark.skipif(bool(os.environ.get("PYTEST_XDIST_WORKER")), reason="free-memory accounting needs the GPU to itself")
 def test_handles_release_their_device_memory(small_tree_sh9):
     """create / use / free trees, contexts (all lazily grown buffers included) and fused networks in a
     loop: free device memory returns to where it started"""

@@ -25,7 +25,8 @@ def main():
     import torch
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-    t = synth.make_tree(depth_limit=7, basis_dim=9, shell=2.5)
+    basis = int(os.environ.get("RTO_CD_BASIS", "9"))  # 25: the shading kernel's SH25 instantiation spills (scratch) as well
+    t = synth.make_tree(depth_limit=7, basis_dim=basis, shell=2.5)
     dt = R.N3Tree.from_arrays(t.child, t.data, t.scale, t.offset, t.data_format)
     torch.manual_seed(3)
     net = denoiser.FusedGuidanceNet(denoiser.GuidanceNetCompact.from_full(denoiser.GuidanceNet(8, 32, 5, 2, 4)).eval())
@@ -85,7 +86,7 @@ def main():
         cnt["factorised filter on planes"] += not twice(lambda: R.filtering(None, w1, g1, ctx.noisy_ptr, ctx.image_ptr, mode=R.FILTER_FAST))
         cnt["one-call denoise exact"] += not twice(lambda: net.denoise(ctx, n, R.FILTER_EXACT))
         ctx.free()
-    print("seed %d: runs that differed from their repeat, of %d: %s" % (seed, iters, cnt), flush=True)
+    print("basis %d" % basis, end=" "); print("seed %d: runs that differed from their repeat, of %d: %s" % (seed, iters, cnt), flush=True)
     return 1 if any(cnt.values()) else 0
 
 

@@ -1456,8 +1456,15 @@ RTO_DEV void leaf_contrib(const TreeDev& tree, uint32_t slot, const float* basis
 #ifndef RTO_SHADE_WPS
 #define RTO_SHADE_WPS 4
 #endif
+// workgroups per CU the kernel is built for: the SH25 layouts (76 coefficients in registers) and the quantised SH16 one need
+// more than the 128 VGPRs that 4 leave them (they spilled 10-50 registers to scratch: SH25 shading 9.6 -> 8.7 ms per 100
+// frames of 1920x1080 without the spills, at 3)
+#ifndef RTO_SHADE_WPS_SH25
+#define RTO_SHADE_WPS_SH25 3
+#endif
+constexpr int shade_wps(int mode) { return (mode == 76 || mode == -25 || mode == -16) ? RTO_SHADE_WPS_SH25 : RTO_SHADE_WPS; }
 template <int SPP, int P, int MODE>
-__global__ void __launch_bounds__(256, RTO_SHADE_WPS) shade_kernel(const TreeDev tree, const OptDev opt, const FrameBatch fb) {
+__global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeDev tree, const OptDev opt, const FrameBatch fb) {
     __shared__ uint32_t s_h[4][kShadeCap];       // packed hit entry
     __shared__ uint16_t s_q[4][kShadeCap];       // its pixel, relative to the wave's first pixel
     __shared__ float s_c[4][3 * kShadeCap];      // its contribution, [channel][entry]

@@ -351,7 +351,9 @@ int rto_filtering_packed_culled(rto_guidance_net* net, void* stream, const float
  * context's aux buffer, the filter from its noisy buffer into its image buffer.  mode RTO_FILTER_FACTORISED: packed fp16
  * maps + factorised filter (the throughput route); RTO_FILTER_EXACT: fp32 planes (a scratch the handle owns, 32 B per
  * pixel) + the bit-exact filter.  When the frames are those of the last rto_launch_renderer_batch on `ctx` its tile marks
- * are used (the *_culled calls above); after a single-frame launch the plain kernels run.  Same results either way. */
+ * are used (the *_culled calls above); after a single-frame launch the plain kernels run.  Same results either way.
+ * Like the packed scratch, the plane scratch grows on demand and growing synchronises the device once: call it once at the
+ * largest extent before a timed or captured region. */
 int rto_denoise(rto_guidance_net* net, rto_ctx* ctx, int n, int mode, void* stream);
 void rto_guidance_net_free(rto_guidance_net* net);
 

@@ -377,6 +377,10 @@ int rto_probe_gather_sweep(uint64_t table_bytes, int lines_per_gather, int block
                            int iters, int repeats, double out[4]);
 int rto_probe_valu(int kind, int wps, int iters, double out[6]);
 const char* rto_probe_valu_name(int kind);
+/* rto_probe_scratch: one launch (null stream, asynchronous) of a kernel with a private segment (kind bit 0: a dynamically
+ * indexed per-thread array), 34 KB of static LDS (bit 1), an MFMA loop (bit 2) -- the would-be trigger in
+ * tools/contention_determinism.py's experiment on determinism when processes share the GPU. */
+int rto_probe_scratch(int kind, int blocks, int iters);
 /* Test hook: host_out[i] = the threshold the renderer draws from the RNG float k / 2^23, k = first_k + i
  * (rt_core.cuh:67-88 `-logf(1 - rng.next_float())` in the library's deterministic arithmetic), computed on the
  * device by the very function the kernels call.  first_k + count <= 2^23: the whole domain can be compared with

@@ -116,6 +116,7 @@ SYMBOLS = {
     "rto_probe_gather": (C.c_int, [C.c_uint64, C.c_int]),
     "rto_probe_gather_sweep": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(C.c_double)]),
+    "rto_probe_scratch": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "rto_probe_valu": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "rto_probe_valu_name": (C.c_char_p, [C.c_int]),
     "rto_probe_thresholds": (C.c_int, [C.c_uint32, C.c_uint32, _P]),

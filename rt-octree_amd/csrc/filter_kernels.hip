@@ -30,6 +30,9 @@
 
 namespace rto {
 
+#ifndef RTO_FILTER_PK
+#define RTO_FILTER_PK 0
+#endif
 constexpr int kFiltW = 32, kFiltH = 8;  // output tile per 256-thread workgroup
 
 // what Filtering::forward keeps for backward when requires_grad (filtering.cu:205-216)
@@ -48,9 +51,29 @@ RTO_DEV void filter_level(const float* __restrict__ g, const float4* __restrict_
 #pragma unroll
         for (int dx = -S; dx <= S; ++dx) max_val = fmaxf(max_val, row[dx]);
     }
-    // accumulators as two packed pairs: {r, g} and {b, kernel_sum}.  The tile's alpha is staged as
-    // 1, so kernel_sum += k is the lane fma(1, k, kernel_sum) = kernel_sum + k exactly, and each tap
-    // costs two v_pk_fma_f32 instead of three FMAs and an add.
+    // accumulators {r, g}, {b, kernel_sum}.  The tile's alpha is staged as 1, so kernel_sum += k is fma(1, k, kernel_sum) =
+    // kernel_sum + k exactly: four FMAs per tap.
+    // Scalar FMAs (v_fma_f32), one tap at a time.  Rounds 1-2 ran this loop on packed pairs -- v_pk_fma_f32, exps of two
+    // neighbouring taps at once (-DRTO_FILTER_PK=1 rebuilds it) -- the same bits and the same speed (a packed instruction
+    // issues at half rate), until round 3 found those bits wrong in lanes 48..63 of some waves whenever another process kept
+    // the GPU busy with MFMA-dense kernels (DESIGN.md "Determinism when the GPU is shared").  Of all kernels only this one
+    // held v_pk_fma_f32; v_pk_add / v_pk_mul (filter_fast, shading) never showed it.
+#if !RTO_FILTER_PK
+    float2v rg = {0.f, 0.f}, bs = {0.f, 0.f};
+#pragma unroll 1
+    for (int dy = -S; dy <= S; ++dy) {
+        const int e0 = centre + dy * TW;
+#pragma unroll
+        for (int dx = -S; dx <= S; ++dx) {
+            const float k = fexp_f32_le88(g[e0 + dx] - max_val);
+            const float4 t = rgb[e0 + dx];
+            rg.x = __builtin_fmaf(t.x, k, rg.x);
+            rg.y = __builtin_fmaf(t.y, k, rg.y);
+            bs.x = __builtin_fmaf(t.z, k, bs.x);
+            bs.y = __builtin_fmaf(t.w, k, bs.y);
+        }
+    }
+#else
     float2v rg = {0.f, 0.f}, bs = {0.f, 0.f};
 #pragma unroll 1
     for (int dy = -S; dy <= S; ++dy) {
@@ -77,6 +100,7 @@ RTO_DEV void filter_level(const float* __restrict__ g, const float4* __restrict_
             bs = __builtin_elementwise_fma(float2v{t.z, t.w}, float2v{k, k}, bs);
         }
     }
+#endif
     float r = rg.x, gg = rg.y, b = bs.x;
     const float kernel_sum = bs.y;
     const float inv = 1.0f / kernel_sum;

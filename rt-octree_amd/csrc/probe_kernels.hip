@@ -479,6 +479,60 @@ extern "C" const char* rto_probe_valu_name(int kind) {
     return kind >= 0 && kind < kNumValuKinds ? kValuKinds[kind].name : nullptr;
 }
 
+// ---- a kernel with a private segment, for tools/contention_determinism.py ----------------------------------------------
+// Round 3 found that a process which had run a GuidanceNet instantiation with register spills got different bits from
+// filter_fused when other processes shared the GPU.  This probe isolates "a kernel with scratch": a per-thread array indexed
+// by a run-time value (the compiler keeps it in scratch memory), optionally beside a static LDS allocation and an MFMA.
+// kind bit 0: the dynamically indexed private array; bit 1: 34 KB of static LDS in use; bit 2: one MFMA per iteration.
+template <int KIND>
+__global__ void __launch_bounds__(256, 4) scratch_probe_kernel(float* __restrict__ out, int iters, int stride) {
+    __shared__ float s_buf[(KIND & 2) ? 34 * 256 : 64];
+    const int tid = threadIdx.x;
+    float acc = (float)tid;
+    if (KIND & 2) {
+        for (int i = tid; i < 34 * 256; i += 256) s_buf[i] = (float)i;
+        __syncthreads();
+    }
+    if constexpr ((KIND & 1) != 0) {
+        float priv[48];
+#pragma unroll
+        for (int i = 0; i < 48; ++i) priv[i] = acc + (float)i;
+        int idx = (tid * 7 + stride) % 48;
+        for (int it = 0; it < iters; ++it) {
+            acc += priv[idx];
+            priv[(idx + 5) % 48] = acc * 0.5f;
+            idx = (idx + stride) % 48;
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) acc = acc * 0.999f + (float)it;
+    }
+    if constexpr ((KIND & 4) != 0) {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        h8 a = {1, 2, 3, 4, 5, 6, 7, 8}, b = {1, 1, 1, 1, 1, 1, 1, 1};
+        f4 c = {acc, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+        acc += c[0];
+    }
+    if (KIND & 2) acc += s_buf[(tid * 33) % (34 * 256)];
+    out[blockIdx.x * 256 + tid] = acc;
+}
+
+extern "C" int rto_probe_scratch(int kind, int blocks, int iters) {
+    if (kind < 0 || kind > 7 || blocks < 1 || blocks > (1 << 20) || iters < 1) return RTO_E_INVALID;
+    static float* out = nullptr;
+    static int cap = 0;
+    if (cap < blocks) {
+        if (out) (void)hipFree(out);
+        if (hipMalloc((void**)&out, (size_t)blocks * 256 * sizeof(float)) != hipSuccess) return RTO_E_HIP;
+        cap = blocks;
+    }
+#define RTO_SP(K) case K: hipLaunchKernelGGL(scratch_probe_kernel<K>, dim3(blocks), dim3(256), 0, nullptr, out, iters, 3 + kind); break;
+    switch (kind) { RTO_SP(0) RTO_SP(1) RTO_SP(2) RTO_SP(3) RTO_SP(4) RTO_SP(5) RTO_SP(6) RTO_SP(7) }
+#undef RTO_SP
+    return hipGetLastError() == hipSuccess ? RTO_OK : RTO_E_HIP;
+}
+
 // out[0] = wall ms, out[1] = mean s_memtime ticks per wave, out[2] = waves, out[3] = VALU instructions per wave (exact:
 // the asm block's count x iters), out[4] = ticks from the first wave's start to the last wave's end, out[5] = CUs
 extern "C" int rto_probe_valu(int kind, int wps, int iters, double out[6]) {

@@ -85,3 +85,22 @@ def test_no_kernel_of_the_denoise_stage_uses_scratch(tmp_path):
         assert len(names) == len(scratch) and len(names) >= 4, (src, len(names), len(scratch))
         bad = [(n, s) for n, s in zip(names, scratch) if s != 0]
         assert not bad, "kernels of %s with a private segment: %s" % (src, bad)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
+def test_no_kernel_holds_v_pk_fma_f32(tmp_path):
+    """Round 3 (tools/scratch_hazard_probe.py, profiles/r3_scratch_hazard_probe.txt): v_pk_fma_f32 returned wrong values in
+    lanes 48..63 while another process ran MFMA-dense kernels on the same GPU -- the bit-exact filter, the only kernel that
+    held the instruction, differed from its own repeat in 507 of 800 runs, and in 0 of 800 once it was built from scalar
+    FMAs (same speed).  filter_kernels.hip is therefore compiled without the SLP vectoriser (which re-forms the packed FMAs);
+    this test builds every device source the way the Makefile does and looks for the instruction."""
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    assert re.search(r"filter_kernels\.o: HIPFLAGS \+= -fno-slp-vectorize", mk), "the Makefile no longer disables SLP for filter_kernels.hip"
+    for src, extra in (("filter_kernels.hip", ["-fno-slp-vectorize"]), ("guidance_kernels.hip", []), ("render_kernels.hip", [])):  # (probe_kernels.hip holds the instruction on purpose: the VALU calibration probe)
+        asm = tmp_path / (src + ".s")
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math"] + extra +
+                       ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", str(asm)],
+                       check=True, capture_output=True, timeout=900)
+        text = asm.read_text()
+        assert "s_endpgm" in text
+        assert "v_pk_fma_f32" not in text, "%s: %d v_pk_fma_f32" % (src, text.count("v_pk_fma_f32"))

@@ -67,11 +67,10 @@ struct NetCull {
 // instead of 32, nothing lost: the reference's `.float()` (network.py:112) only widens those fp16 values, and the
 // consumer (filter_fast<L, true>) applies softmax_weights() below to the logits itself.
 // Launch bounds per instantiation: with all 8 aux planes in flight (SQ = false) the kernel needs 134 VGPRs; bounded to 128
-// (4 workgroups per CU) it spilled 2-4 of them to scratch.  Besides the cost, a process that had run such a kernel then got
-// different bits from rto_filtering (filter_fused, which has no scratch at all) in a quarter of its runs WHEN OTHER PROCESSES
-// SHARED THE GPU (tools/contention_determinism.py, profiles/r3_contention_determinism.txt; nothing of the kind alone on the
-// GPU, and the traversal kernel's spills do not cause it).  Whatever the mechanism below this library is, no kernel of the
-// denoise stage uses scratch now (tests/test_codegen.py).  -DRTO_NET_SQ0_WG=4 rebuilds the old bound for that experiment.
+// (4 workgroups per CU) it spilled 2-4 of them to scratch and ran slower.  It was also the kernel in whose company the
+// bit-exact filter first lost its determinism on a shared GPU (DESIGN.md "Determinism when the GPU is shared": the cause
+// turned out to be v_pk_fma_f32 under MFMA load from other processes, this kernel being the longest MFMA kernel around); no
+// kernel of the denoise stage uses scratch now (tests/test_codegen.py).  -DRTO_NET_SQ0_WG=4 rebuilds the old bound.
 #ifndef RTO_NET_SQ0_WG
 #define RTO_NET_SQ0_WG 3
 #endif

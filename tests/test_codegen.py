@@ -71,10 +71,10 @@ def test_the_valu_probe_loops_hold_exactly_the_instructions_they_claim(tmp_path)
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
 def test_no_kernel_of_the_denoise_stage_uses_scratch(tmp_path):
-    """Round 3 (tools/contention_determinism.py, profiles/r3_contention_determinism.txt): with several processes on one
-    GPU, a process that had run a GuidanceNet instantiation with register spills got different bits from the bit-exact
-    filter in a quarter of its runs.  The spills are gone (launch bounds per instantiation); this keeps them gone for
-    every kernel of guidance_kernels.hip and filter_kernels.hip."""
+    """Round 3 (tools/contention_determinism.py, profiles/r3_contention_determinism.txt): the GuidanceNet instantiations that
+    spilled registers were the slowest MFMA kernels of the path -- and the company in which the bit-exact filter first lost
+    its determinism on a shared GPU (see the next test for the cause).  The spills are gone (launch bounds per
+    instantiation); this keeps them gone for every kernel of guidance_kernels.hip and filter_kernels.hip."""
     for src in ("guidance_kernels.hip", "filter_kernels.hip"):
         r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math",
                             "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", "--cuda-device-only",

@@ -3,11 +3,10 @@ the processes' queues: waves are saved and restored mid-kernel).  Each stage is 
 bit for bit, over random frame sizes; tools/contention_check.sh starts 8 copies of this script at once.
 
 Why this exists (round 3): with 8 processes on one GPU, rto_filtering (the bit-exact filter, filter_fused) returned
-different bits in ~25 % of its runs -- lanes 48..63 of some waves a few ulp to 1e-2 off -- but only in processes that had
-earlier run a GuidanceNet instantiation with register spills (the squares_implied = false variants: 12-20 bytes of scratch
-per lane).  Alone on the GPU everything was deterministic, and so were all other kernels (the traversal kernel spills too).
-The mechanism is below this library; the spills were removed (guidance_kernels.hip: launch bounds per instantiation,
-tests/test_codegen.py pins it) and this check stays.
+different bits in ~25 % of its runs -- lanes 48..63 of some waves a few ulp to 1e-2 off.  Alone on the GPU everything was
+deterministic, and so were all other kernels.  tools/scratch_hazard_probe.py isolated it: v_pk_fma_f32 (only that kernel had
+it) goes wrong while waves of another process run MFMA-dense kernels.  The filter is built from scalar FMAs now
+(tests/test_codegen.py keeps the instruction out) and this check stays.
 
 python tools/contention_determinism.py SEED [ITERS]"""
 import os

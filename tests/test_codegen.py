@@ -14,15 +14,27 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "rt-octree_amd", "csrc")
+_ASM = {}
+
+
+def device_asm(src, extra=()):
+    """gfx950 assembly of one device source, compiled once per test session with the Makefile's flags (+ extra)"""
+    key = (src, tuple(extra))
+    if key not in _ASM:
+        import tempfile
+        out = os.path.join(tempfile.mkdtemp(prefix="rto_codegen_"), src + ".s")
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math"] + list(extra) +
+                       ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out],
+                       check=True, capture_output=True, timeout=900)
+        with open(out) as f:
+            _ASM[key] = f.read()
+        shutil.rmtree(os.path.dirname(out), ignore_errors=True)
+    return _ASM[key]
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
 def test_the_two_gathers_of_a_node_visit_are_issued_back_to_back(tmp_path):
-    asm = tmp_path / "render_kernels.s"
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math",
-                    "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-S", "--cuda-device-only",
-                    os.path.join(CSRC, "render_kernels.hip"), "-o", str(asm)], check=True, capture_output=True, timeout=900)
-    text = asm.read_text()
+    text = device_asm("render_kernels.hip")
     for spp in (1, 6):  # the benchmark's instantiations (C5, C2 / C4)
         m = re.search(r"^_ZN3rto14render_persistILi%dELi32ELi7EEE[^\n]*\n(.*?)s_endpgm" % spp, text, re.S | re.M)
         assert m, "render_persist<%d,32,7> not found in the assembly" % spp
@@ -97,10 +109,6 @@ def test_no_kernel_holds_v_pk_fma_f32(tmp_path):
     mk = open(os.path.join(CSRC, "Makefile")).read()
     assert re.search(r"filter_kernels\.o: HIPFLAGS \+= -fno-slp-vectorize", mk), "the Makefile no longer disables SLP for filter_kernels.hip"
     for src, extra in (("filter_kernels.hip", ["-fno-slp-vectorize"]), ("guidance_kernels.hip", []), ("render_kernels.hip", [])):  # (probe_kernels.hip holds the instruction on purpose: the VALU calibration probe)
-        asm = tmp_path / (src + ".s")
-        subprocess.run(["hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math"] + extra +
-                       ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", str(asm)],
-                       check=True, capture_output=True, timeout=900)
-        text = asm.read_text()
+        text = device_asm(src, extra)
         assert "s_endpgm" in text
         assert "v_pk_fma_f32" not in text, "%s: %d v_pk_fma_f32" % (src, text.count("v_pk_fma_f32"))

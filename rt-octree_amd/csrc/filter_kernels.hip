@@ -55,8 +55,8 @@ RTO_DEV void filter_level(const float* __restrict__ g, const float4* __restrict_
     // kernel_sum + k exactly: four FMAs per tap.
     // Scalar FMAs (v_fma_f32), one tap at a time.  Rounds 1-2 ran this loop on packed pairs -- v_pk_fma_f32, exps of two
     // neighbouring taps at once (-DRTO_FILTER_PK=1 rebuilds it) -- the same bits and the same speed (a packed instruction
-    // issues at half rate), until round 3 found those bits wrong in lanes 48..63 of some waves whenever another process kept
-    // the GPU busy with MFMA-dense kernels (DESIGN.md "Determinism when the GPU is shared").  Of all kernels only this one
+    // issues at half rate), until round 3 found the packed build's bits wrong in lanes 48..63 of some waves whenever another
+    // process kept the GPU busy with MFMA-dense kernels (DESIGN.md "Determinism when the GPU is shared").  Of all kernels only this one
     // held v_pk_fma_f32; v_pk_add / v_pk_mul (filter_fast, shading) never showed it.
 #if !RTO_FILTER_PK
     float2v rg = {0.f, 0.f}, bs = {0.f, 0.f};

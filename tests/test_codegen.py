@@ -101,10 +101,10 @@ def test_no_kernel_of_the_denoise_stage_uses_scratch(tmp_path):
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
 def test_no_kernel_holds_v_pk_fma_f32(tmp_path):
-    """Round 3 (tools/scratch_hazard_probe.py, profiles/r3_scratch_hazard_probe.txt): v_pk_fma_f32 returned wrong values in
-    lanes 48..63 while another process ran MFMA-dense kernels on the same GPU -- the bit-exact filter, the only kernel that
-    held the instruction, differed from its own repeat in 507 of 800 runs, and in 0 of 800 once it was built from scalar
-    FMAs (same speed).  filter_kernels.hip is therefore compiled without the SLP vectoriser (which re-forms the packed FMAs);
+    """Round 3 (tools/scratch_hazard_probe.py, profiles/r3_scratch_hazard_probe.txt): the bit-exact filter, the only kernel
+    that held v_pk_fma_f32, returned wrong values in lanes 48..63 while another process ran MFMA-dense kernels on the same
+    GPU -- it differed from its own repeat in 507 of 800 runs, and in 0 of 800 once it was built from scalar FMAs (same
+    speed).  filter_kernels.hip is therefore compiled without the SLP vectoriser (which re-forms the packed FMAs);
     this test builds every device source the way the Makefile does and looks for the instruction."""
     mk = open(os.path.join(CSRC, "Makefile")).read()
     assert re.search(r"filter_kernels\.o: HIPFLAGS \+= -fno-slp-vectorize", mk), "the Makefile no longer disables SLP for filter_kernels.hip"

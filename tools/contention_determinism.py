@@ -4,8 +4,8 @@ bit for bit, over random frame sizes; tools/contention_check.sh starts 8 copies 
 
 Why this exists (round 3): with 8 processes on one GPU, rto_filtering (the bit-exact filter, filter_fused) returned
 different bits in ~25 % of its runs -- lanes 48..63 of some waves a few ulp to 1e-2 off.  Alone on the GPU everything was
-deterministic, and so were all other kernels.  tools/scratch_hazard_probe.py isolated it: v_pk_fma_f32 (only that kernel had
-it) goes wrong while waves of another process run MFMA-dense kernels.  The filter is built from scalar FMAs now
+deterministic, and so were all other kernels.  tools/scratch_hazard_probe.py isolated it: the build of that kernel on v_pk_fma_f32
+(no other kernel had the instruction) goes wrong while waves of another process run MFMA-dense kernels.  The filter is built from scalar FMAs now
 (tests/test_codegen.py keeps the instruction out) and this check stays.
 
 python tools/contention_determinism.py SEED [ITERS]"""

@@ -73,6 +73,42 @@ RTO_DEV void filter_level(const float* __restrict__ g, const float4* __restrict_
             bs.y = __builtin_fmaf(t.w, k, bs.y);
         }
     }
+#elif RTO_FILTER_PK == 3  // (experiment: scalar exps, packed accumulation -- which half of the packed form is it?)
+    float2v rg = {0.f, 0.f}, bs = {0.f, 0.f};
+#pragma unroll 1
+    for (int dy = -S; dy <= S; ++dy) {
+        const int e0 = centre + dy * TW;
+#pragma unroll
+        for (int dx = -S; dx <= S; ++dx) {
+            const float k = fexp_f32_le88(g[e0 + dx] - max_val);
+            const float4 t = rgb[e0 + dx];
+            rg = __builtin_elementwise_fma(float2v{t.x, t.y}, float2v{k, k}, rg);
+            bs = __builtin_elementwise_fma(float2v{t.z, t.w}, float2v{k, k}, bs);
+        }
+    }
+#elif RTO_FILTER_PK == 2  // (experiment: packed exps, scalar accumulation)
+    float2v rg = {0.f, 0.f}, bs = {0.f, 0.f};
+#pragma unroll 1
+    for (int dy = -S; dy <= S; ++dy) {
+        const int e0 = centre + dy * TW;
+#pragma unroll
+        for (int dx = -S; dx <= S; dx += 2) {
+            float2v x2;
+            x2.x = g[e0 + dx] - max_val;
+            x2.y = dx + 1 <= S ? g[e0 + dx + 1] - max_val : 0.f;
+            const float2v k2 = fexp_f32_le88_x2(x2);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (dx + h > S) break;
+                const float k = h ? k2.y : k2.x;
+                const float4 t = rgb[e0 + dx + h];
+                rg.x = __builtin_fmaf(t.x, k, rg.x);
+                rg.y = __builtin_fmaf(t.y, k, rg.y);
+                bs.x = __builtin_fmaf(t.z, k, bs.x);
+                bs.y = __builtin_fmaf(t.w, k, bs.y);
+            }
+        }
+    }
 #else
     float2v rg = {0.f, 0.f}, bs = {0.f, 0.f};
 #pragma unroll 1

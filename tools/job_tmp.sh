@@ -1,8 +1,14 @@
 #!/bin/bash
 OUT=gpurun_out; rm -f $OUT/r3_scratch_hazard_probe.txt
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -n 1
-echo "--- processes right after pytest:"; ps -eo pid,etime,pcpu,cmd | grep -E "python|volrend|torch" | grep -v grep | cut -c1-150 | head
-rocm-smi --showuse --showpower --showtemp --showclocks 2>/dev/null | grep -E "GPU\[0\]" | head -12
-KINDS="-1 -1" bash tools/scratch_hazard_probe.sh 100 > /dev/null
-rocm-smi --showuse --showpower --showtemp 2>/dev/null | grep -E "GPU\[0\]" | head -8
+for i in 0 1 2; do
+  echo "== $(cat rt-octree_amd/lib_ab/flags_$i.txt)" >> $OUT/r3_scratch_hazard_probe.txt
+  RTO_LIB=$PWD/rt-octree_amd/lib_ab/librto_$i.so KINDS="5" bash tools/scratch_hazard_probe.sh 100 > /dev/null
+done
+echo "== shipped" >> $OUT/r3_scratch_hazard_probe.txt
+KINDS="5" bash tools/scratch_hazard_probe.sh 100 > /dev/null
 cat $OUT/r3_scratch_hazard_probe.txt
+python - <<'PY'
+import sys; sys.path.insert(0,'tests'); sys.path.insert(0,'.')
+PY
+timeout 600 python -m pytest tests/test_filter_parity.py -x -q -m gpu 2>&1 | tail -n 1
+for i in 1 2; do RTO_LIB=$PWD/rt-octree_amd/lib_ab/librto_$i.so timeout 600 python -m pytest tests/test_filter_parity.py -x -q -m gpu 2>&1 | tail -n 1; done

@@ -40,6 +40,7 @@ Rank 0 prints ONE JSON line (contract in the task statement) with these extra ob
                     bounded sample of the same frames, all host cores.
 """
 import argparse
+import gc
 import hashlib
 import json
 import os
@@ -411,12 +412,26 @@ def main():
             lc.kernel_timing(True)
         barrier()
         torch.cuda.synchronize(dev)
+        # No Python garbage collection inside the timed region: a full collection of a process that holds torch and the
+        # host copy of the tree takes 35-40 ms, as long as the whole timed region of the SPP-1 configuration, and whether
+        # one falls into the region depends on allocation counts (round 3: C5 read 10 k or 21 k frames/s from one run to
+        # the next until this was found; the GPU timeline of both was the same).
+        gc.collect()
+        gc.disable()
         t0 = time.perf_counter()
+        host_ms = []
         for g, (sc, idx) in enumerate(work):
+            t1 = time.perf_counter()
             group(sc, idx, events[g], g % len(lanes), exact)
+            host_ms.append((time.perf_counter() - t1) * 1e3)
+        t_issued = time.perf_counter() - t0
         torch.cuda.synchronize(dev)
         barrier()
         elapsed = time.perf_counter() - t0
+        gc.enable()
+        if os.environ.get("RTO_BENCH_DEBUG"):
+            print("[bench] host ms per group call: %s; issued after %.1f ms, done after %.1f ms" % (
+                " ".join("%.2f" % h for h in host_ms), t_issued * 1e3, elapsed * 1e3), file=sys.stderr)
         if world > 1:
             t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -484,6 +484,7 @@ extern "C" const char* rto_probe_valu_name(int kind) {
 // filter_fused when other processes shared the GPU.  This probe isolates "a kernel with scratch": a per-thread array indexed
 // by a run-time value (the compiler keeps it in scratch memory), optionally beside a static LDS allocation and an MFMA.
 // kind bit 0: the dynamically indexed private array; bit 1: 34 KB of static LDS in use; bit 2: one MFMA per iteration.
+#ifndef RTO_NO_SCRATCH_PROBE
 template <int KIND>
 __global__ void __launch_bounds__(256, 4) scratch_probe_kernel(float* __restrict__ out, int iters, int stride) {
     __shared__ float s_buf[(KIND & 2) ? 34 * 256 : 64];
@@ -532,6 +533,9 @@ extern "C" int rto_probe_scratch(int kind, int blocks, int iters) {
 #undef RTO_SP
     return hipGetLastError() == hipSuccess ? RTO_OK : RTO_E_HIP;
 }
+#else
+extern "C" int rto_probe_scratch(int, int, int) { return RTO_E_UNSUPPORTED; }
+#endif
 
 // out[0] = wall ms, out[1] = mean s_memtime ticks per wave, out[2] = waves, out[3] = VALU instructions per wave (exact:
 // the asm block's count x iters), out[4] = ticks from the first wave's start to the last wave's end, out[5] = CUs

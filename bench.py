@@ -574,6 +574,8 @@ def main():
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         sums = [0.0, 0.0, 0.0]
         t_wall = 0.0
+        gc.collect()
+        gc.disable()  # (wall-clock loops of 10-20 ms: see timed())
         for k in range(-8, nf):  # 8 untimed warm-up frames
             sc, i = frame_of(max(k, 0), maps[0])
             t1 = time.perf_counter()
@@ -630,6 +632,7 @@ def main():
                                              "frame k - D before launching frame k"}
             for c2, _, _, _ in plane[1:]:
                 c2.free()
+        gc.enable()
         one.free()
 
     # ---------------- untimed: work units of the same frames -> algorithmic bytes ----------------

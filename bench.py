@@ -215,10 +215,7 @@ def plan_only(args):
     """--plan-only: what every rank WOULD render (no GPU): {"world", "plans": {map: [[(scene, [poses]) ...] per rank]},
     "rng_jumps": the per-frame jump of pose i}; ranks exchange their plans over gloo."""
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    rank, world, _ = check_world(args)
     B = max(1, min(128, args.batch))
     n_scenes = 1 if args.tree else max(1, min(8, args.scenes))
     maps = ["pose", "scene"] if n_scenes > 1 else ["pose"]
@@ -237,8 +234,47 @@ def plan_only(args):
                           "rng_jump_of_pose": "%d + pose" % WARM_FRAMES_REF}))
 
 
+def self_launch(args, argv=None):
+    """`bench.py --gpus N` with no launcher around it (WORLD_SIZE unset, N > 1): start the N ranks HERE, as a CHILD process
+    running the driver's own line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same
+    args>`), relay its output and return its exit code.  Called before torch is imported: this process never touches a
+    GPU (nothing is exec'ed from a process that initialised HIP; the child is started, not exec'ed into).  The
+    reference has no multi-GPU mode -- it selects ONE device (main_headless.cpp:234-238, opts.cpp:13-14); SURVEY 8e."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+    cmd += list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               RTO_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    print("[bench] --gpus %d without a launcher: starting %d ranks as a child process: %s" % (args.gpus, args.gpus, " ".join(cmd)),
+          file=sys.stderr)
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
+
+
+def check_world(args):
+    """(rank, world, local_rank) from the launcher's environment; a launcher whose WORLD_SIZE differs from --gpus is
+    refused (N = 1 included: `--gpus 8` inside a 1-rank launcher must not print a one-GPU line as if it were 8)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %s: start bench.py with --gpus equal to the number of ranks "
+                         "(or without a launcher: it starts its own ranks)" % (args.gpus, os.environ.get("WORLD_SIZE", "unset")))
+    return rank, world, int(os.environ.get("LOCAL_RANK", "0"))
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     if args.plan_only:
         return plan_only(args)
     import torch
@@ -247,17 +283,17 @@ def main():
     import rt_octree_amd as R
     from rt_octree_amd import denoiser, synth
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the render path has no CPU fallback")
+    rank, world, local_rank = check_world(args)
     # one rank per GPU; RTO_BENCH_BACKEND=gloo lets several ranks share one GPU to smoke-test the
     # multi-process control flow on a single-GPU box (RCCL refuses two ranks on one device)
     backend = os.environ.get("RTO_BENCH_BACKEND", "nccl")
-    local_rank = local_rank % torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()  # (counting devices does not initialise HIP)
+    if n_dev < 1 or not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the render path has no CPU fallback")
+    if world > n_dev and backend == "nccl":
+        raise SystemExit("--gpus %d but this node shows %d GPU(s): one rank per GPU over RCCL (RTO_BENCH_BACKEND=gloo lets "
+                         "ranks share a GPU for a control-flow smoke test only)" % (world, n_dev))
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -524,6 +560,7 @@ def main():
                     same = bool(np.array_equal(ctx.download_rgba8(noisy=denoise, stream=stream), frames_g[other]))
                 nbytes = sum(f.nbytes for f in frames_g)
                 gather = {"frames": len(frames_g), "bytes": nbytes, "seconds": tg, "backend": backend,
+                          "world": dist.get_world_size(), "ranks_on_distinct_gpus": bool(world <= n_dev),
                           "frame_of_rank_1_rendered_on_rank_0_is_identical": same,
                           "note": "sharding.gather_frames: one padded all_gather of uint8 [K,H,W,4] per rank (host -> device -> "
                                   "RCCL -> host, untimed plumbing); the timed region has no collective"}
@@ -926,6 +963,9 @@ def main():
             "frames_per_step": B, "frames_timed": total_frames, "frames_per_launch": frames_per_launch, "streams": len(lanes),
             "scenes": n_scenes, "scene_map": maps[0], "filter": "exact" if args.exact_filter else "factorised", "maps": "fp16 packed" if packed_route else "fp32 planes",
             "parallelism": "frames x%d" % world,
+            "world": world, "backend": (backend if world > 1 else None), "gpus_visible": n_dev,
+            "launcher": ("none" if world == 1 else "bench.py itself (child torch.distributed.run)"
+                         if os.environ.get("RTO_BENCH_SELF_LAUNCHED") else "external (torchrun)"),
         },
         "reference_timer": {  # Timer::report formula (render_context.hpp:190-206), rank 0, per frame
             "render_ms": tstats["render_ms"], "torch_ms": tstats["torch_ms"], "filter_ms": tstats["filter_ms"],

@@ -225,6 +225,13 @@ int rto_ctx_kernel_timing_read3(rto_ctx* c, float* raygen_ms, float* traverse_ms
  * root-restart walk visits, distinct hit leaves, rays with a hit}.  Never enable it in a timed run. */
 int rto_ctx_enable_stats(rto_ctx* c, int enable);
 int rto_ctx_get_stats(rto_ctx* c, void* stream, uint64_t out[6], int reset);
+/* enable = 2: additionally count the frame as the BATCHED path works through it (round 4: the figure above prices a
+ * root-restart walk of every ray, rt_core.cuh:241-270 + n3tree_query.hpp:22-47, which the batched kernels do not perform).
+ * The caller renders frames with rto_launch_renderer_batch, selects a slot and re-renders that slot's pose (same RNG) with
+ * rto_launch_renderer: rays of tiles the batched launch culled are left out, and a node visit counts as the one load
+ * render_persist issues for it.  out = {rays of marked tiles, their march steps, top-grid entries loaded (8 B each),
+ * traversal-image words loaded (4 B each), hit entries written (4 B each), rays of marked tiles that entered the volume}. */
+int rto_ctx_get_march_stats(rto_ctx* c, void* stream, uint64_t out[6], int reset);
 
 /* ---- the operator ---- */
 /* launch_renderer(tree, cam, options, ctx, stream, offscreen=true) (volrend.cu:236-285).

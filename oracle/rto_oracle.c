@@ -620,6 +620,7 @@ static int filter_core(int L, int H, int W, const float* weight, const float* gu
     if (L < 1 || L > 6) return -4; /* kernel_apply :338-367 supports SUPPORT 1..6 */
 #ifdef _OPENMP
     if (num_threads <= 0) num_threads = omp_get_max_threads();
+    if (num_threads > (H + 3) / 4) num_threads = (H + 3) / 4; /* no more threads than chunks of rows */
 #else
     num_threads = 1;
 #endif
@@ -627,7 +628,9 @@ static int filter_core(int L, int H, int W, const float* weight, const float* gu
         const int S = level + 1;
         const float* g = guidance + (int64_t)level * H * W;
         const float* wm = weight + (int64_t)level * H * W;
-#pragma omp parallel for schedule(static) num_threads(num_threads)
+        /* (rows are dealt out dynamically, four at a time: with a static split of 800 rows over 256 threads one late thread
+         *  holds up every level -- bench.py's cpu_baseline timed this leg at single-core speed on the 256-core box) */
+#pragma omp parallel for schedule(dynamic, 4) num_threads(num_threads)
         for (int iy = 0; iy < H; ++iy) {
             for (int ix = 0; ix < W; ++ix) {
                 float max_val = -FLT_MAX; /* :175-180 */

@@ -89,6 +89,7 @@ SYMBOLS = {
     "rto_ctx_kernel_timing_read3": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "rto_ctx_enable_stats": (C.c_int, [_P, C.c_int]),
     "rto_ctx_get_stats": (C.c_int, [_P, _P, C.POINTER(C.c_uint64), C.c_int]),
+    "rto_ctx_get_march_stats": (C.c_int, [_P, _P, C.POINTER(C.c_uint64), C.c_int]),
     "rto_launch_renderer": (C.c_int, [_P, C.POINTER(CCamera), C.POINTER(COptions), _P, _P]),
     "rto_launch_renderer_batch": (C.c_int, [_P, C.POINTER(CCamera), C.POINTER(C.c_int64), C.c_int, C.POINTER(COptions), _P, _P]),
     "rto_filtering_batch": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),

@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
     float dir[3], vdir[3], cen[3], invdir[3];
     ray_setup(x, y, cam, tree, dir, vdir, cen);
     float delta_scale, tmin, tmax;
-    unsigned long long st_steps = 0, st_levels = 0, st_hits = 0, st_inbox = 0;
+    unsigned long long st_steps = 0, st_levels = 0, st_hits = 0, st_inbox = 0, st_grid = 0, st_words = 0;
     if (ray_enter(tree, opt, dir, cen, 1e9f, invdir, delta_scale, tmin, tmax)) {
         if (STATS) st_inbox = 1;
         Pcg32 rng = rng_base;
@@ -616,6 +616,7 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
                 node = slot >> 3;
                 w = e.y;
                 have_w = true;
+                if (STATS) ++st_grid;
             } else {
                 node = lvl ? stack[lvl * 256] : 0u;
             }
@@ -625,6 +626,7 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
                     const uint32_t ci = (((ix >> sh) & 1u) << 2) | (((iy >> sh) & 1u) << 1) | ((iz >> sh) & 1u);
                     slot = node * 8u + ci;
                     w = tree.nodew[slot];
+                    if (STATS) ++st_words;
                 }
                 have_w = false;
                 if (nodew_is_leaf(w)) break;
@@ -709,6 +711,21 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
         atomicAdd(fo.stats + 3, st_levels);
         atomicAdd(fo.stats + 4, st_hits);
         atomicAdd(fo.stats + 5, st_hits ? 1ULL : 0ULL);
+        // the same ray as the batched path sees it: marched only if its 8x8 tile is marked (mark_tiles_kernel); one
+        // top-grid entry or one traversal-image word per node visit is exactly what render_persist loads (same restart rule)
+        bool marched = true;
+        if (fo.stat_marks) {
+            const uint32_t t = (uint32_t)(y >> 3) * ((uint32_t)(cam.width + 7) >> 3) + (uint32_t)(x >> 3);
+            marched = ((fo.stat_marks[t >> 5] >> (t & 31u)) | fo.stat_marks[fo.stat_mask_words - 1]) & 1u;
+        }
+        if (marched) {
+            atomicAdd(fo.stats + 6, 1ULL);
+            atomicAdd(fo.stats + 7, st_steps);
+            atomicAdd(fo.stats + 8, st_grid);
+            atomicAdd(fo.stats + 9, st_words);
+            atomicAdd(fo.stats + 10, st_hits);
+            atomicAdd(fo.stats + 11, st_inbox);
+        }
     }
 }
 
@@ -1788,11 +1805,17 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
     const void* fn = reinterpret_cast<const void*>(&render_persist<SPP, REFILL, WPS>);
     OccupancyCache local;
     if (!occ) occ = &local;
+    occ->lds_refused = false;
+    if (occ->force_lds_refusal) {
+        occ->lds_refused = true;
+        return hipSuccess;
+    }
     if (occ->blocks_per_cu == 0 || occ->fn != fn || occ->lds != lds) {
         if (lds > 64 * 1024) {  // beyond the default dynamic-LDS window: ask for it (the CU has 160 KB)
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
                 (void)hipGetLastError();
-                return hipErrorInvalidConfiguration;  // the caller reports it (deep tree x SPP 32) and takes the generic kernel
+                occ->lds_refused = true;  // (deep tree x SPP 32 x many frames) nothing launched: the caller takes the generic kernel
+                return hipSuccess;
             }
         }
         int nb = 0;

@@ -127,6 +127,7 @@ struct rto_ctx {
     bool frame_via_batch = false;
     int last_n_queues = 0;                // of the last batched launch (rto_ctx_queue_stats)
     int64_t last_slots = 0;
+    int batch_fallback = 0;               // tuning / test hook, see rto_ctx_set_tuning
     int marks_n = 0, marks_slot0 = 0;     // frames whose tile marks the last launch left in tile_mask (0: none), their first slot
     float marks_bg = 0.f;                 // ... and the background brightness of that launch
     // per-kernel event timing of the batched path (off by default)
@@ -146,7 +147,8 @@ struct rto_ctx {
     int refill = 0;  // 0 = the default instantiation; 100 * waves/SIMD + idle-lane threshold picks an A/B one
     bool tile_order_on = true;
     bool stats_on = false;
-    unsigned long long* stats = nullptr;  // device, 6 counters
+    bool stats_marks = false;             // rto_ctx_enable_stats(2): count against the tile marks of the last batched launch
+    unsigned long long* stats = nullptr;  // device, rto::kStatsWords counters
     // Timer (render_context.hpp:122-213)
     hipStream_t t_stream = nullptr;
     hipEvent_t t_start[3] = {nullptr, nullptr, nullptr}, t_stop[3] = {nullptr, nullptr, nullptr};
@@ -1098,6 +1100,8 @@ int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value) {
     } else if (k == "blocks_per_cu") {  // occupancy of the persistent traversal kernel: 0 = what fits, else a cap (1..8)
         if (value < 0 || value > 8) return set_err(RTO_E_INVALID, "blocks_per_cu must be 0..8");
         c->occ.cap = value;
+    } else if (k == "batch_fallback") {  // test hook: 1 = batched launches take the per-frame generic fallback (as a tree with too
+        c->batch_fallback = value;       // many leaf slots for the SPP does), 2 = as if the device refused the traversal kernel's LDS
     } else if (k == "strip_rows") {
         if (value < 1) return set_err(RTO_E_INVALID, "strip_rows must be >= 1");
         c->strip_rows = value;
@@ -1176,10 +1180,22 @@ int rto_ctx_enable_stats(rto_ctx* c, int enable) {
     if (!c) return set_err(RTO_E_INVALID, "rto_ctx_enable_stats: null context");
     DeviceGuard guard(c->device);
     if (enable && !c->stats) {
-        HIP_TRY(hipMalloc((void**)&c->stats, 6 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(c->stats, 0, 6 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void**)&c->stats, rto::kStatsWords * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(c->stats, 0, rto::kStatsWords * sizeof(unsigned long long)));
     }
     c->stats_on = enable != 0;
+    c->stats_marks = enable == 2;
+    return RTO_OK;
+}
+
+int rto_ctx_get_march_stats(rto_ctx* c, void* stream_, uint64_t out[6], int reset) {
+    if (!c || !out) return set_err(RTO_E_INVALID, "rto_ctx_get_march_stats: null argument");
+    if (!c->stats) return set_err(RTO_E_INVALID, "rto_ctx_get_march_stats: counters were never enabled");
+    DeviceGuard guard(c->device);
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipMemcpyAsync(out, c->stats + 6, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    if (reset) HIP_TRY(hipMemsetAsync(c->stats + 6, 0, 6 * sizeof(uint64_t), stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     return RTO_OK;
 }
 
@@ -1251,12 +1267,22 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
     fo.aux = rto_ctx_aux(ctx);
     fo.image = o->denoise ? rto_ctx_noisy(ctx) : rto_ctx_image(ctx);  // volrend.cu:206
     fo.stats = nullptr;
+    fo.stat_marks = nullptr;
+    fo.stat_mask_words = 0;
+    bool keep_marks = false;
     if (ctx->stats_on) {
         if (kernel != RTO_KERNEL_FAST) return set_err(RTO_E_UNSUPPORTED, "work counters need the fast kernel");
         fo.stats = ctx->stats;
+        if (ctx->stats_marks) {  // the selected slot's marks of the last batched launch (the caller re-renders that frame)
+            if (ctx->marks_n < 1 || !ctx->tile_mask || ctx->sel < ctx->marks_slot0 || ctx->sel >= ctx->marks_slot0 + ctx->marks_n)
+                return set_err(RTO_E_INVALID, "rto_ctx_enable_stats(2): the selected frame slot holds no tile marks of a batched launch");
+            fo.stat_marks = ctx->tile_mask + (size_t)(ctx->sel - ctx->marks_slot0) * ctx->mask_words;
+            fo.stat_mask_words = ctx->mask_words;
+            keep_marks = true;  // (the counting launch re-renders the frame the marks describe)
+        }
     }
 
-    ctx->marks_n = 0;  // (the per-frame kernels mark no tiles)
+    if (!keep_marks) ctx->marks_n = 0;  // (the per-frame kernels mark no tiles)
     hipError_t e = rto::launch_render(kernel, o->spp, tree->dev, cd, od, ctx->rng, ctx->jump, fo, ctx->strip_rows, stream);
     if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("render launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
@@ -1265,6 +1291,50 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
 int rto_launch_renderer_batch(const rto_tree* tree, const rto_camera* cams, const int64_t* rng_jumps, int n,
                               const rto_options* o, rto_ctx* ctx, void* stream_) {
     return launch_batch_at(tree, cams, rng_jumps, n, o, ctx, stream_, 0);
+}
+
+// The frames of a batched call rendered one by one with the generic kernel (render_generic: any N, any depth, any slot
+// count): what rto_launch_renderer_batch does for a tree the batched kernels cannot take.  The generic kernel reads the
+// reference arrays child[] / data[], which a dense SH9 / SH16 upload released: they are rebuilt first.
+// No tile marks exist afterwards (marks_n stays 0: the denoise stage must not fill "culled" tiles from an older launch).
+static int generic_frames(const rto_tree* tree, const rto_camera* cams, const int64_t* rng_jumps, int n, const rto_options* o,
+                          rto_ctx* ctx, void* stream_, int slot0) {
+    ctx->marks_n = 0;
+    if (tree->quant)
+        return set_err(RTO_E_UNSUPPORTED, "a quantised tree kept quantised cannot take the generic kernel (too many leaf slots for the "
+                                          "batched kernels at this spp, or the traversal kernel's LDS was refused)");
+    int rc = ensure_reference_arrays(tree);
+    if (rc != RTO_OK) return rc;
+    const rto::OptDev od = make_opt_dev(o);
+    const size_t px = frame_px(ctx);
+    for (int f = 0; f < n; ++f) {
+        if (cams[f].width != ctx->width || cams[f].height != ctx->height)
+            return set_err(RTO_E_INVALID, "camera size does not match the render context");
+        if (!(cams[f].fx != 0.f) || !(cams[f].fy != 0.f)) return set_err(RTO_E_INVALID, "camera focal length is zero");
+    }
+    for (int f = 0; f < n; ++f) {
+        rto::CamDev cd;
+        cd.width = cams[f].width;
+        cd.height = cams[f].height;
+        cd.fx = cams[f].fx;
+        cd.fy = cams[f].fy;
+        std::memcpy(cd.transform, cams[f].transform, sizeof(cd.transform));
+        const int64_t jumps = rng_jumps ? rng_jumps[f] : (int64_t)f;
+        const rto::PcgJumpEntry j = pcg_jump(ctx->rng.inc, (uint64_t)jumps << 32);
+        rto::Pcg32 rng = ctx->rng;
+        rng.state = j.mult * ctx->rng.state + j.plus;
+        const size_t slot = (size_t)(slot0 + f);
+        rto::FrameOut fo;
+        fo.aux = ctx->aux + slot * RTO_AUX_CHANNELS * px;
+        fo.image = (o->denoise ? ctx->noisy : ctx->image) + slot * 4 * px;
+        fo.stats = nullptr;
+        fo.stat_marks = nullptr;
+        fo.stat_mask_words = 0;
+        hipError_t e = rto::launch_render(RTO_KERNEL_GENERIC, o->spp, tree->dev, cd, od, rng, ctx->jump, fo, ctx->strip_rows,
+                                          (hipStream_t)stream_);
+        if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("render launch failed: ") + hipGetErrorString(e));
+    }
+    return RTO_OK;
 }
 
 // frames 0..n-1 of the batch land in context slots slot0..slot0+n-1
@@ -1284,38 +1354,12 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
         return set_err(RTO_E_UNSUPPORTED, "SG/ASG bases are untested upstream and not built");
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");
-    if (!tree->fast_ok || !slots_fit_spp(tree->info.capacity * tree->dev.N3, o->spp)) {
+    ctx->marks_n = 0;  // whatever happens below, the tile marks of an earlier launch no longer describe this context's frames
+    if (!tree->fast_ok || !slots_fit_spp(tree->info.capacity * tree->dev.N3, o->spp) || ctx->batch_fallback == 1) {
         // No traversal image (N != 2, depth > 24, >= 2^29 leaf slots: the top-grid entry's budget) or more slots than a
         // hit-list entry can name at this SPP (2^28 at spp <= 8, 2^26 at spp 32): the same frames, one launch of the
         // generic kernel each -- same images, without the batching gain.
-        if (tree->quant)
-            return set_err(RTO_E_UNSUPPORTED, "a quantised tree kept quantised has too many leaf slots for the batched kernels at this spp");
-        const rto::OptDev od = make_opt_dev(o);
-        const size_t px = frame_px(ctx);
-        for (int f = 0; f < n; ++f) {
-            if (cams[f].width != ctx->width || cams[f].height != ctx->height)
-                return set_err(RTO_E_INVALID, "camera size does not match the render context");
-            if (!(cams[f].fx != 0.f) || !(cams[f].fy != 0.f)) return set_err(RTO_E_INVALID, "camera focal length is zero");
-            rto::CamDev cd;
-            cd.width = cams[f].width;
-            cd.height = cams[f].height;
-            cd.fx = cams[f].fx;
-            cd.fy = cams[f].fy;
-            std::memcpy(cd.transform, cams[f].transform, sizeof(cd.transform));
-            const int64_t jumps = rng_jumps ? rng_jumps[f] : (int64_t)f;
-            const rto::PcgJumpEntry j = pcg_jump(ctx->rng.inc, (uint64_t)jumps << 32);
-            rto::Pcg32 rng = ctx->rng;
-            rng.state = j.mult * ctx->rng.state + j.plus;
-            const size_t slot = (size_t)(slot0 + f);
-            rto::FrameOut fo;
-            fo.aux = ctx->aux + slot * RTO_AUX_CHANNELS * px;
-            fo.image = (o->denoise ? ctx->noisy : ctx->image) + slot * 4 * px;
-            fo.stats = nullptr;
-            hipError_t e = rto::launch_render(RTO_KERNEL_GENERIC, o->spp, tree->dev, cd, od, rng, ctx->jump, fo,
-                                              ctx->strip_rows, (hipStream_t)stream_);
-            if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("render launch failed: ") + hipGetErrorString(e));
-        }
-        return RTO_OK;
+        return generic_frames(tree, cams, rng_jumps, n, o, ctx, stream_, slot0);
     }
     // the traversal kernel addresses the hand-off buffer with 32-bit offsets (frame * spp * pixels + pixel)
     if ((uint64_t)(slot0 + n) * (uint64_t)o->spp * (uint64_t)frame_px(ctx) > 0xffffffffULL)
@@ -1413,16 +1457,16 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     HIP_TRY(rto::launch_write_frames(frames, n, ctx->d_frames, stream));
     hipEvent_t* ev = nullptr;
     if (ctx->kt_on && ctx->kt_count < kKtRing) ev = &ctx->kt_ev[(size_t)ctx->kt_count++ * 4];
-    ctx->marks_n = 0;
+    ctx->occ.force_lds_refusal = ctx->batch_fallback == 2;
     hipError_t e = rto::launch_render_batch(o->spp, tree->dev, od, fb, ctx->jump, ctx->queue,
                                             ctx->hits + (size_t)slot0 * o->spp * px,  // = fb.f[0].hits: the kernel indexes frames from here
                                             ctx->num_cus, ctx->refill, cull, &ctx->occ, ev, stream);
-    if (e == hipErrorInvalidConfiguration)
-        return set_err(RTO_E_UNSUPPORTED, "batched render: the traversal kernel needs (max_depth + 1 - top_levels + spp + 1) KB of LDS for its "
-                                          "ancestor stack and thresholds plus 96 B per frame -- depth " + std::to_string(tree->dev.max_depth) +
-                                          " at spp " + std::to_string(o->spp) + " with " + std::to_string(n) +
-                                          " frames exceeds what the device grants a workgroup; render fewer samples per launch or "
-                                          "frame by frame with the generic kernel (rto_ctx_set_kernel)");
+    if (ctx->occ.lds_refused) {
+        // the device does not grant a workgroup the LDS the traversal kernel needs for this depth x SPP x frame count
+        // ((max_depth + 1 - top_levels + spp + 1) KB for the ancestor stack and thresholds + 56 B per frame); nothing but
+        // the frame table was written so far: the same frames through the generic kernel, frame by frame
+        return generic_frames(tree, cams, rng_jumps, n, o, ctx, stream_, slot0);
+    }
     if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("batched render launch failed: ") + hipGetErrorString(e));
     ctx->marks_n = n;
     ctx->marks_slot0 = slot0;

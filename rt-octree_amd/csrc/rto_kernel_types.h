@@ -150,7 +150,16 @@ struct FrameChunk {
 struct FrameOut {
     float* aux;    // [8][H][W]
     float* image;  // [H][W][4]: noisy image when opt.denoise, else final (volrend.cu:206)
-    unsigned long long* stats;  // nullptr, or 6 counters (fast kernel, stats instantiation)
+    unsigned long long* stats;  // nullptr, or kStatsWords counters (fast kernel, stats instantiation)
+    // stats only: the tile marks of THIS frame left by a batched launch (nullptr: every tile counts as marched) -- the
+    // counting kernel then also reports the work of the rays the batched path really marches (stats[6..])
+    const uint32_t* stat_marks;
+    int stat_mask_words;
 };
+// stats[0..5] = SURVEY 8d's units over EVERY ray (orc_stats order: rays, rays_in_box, steps, levels of a root-restart walk,
+// hit leaves, rays with a hit); stats[6..11] = the same frame as the batched path works through it: rays of marked tiles,
+// their march steps, top-grid entries loaded (8 B each), traversal-image words loaded (4 B each), hit entries written,
+// rays of marked tiles that entered the volume
+constexpr int kStatsWords = 12;
 
 }  // namespace rto

@@ -37,6 +37,10 @@ struct OccupancyCache {
     size_t lds = 0;
     int blocks_per_cu = 0;
     int cap = 0;  // tuning ("blocks_per_cu"): launch at most this many workgroups per CU (0 = what fits)
+    // out: the device refused the dynamic LDS this launch needs (hipFuncSetAttribute failed); NOTHING was launched and
+    // launch_render_batch returned hipSuccess -- the caller renders the frames with the generic kernel instead
+    bool lds_refused = false;
+    bool force_lds_refusal = false;  // test hook
 };
 
 // persistent batched renderer (N == 2 trees): fb.n frames in one launch (traversal kernel, then the

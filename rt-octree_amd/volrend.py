@@ -351,9 +351,16 @@ class RenderContext:
             return None
         return p.value, w.value, s0.value, n.value, bg.value
 
-    def enable_stats(self, on=True):
-        """Work counters for the roofline's algorithmic byte count (never in a timed run)."""
-        check(lib().rto_ctx_enable_stats(self._h, int(bool(on))))
+    def enable_stats(self, on=True, marched=False):
+        """Work counters for the roofline's algorithmic byte count (never in a timed run).  marched: also count the frame as
+        the batched path works through it (get_march_stats) -- select a slot of the last batched launch and re-render its pose."""
+        check(lib().rto_ctx_enable_stats(self._h, 2 if (on and marched) else int(bool(on))))
+
+    def get_march_stats(self, reset=True, stream=None):
+        out = (C.c_uint64 * 6)()
+        check(lib().rto_ctx_get_march_stats(self._h, _stream_ptr(stream), out, int(bool(reset))))
+        keys = ("rays", "steps", "grid_loads", "node_loads", "hit_entries", "rays_in_box")
+        return {k: int(out[i]) for i, k in enumerate(keys)}
 
     def get_stats(self, reset=True, stream=None):
         out = (C.c_uint64 * 6)()

@@ -32,8 +32,17 @@ def test_bench_line_has_the_contract_fields():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert rf["traffic"] is None and "ALGORITHMIC" in rf["basis"]  # counter passes exist for the BASELINE workloads only
-    for k in ("algorithmic_gbps", "algorithmic_frac", "avg_launch_ms", "frames_per_launch", "tcp"):
+    for k in ("algorithmic_marched_gbps", "algorithmic_marched_frac", "algorithmic_marched_render_frac", "survey_8d_every_ray_gbps",
+              "avg_launch_ms", "frames_per_launch", "tcp"):
         assert k in rf, k
+    # VERDICT r3 task 2: a roofline fraction describes the work the timed kernel does, so it cannot exceed 1; without a
+    # counter pass the line falls back to the MARCHED figure (never to the every-ray root-restart one, which may)
+    assert 0 < rf["frac"] <= 1 and 0 < rf["algorithmic_marched_frac"] <= 1 and 0 < rf["algorithmic_marched_render_frac"] <= 1
+    assert abs(rf["achieved"] - rf["algorithmic_marched_gbps"]) < 1e-9 * rf["achieved"]
+    mu, eu = rf["marched_units_per_frame"], rf["units_per_frame"]
+    assert 0 < mu["rays"] <= eu["rays"] and 0 < mu["steps"] <= eu["steps"] and mu["hit_entries"] == eu["hit_leaves"]
+    assert mu["tiles_marked"] <= mu["tiles"] and 1.0 <= mu["loads_per_step"] < 4.0
+    assert mu["grid_loads"] + mu["node_loads"] < eu["levels"]  # fewer loads than a root-restart walk has levels
     assert d["config"]["frames_per_launch"] == rf["frames_per_launch"] == 4.0  # the actual value
     rl = d["reference_loop"]
     assert rl["batch"] == 1 and rl["fps"] > 0 and rl["render_ms"] > 0 and rl["fps"] < d["reference_timer"]["fps"] * 1.5

@@ -110,3 +110,57 @@ def test_a_tree_without_density_renders_the_background_without_marching():
     (frame,), (live, total) = _render(dt, [cam], 6, True, ctx, [0])
     assert live == 0 and total == 8 * 6
     assert np.all(frame[0][:3] == 1.0) and np.all(frame[0][3] == 0.0) and np.all(frame[1][..., :3] == 1.0)
+
+
+def test_march_counters_count_the_batched_paths_own_work():
+    """bench.py's `roofline.algorithmic_marched_*` (VERDICT r3 task 2): the counting kernel, given the tile marks of a
+    batched launch, reports the work of the rays the batched path marches -- a subset of SURVEY 8d's every-ray units with
+    the SAME hit entries (a culled ray meets no density), one load per node visit instead of a root-restart walk; with the
+    culling off the two descriptions cover the same rays."""
+    tree = synth.make_tree(depth_limit=8, basis_dim=9, seed=21, shell=2.0)
+    ht, dt = make_pair(tree)
+    W, H = 200, 136
+    cams = []
+    for p in list(synth.orbit_poses(4)):
+        c = R.Camera(W, H, 260.0, 260.0)
+        c.set_c2w(p)
+        cams.append(c)
+    ctx = R.RenderContext(W, H, frames=len(cams))
+    opt = R.RenderOptions(spp=6, denoise=False)
+    res = {}
+    for cull in (1, 0):
+        ctx.set_tuning("cull", cull)
+        ctx.rng_seed()
+        R.launch_renderer_batch(dt, cams, opt, ctx, rng_jumps=[100 + i for i in range(len(cams))])
+        live, _ = ctx.queue_stats()
+        ctx.set_kernel(R.KERNEL_FAST)
+        ctx.enable_stats(True, marched=True)
+        ctx.get_stats(reset=True)
+        ctx.get_march_stats(reset=True)
+        frames = []
+        for k in range(len(cams)):
+            ctx.select_frame(k)
+            before = ctx.download_aux()
+            ctx.rng_seed()
+            ctx.rng_advance((100 + k) << 32)
+            R.launch_renderer(dt, cams[k], opt, ctx)
+            assert_bits_equal(ctx.download_aux(), before, "the counting launch re-renders the batched frame")
+        assert ctx.tile_marks() is not None  # (a counting launch against the marks keeps them)
+        res[cull] = (ctx.get_stats(), ctx.get_march_stats(), live)
+        ctx.enable_stats(False)
+        ctx.set_kernel(R.KERNEL_AUTO)
+    (ev, mv, live_on), (ev0, mv0, live_off) = res[1], res[0]
+    assert ev == ev0
+    assert mv0["rays"] == ev["rays"] == len(cams) * W * H and mv0["steps"] == ev["steps"] and mv0["rays_in_box"] == ev["rays_in_box"]
+    assert mv["rays"] == 64 * live_on < mv0["rays"]  # (200 x 136 is a whole number of 8x8 tiles)
+    assert 0 < mv["steps"] < ev["steps"] and mv["hit_entries"] == mv0["hit_entries"] == ev["hit_leaves"] > 0
+    for m in (mv, mv0):
+        loads = m["grid_loads"] + m["node_loads"]
+        assert m["steps"] <= loads < 3 * m["steps"] and m["grid_loads"] > 0 and m["node_loads"] > 0
+    assert mv0["grid_loads"] + mv0["node_loads"] < ev["levels"]  # a root-restart walk visits more levels than the kernel loads words
+    # without marks in the selected slot the mode refuses instead of counting against stale ones
+    ctx.enable_stats(True, marched=True)
+    one = R.RenderContext(W, H)
+    one.enable_stats(True, marched=True)
+    with pytest.raises(R.RtoError):
+        R.launch_renderer(dt, cams[0], opt, one)

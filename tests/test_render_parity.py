@@ -135,6 +135,47 @@ def test_batched_launch_on_a_tree_without_traversal_image():
     assert aux_o[3].max() > 0
 
 
+@pytest.mark.parametrize("hook", [1, 2])
+def test_batched_fallback_on_a_tree_that_released_its_reference_arrays(hook):
+    """ADVICE r3 (high + medium): the per-frame generic fallback inside rto_launch_renderer_batch -- taken for a tree with
+    more leaf slots than a hit entry can name at the SPP (hook 1) or when the device refuses the traversal kernel's LDS
+    (hook 2) -- on a dense SH tree whose upload RELEASED child[] / data[] (the default): the arrays are rebuilt first
+    (round 3 launched the generic kernel on null pointers), the frames equal the oracle's, and the tile marks of an
+    EARLIER batched launch on the context are gone (the denoise stage would fill "culled" tiles of the new frames)."""
+    tree = synth.make_tree(depth_limit=6, basis_dim=9, seed=77)
+    ht, dt = make_pair(tree)
+    before = dt.device_bytes
+    cams, ocams = [], []
+    for i in range(3):
+        ocam, cam = cameras(64, 48, POSES[i])
+        cams.append(cam)
+        ocams.append(ocam)
+    ctx = R.RenderContext(64, 48, frames=3)
+    opt = R.RenderOptions(spp=4, denoise=False)
+    R.launch_renderer_batch(dt, cams, opt, ctx, rng_jumps=[2, 0, 5])  # the batched kernels: marks exist
+    assert ctx.tile_marks() is not None and ctx.tile_marks()[3] == 3
+    dt._refresh()
+    assert dt.device_bytes == before
+    fast = []
+    for i in range(3):
+        ctx.select_frame(i)
+        fast.append(ctx.download_aux())
+    ctx.set_tuning("batch_fallback", hook)
+    R.launch_renderer_batch(dt, cams, opt, ctx, rng_jumps=[2, 0, 5])
+    assert ctx.tile_marks() is None  # stale marks must not survive
+    dt._refresh()
+    assert dt.device_bytes >= before + tree.data.nbytes + tree.child.nbytes  # the generic kernel's arrays came back
+    for i, j in enumerate([2, 0, 5]):
+        aux_o, rgba_o, _ = oracle_frame(ht, ocams[i], 4, frame=j)
+        ctx.select_frame(i)
+        assert_bits_equal(ctx.download_aux(), aux_o, "fallback aux %d" % i)
+        assert_bits_equal(ctx.download_image(), rgba_o, "fallback rgba %d" % i)
+        assert_bits_equal(fast[i], aux_o, "batched aux %d" % i)
+    ctx.set_tuning("batch_fallback", 0)
+    R.launch_renderer_batch(dt, cams, opt, ctx, rng_jumps=[2, 0, 5])
+    assert ctx.tile_marks() is not None
+
+
 @pytest.mark.parametrize("depth,basis", [(1, 4), (2, 4), (3, 9), (8, 9)])
 def test_batched_path_on_shallow_and_deep_trees(depth, basis):
     """no top grid (depth < 3), a shallow grid, a deeper tree; SPP 1 and 32; a negative sigma_thresh makes even

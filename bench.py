@@ -84,6 +84,9 @@ def parse_args(argv=None):
     ap.add_argument("--ref-loop-inflight", type=int, default=4,
                     help="frames in flight in the pipelined variant of the reference loop (1 = skip it)")
     ap.add_argument("--spot-pixels", type=int, default=64, help="oracle spot pixels per checked frame of the last timed group (0 = skip)")
+    ap.add_argument("--count-frames", type=int, default=64,
+                    help="frames of the untimed work-unit count behind the algorithmic figures (0 = skip: profiling runs, whose "
+                         "per-kernel counter means must hold the timed launches only)")
     ap.add_argument("--no-exact-pass", action="store_true", help="skip the second timed pass through the bit-exact filter route")
     ap.add_argument("--tree", default="", help="render this tree.npz instead of the synthetic one")
     ap.add_argument("--shuffle-nodes", type=int, default=0, metavar="SEED",
@@ -684,9 +687,9 @@ def main():
     ctx.get_stats(reset=True)
     ctx.get_march_stats(reset=True)
     opt_nd = R.RenderOptions(spp=args.spp, denoise=False)
-    count_steps = min(n_frames, 64)  # per-frame means need no more
+    count_steps = max(0, min(n_frames, args.count_frames))  # per-frame means need no more
     marked_tiles = all_tiles = 0
-    for sc, idx in plan(count_steps, maps[0]):  # same poses, same RNG bases as the timed frames
+    for sc, idx in (plan(count_steps, maps[0]) if count_steps else []):  # same poses, same RNG bases as the timed frames
         ctx.rng_seed()
         R.launch_renderer_batch(trees[sc], [cams[i] for i in idx], opt_nd, ctx, stream, rng_jumps=[WARM_FRAMES_REF + i for i in idx])
         lv, al = ctx.queue_stats()
@@ -707,6 +710,8 @@ def main():
     march = ctx.get_march_stats(reset=True)
     ctx.enable_stats(False)
     ctx.select_frame(0)
+    counted = count_steps > 0
+    count_steps = max(count_steps, 1)  # (--count-frames 0: every unit is 0 and the algorithmic figures are reported as null)
     px = W * H
     alg_bytes_frame = (4 * units["levels"] + 2 * units["steps"] + 2 * (tree.data_dim - 1) * units["hit_leaves"]
                        + 48 * px * count_steps) / count_steps
@@ -973,17 +978,21 @@ def main():
     # without a counter pass for this workload the line falls back to the MARCHED algorithmic figure (bytes the kernel has
     # to move for the work it does: <= what any memory system moved), never to the every-ray one (which may exceed the peak)
     use = achieved if achieved is not None else m_trav_gbps
+    if not counted:
+        m_trav_launch = m_trav_gbps = m_render_launch = m_render_gbps = alg_bytes_launch = alg_gbps = None
+        use = achieved
+    frac_of = lambda g: (g / HBM_PEAK_GBS) if g is not None else None
     roof = {
         "kernel": "render_persist<%d>" % args.spp, "bound": "hbm",
-        "achieved": use, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": use / HBM_PEAK_GBS,
+        "achieved": use, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac_of(use),
         "basis": ("counters: FETCH_SIZE + WRITE_SIZE of this workload (profiles/pmc_traffic.json) / this run's launch duration"
                   if achieved is not None else
                   "ALGORITHMIC bytes of the marched work (no counter pass is committed for this workload): see algorithmic_marched_note"),
         "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale, "kernel_code_id": code_id,
         "algorithmic_marched_bytes": m_trav_launch, "algorithmic_marched_gbps": m_trav_gbps,
-        "algorithmic_marched_frac": m_trav_gbps / HBM_PEAK_GBS,
+        "algorithmic_marched_frac": frac_of(m_trav_gbps),
         "algorithmic_marched_render_bytes": m_render_launch, "algorithmic_marched_render_gbps": m_render_gbps,
-        "algorithmic_marched_render_frac": m_render_gbps / HBM_PEAK_GBS,
+        "algorithmic_marched_render_frac": frac_of(m_render_gbps),
         "algorithmic_marched_note": "the work the batched kernels perform, counted on the same frames: rays of the tiles the culling left "
                                     "marked only; per node visit the ONE load render_persist issues (8 B top-grid entry or 4 B traversal-image "
                                     "word); 4 B x SPP thresholds read per marched ray that enters the volume; 4 B per hit entry written; 4 B "
@@ -992,9 +1001,9 @@ def main():
                                     "every tile) over traversal + shading time.  Cache-served re-reads count (algorithmic, not DRAM)",
         "marched_units_per_frame": dict({k: v / count_steps for k, v in march.items()},
                                         tiles_marked=marked_tiles / count_steps, tiles=all_tiles / count_steps,
-                                        loads_per_step=(march["grid_loads"] + march["node_loads"]) / max(march["steps"], 1)),
+                                        loads_per_step=(march["grid_loads"] + march["node_loads"]) / max(march["steps"], 1)) if counted else None,
         "survey_8d_every_ray_bytes_per_launch": alg_bytes_launch, "survey_8d_every_ray_gbps": alg_gbps,
-        "survey_8d_every_ray_over_peak": alg_gbps / HBM_PEAK_GBS,
+        "survey_8d_every_ray_over_peak": frac_of(alg_gbps),
         "survey_8d_note": "root-restart walk, EVERY ray (SURVEY 8d formula: 4 B per level + 2 B per step + SH record per hit leaf + 48 B per "
                           "pixel): the reference's walk priced on this frame.  The kernels here never march the culled rays and skip most "
                           "levels (top grid, ancestor stack), so this is NOT a roofline of the timed kernel and may exceed the peak; kept for "
@@ -1007,7 +1016,7 @@ def main():
         "culling_note": "8x8-pixel tiles that no culling cell of the tree projects into hold only rays that never meet density: they are "
                         "background pixels without marching (bit-identical, tests/test_culling.py); thresholds_kernel_avg_launch_ms "
                         "covers tile marking + queue lists + threshold draws",
-        "units_per_frame": {k: v / count_steps for k, v in units.items()},
+        "units_per_frame": {k: v / count_steps for k, v in units.items()} if counted else None,
         "tcp": tcp,
         "valu": valu,
     }

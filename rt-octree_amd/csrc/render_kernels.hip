@@ -1453,7 +1453,10 @@ hipError_t launch_pack_quant(const uint16_t* qmap, const uint16_t* retained, int
 // the pixel lanes then add their entries' contributions up in hit order, which keeps the float sums
 // those of the reference's loop.  The list is processed in windows of kShadeCap entries so LDS use
 // does not depend on SPP.
-constexpr int kShadeCap = 320;
+#ifndef RTO_SHADE_CAP
+#define RTO_SHADE_CAP 320
+#endif
+constexpr int kShadeCap = RTO_SHADE_CAP;
 
 // contribution of one hit leaf: rgb[c] = cnt * sigmoid(<basis, coeffs_c>) (or cnt * rgb for RGBA trees)
 // MODE (host-chosen, so that each instantiation carries one leaf layout's registers only):

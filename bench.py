@@ -170,6 +170,33 @@ C4_ARGS = ["--width", "1920", "--height", "1080", "--basis", "25", "--depth", "1
            "--cam-radius", "2.6"]
 
 
+def usable_cores():
+    """CPU cores this process may actually use: the affinity mask, capped by the cgroup's CPU quota.  (The GPU boxes show
+    256 logical CPUs and a quota of 16: a team of 256 OpenMP threads is then throttled to a fraction of one core each --
+    rounds 1-3 quoted "256 cores" for a baseline that ran at single-core speed.)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = min(n, max(1, int(quota)))
+    return max(1, n)
+
+
 def n_poses_for(world):
     """Poses of the synthetic orbit.  One GPU renders the reference's 200-pose test trajectory; N ranks render an orbit N
     times as dense, frame g -> pose g -> rank g mod N: every rank's launch groups then hold DISTINCT poses at the angular
@@ -254,7 +281,7 @@ def self_launch(args, argv=None):
     cmd += list(sys.argv[1:] if argv is None else argv)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                RTO_BENCH_SELF_LAUNCHED="1")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // args.gpus)))
     print("[bench] --gpus %d without a launcher: starting %d ranks as a child process: %s" % (args.gpus, args.gpus, " ".join(cmd)),
           file=sys.stderr)
     sys.stderr.flush()
@@ -647,17 +674,23 @@ def main():
             done = [torch.cuda.Event() for _ in range(D)]
             npipe = max(nf, 4 * D)
             t0p = None
+            host_wait = host_issue = 0.0
             for k in range(-2 * D, npipe):
                 if k == 0:
                     torch.cuda.synchronize(dev)
                     t0p = time.perf_counter()
                 ln = k % D
+                tw0 = time.perf_counter()
                 if k >= -D:
                     done[ln].synchronize()  # the host waits for the frame this lane rendered D frames ago
+                tw1 = time.perf_counter()
                 sc, i = frame_of(max(k, 0) % max(nf, 1), maps[0])
                 lc, ls, lnn, la = plane[ln]
                 one_frame(lc, ls, lnn, la, sc, i)
                 done[ln].record(ls)
+                if k >= 0:
+                    host_wait += tw1 - tw0
+                    host_issue += time.perf_counter() - tw1
             torch.cuda.synchronize(dev)
             wall = time.perf_counter() - t0p
             last_ln = (npipe - 1) % D
@@ -667,6 +700,7 @@ def main():
             if i_last == i_seq:
                 same = bool(np.array_equal(plane[last_ln][0].download_image().view(np.uint32), seq_last.view(np.uint32)))
             ref_loop["pipelined"] = {"frames_in_flight": D, "frames": npipe, "wall_fps": npipe / wall,
+                                     "host_issue_ms_per_frame": host_issue / npipe * 1e3, "host_wait_ms_per_frame": host_wait / npipe * 1e3,
                                      "last_frame_bit_identical_to_the_sequential_loop": same,
                                      "note": "same operator calls per frame; lane k mod D = its own context + stream; the host waits for "
                                              "frame k - D before launching frame k"}
@@ -836,7 +870,7 @@ def main():
         else:
             child, data, scale, offset, fmt = tree_host.child, tree_host.data, tree_host.scale, tree_host.offset, tree_host.data_format
         ht = orc.HostTree(child, data, scale, offset, fmt)
-        cores = args.cpu_threads or (os.cpu_count() or 1)
+        cores = args.cpu_threads or usable_cores()
         oopt = orc.default_options(spp=args.spp, denoise=int(denoise))
         cpu_net = denoiser.GuidanceNetCompact.from_full(full).float() if denoise else None
         # One thread pool at a time: the three legs run one after the other over all sample frames --
@@ -894,6 +928,7 @@ def main():
                          % (nf_cpu, W, H, args.spp, nf_cpu - 1,
                             " + fp32 PyTorch-CPU GuidanceNet + oracle filter" if denoise else ""),
                "threads_per_leg": {"render": cores, "net": net_threads, "filter": filter_threads},
+               "logical_cpus_visible": os.cpu_count(), "cores_note": "cores = min(affinity mask, cgroup CPU quota): what the box grants this process",
                "render_s_per_frame": t_render / nf_cpu, "net_s_per_frame": t_net / nf_cpu,
                "filter_s_per_frame": t_filter / nf_cpu, "steps_per_frame": cpu_steps / nf_cpu}
 

@@ -1062,7 +1062,18 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     uint32_t* const stack_g = stack - G * 256;  // indexed by node level (only ever with levels >= G)
 
 #ifdef RTO_DBG_COUNTERS
-    unsigned dbg_wave_steps = 0, dbg_lane_steps = 0, dbg_lane_loads = 0, dbg_lane_leafs = 0, dbg_refills = 0, dbg_refilled = 0;
+    // per-branch occupancy of the march loop (tools/dbg_counters.py): for each branch, how many wave-level executions and
+    // how many lanes took part.  0 iteration (any active lane), 1 descend, 2 leaf (march step), 3 sigma > thresh,
+    // 4 hit (threshold crossed), 5 restart (ray goes on), 6 ray set-up (refill round), 7 grid lookups
+    unsigned dbg_w[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RTO_DBG_AT(i)                                                                                          \
+    {                                                                                                          \
+        const unsigned long long m_ = __builtin_amdgcn_ballot_w64(true);                                      \
+        ++dbg_l[i];                                                                                            \
+        if ((tid & 63) == __ffsll((long long)m_) - 1) ++dbg_w[i];                                              \
+    }
+#else
+#define RTO_DBG_AT(i)
 #endif
     RayState rs;
     // a lane marches a ray while rs.t < rs.tmax: that comparison IS the lane's state (an ended ray has t >= tmax or
@@ -1125,6 +1136,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     const int x = (int)(entry & 1023u) * 8 + (int)(r & 7u);  // (Z-order inside the tile was tried: no fewer L1 accesses)
                     const int y = (int)((entry >> 10) & 1023u) * 8 + (int)((r >> 3) & 7u);
                     if (rank < take && x < W && y < H) {
+                        RTO_DBG_AT(6)
                         const float* fd = s_cams + frame * kCamFloats;
                         CamDev cam;
                         cam.width = W;
@@ -1182,13 +1194,10 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
         const int exit_at = drained ? 0 : 64 - REFILL;
         int n_active;
         do {
-#ifdef RTO_DBG_COUNTERS
-        ++dbg_wave_steps;
-        dbg_lane_steps += (unsigned)__popcll(__ballot(active));
-#endif
         {
             // ---- one node visit for every active lane
             if (active) {
+                RTO_DBG_AT(0)
                 const bool grid = rs.node == kGridNext;
                 const uint32_t gs = 24u - (uint32_t)G;
                 const uint32_t key = (((rs.pix >> gs) << G | (rs.piy >> gs)) << G) | (rs.piz >> gs);
@@ -1263,14 +1272,14 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     w = *pn;  // (through the L1: a non-temporal load here costs 50 %)
                 }
 #endif
-#ifdef RTO_DBG_COUNTERS
-                ++dbg_lane_loads;
-#endif
+                if (grid) RTO_DBG_AT(7)
                 if ((int32_t)w >= -(1 << 30)) {  // internal: one level down
+                    RTO_DBG_AT(1)
                     rs.node += w;
                     ++rs.prev_lvl;
                     stack_g[rs.prev_lvl * 256] = rs.node;
                 } else {  // leaf: the march step (rt_core.cuh:241-270)
+                    RTO_DBG_AT(2)
                     const int lvl = rs.prev_lvl;
                     // rs.pos is clamp(cen + t * dir) of this very t (computed when the previous step
                     // picked its restart node)
@@ -1295,9 +1304,11 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     const float delta_t = tm * inv_cube + step_size;
                     const float sigma = half_bits_to_float((uint16_t)w);
                     if (sigma > sigma_thresh) {
+                        RTO_DBG_AT(3)
                         const float delta = delta_t * rs.delta_scale * sigma;
                         const float reach = rs.src + delta;
                         if (reach >= rs.cur) {
+                            RTO_DBG_AT(4)
                             uint32_t cnt = 0;
                             do {
                                 ++cnt;
@@ -1314,12 +1325,10 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     rs.t += delta_t;
                     active = rs.t < rs.tmax;
                     if (active)
-#ifdef RTO_DBG_COUNTERS
-                    ++dbg_lane_leafs;
-#endif
                     {  // next position -> restart node (deepest ancestor shared with this step).  (Running this for rays that
                        // just ended as well -- one divergent branch less per iteration -- measured 3 % SLOWER in one box:
                        // the register allocator pays for the merged live ranges with a dozen copies.)
+                        RTO_DBG_AT(5)
                         const f2 pxy = rs.cxy + (f2){rs.dir[0], rs.dir[1]} * rs.t;
                         rs.pos[0] = clamp_unit(pxy.x);
                         rs.pos[1] = clamp_unit(pxy.y);
@@ -1335,10 +1344,6 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                         uint32_t lead;
                         asm("v_ffbh_u32 %0, %1" : "=v"(lead) : "v"(diff));
                         const uint32_t mu = lead - 8u;
-#ifdef RTO_DBG_COUNTERS
-                        if ((int)mu >= lvl) ++dbg_refilled;      // next leaf is a sibling (same parent node)
-                        if ((int)mu == lvl - 1) ++dbg_refills;   // next leaf is a cousin (same grandparent)
-#endif
                         const int m = (int)(mu < (uint32_t)lvl ? mu : (uint32_t)lvl);
                         rs.pix = ix;
                         rs.piy = iy;
@@ -1361,18 +1366,11 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
         } while (n_active > exit_at);
     }
 #ifdef RTO_DBG_COUNTERS
-    {
-        // wave-level descent iterations = max over lanes is not directly visible; report lane loads
-        atomicAdd(queue + 4, (unsigned long long)dbg_lane_loads);
-        atomicAdd(queue + 5, (unsigned long long)dbg_lane_leafs);
-        if ((tid & 63) == 0) {
-            atomicAdd(queue + 2, (unsigned long long)dbg_wave_steps);
-            atomicAdd(queue + 3, (unsigned long long)dbg_lane_steps);
-        }
-        {
-            atomicAdd(queue + 6, (unsigned long long)dbg_refills);
-            atomicAdd(queue + 7, (unsigned long long)dbg_refilled);
-        }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // queue words 1..7 / 9..15 are padding of the queue counters: wave counts, lane counts
+        const int wi = i == 0 ? 16 + 1 : i, li = i == 0 ? 16 + 2 : 8 + i;
+        if (dbg_w[i]) atomicAdd(queue + wi, (unsigned long long)dbg_w[i]);
+        if (dbg_l[i]) atomicAdd(queue + li, (unsigned long long)dbg_l[i]);
     }
 #endif
 }

@@ -1070,8 +1070,8 @@ int rto_ctx_set_kernel(rto_ctx* c, int kernel) {
 }
 
 #if defined(RTO_DBG_COUNTERS) || defined(RTO_DBG_GRIDUNIQ)
-extern "C" int rto_debug_read_queue(rto_ctx* c, uint64_t out[8]) {
-    return hipMemcpy(out, c->queue, 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -4;
+extern "C" int rto_debug_read_queue(rto_ctx* c, uint64_t out[24]) {
+    return hipMemcpy(out, c->queue, 24 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -4;
 }
 extern "C" int rto_debug_zero_queue(rto_ctx* c) { return hipMemset(c->queue + 2, 0, 48) == hipSuccess ? 0 : -4; }
 #endif

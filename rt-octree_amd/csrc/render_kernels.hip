@@ -759,8 +759,8 @@ struct RayState {
     uint32_t pix, piy, piz;
     int prev_lvl;   // level of the node about to be visited
     uint32_t hoff, hnext;  // index of this pixel's next free hit entry in the hand-off buffer, and of the one behind it
-                           // (RTO_HITS_STAGED: of its entries 0 and 1, fixed for the ray's life)
-    uint32_t nh;           // RTO_HITS_STAGED: hit entries of this ray parked in LDS, not yet written out
+                           // (staged hit lists, the default: of its entries 0 and 1, fixed for the ray's life)
+    uint32_t nh;           // staged hit lists: hit entries of this ray parked in LDS, not yet written out
     uint32_t node;  // node about to be visited; kGridNext = the top grid is visited next
     float cxy __attribute__((ext_vector_type(2)));  // cen[0], cen[1] as a register pair for the packed march arithmetic
     // _dda_unit's max(t1, t1 + invdir) per axis is t1 + (invdir > 0 ? invdir : 0): the sign of invdir is the ray's, not the
@@ -1004,7 +1004,7 @@ __global__ void __launch_bounds__(256) sample_kernel(const FrameBatch fb, const 
     for (int i = 0; i < SPP; ++i) fd.hits[hit_index<SPP>(idx, (uint32_t)i, SIZE)] = __float_as_uint(dst[i]) & ~kHitValid;
 }
 
-// RTO_HITS_STAGED (round 4, VERDICT r3 task 5): a ray's hit entries wait in LDS -- in the rows of its threshold column that
+// Staged hit lists (round 4, VERDICT r3 task 5; -DRTO_HITS_DIRECT restores the store per hit): a ray's hit entries wait in LDS -- in the rows of its threshold column that
 // its consumed thresholds left free -- and are written to the hand-off buffer when the ray has ended: entry 0 into the dense
 // plane, entries 1.. as one contiguous run (4 * (n - 1) bytes of ONE 32-byte sector for SPP <= 9), back to back, instead of
 // one 4-byte store per hit at the moment it happens (71.6 M scattered dwords per 100 frames cost 2.48 GB of line-granular
@@ -1092,6 +1092,9 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
 #else
 #define RTO_DBG_AT(i) {}
 #endif
+#ifdef RTO_LEAF_K
+    uint32_t pend_w = 0u, pend_slot = 0u;  // the leaf word / slot a lane waits at (0: none; a leaf word carries kLeafTag)
+#endif
     RayState rs;
     // a lane marches a ray while rs.t < rs.tmax: that comparison IS the lane's state (an ended ray has t >= tmax or
     // tmax = -1), so the wave-level count of marching lanes is the ballot of one v_cmp instead of a loop-carried flag
@@ -1143,7 +1146,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                 const uint32_t take = (uint32_t)n_need < res_end - res_next ? (uint32_t)n_need : res_end - res_next;
                 const uint32_t first = res_next;
                 res_next += take;
-#ifdef RTO_HITS_STAGED
+#ifndef RTO_HITS_DIRECT
                 if (idle && rs.nh) flush_hits<SPP>(rs, hits, s_dst, hstride);  // the ended ray's hit list leaves in one go
 #endif
                 if (idle) {
@@ -1217,7 +1220,11 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
         do {
         {
             // ---- one node visit for every active lane
+#ifdef RTO_LEAF_K
+            if (active && pend_w == 0u) {
+#else
             if (active) {
+#endif
                 RTO_DBG_AT(0)
                 const bool grid = rs.node == kGridNext;
                 const uint32_t gs = 24u - (uint32_t)G;
@@ -1300,91 +1307,30 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     ++rs.prev_lvl;
                     stack_g[rs.prev_lvl * 256] = rs.node;
                 } else {  // leaf: the march step (rt_core.cuh:241-270)
-                    RTO_DBG_AT(2)
-                    const int lvl = rs.prev_lvl;
-                    // rs.pos is clamp(cen + t * dir) of this very t (computed when the previous step
-                    // picked its restart node)
-                    const float cube_sz = __uint_as_float((uint32_t)(128 + lvl) << 23);
-                    const float inv_cube = __uint_as_float((uint32_t)(126 - lvl) << 23);
-                    // _dda_unit (rt_core.cuh:38-51) on the leaf-local point frac(pos * cube_sz)
-                    // (x and y as packed pairs: v_pk_mul_f32 / v_pk_add_f32 are the same IEEE operations, two per issue)
-                    typedef float f2 __attribute__((ext_vector_type(2)));
-                    // max(t1, t2) with t1 = -p * invdir, t2 = t1 + invdir (rt_core.cuh:44-48): invdir > 0 gives t2 >= t1, so the
-                    // maximum IS t1 + invdir; invdir < 0 gives t2 <= t1, so it is t1 = t1 + 0 (a zero's sign aside, which the
-                    // sums below cannot observe).  One add per axis instead of an add and a max (round 3: the kernel is bound
-                    // by instruction issue and v_max_f32 costs two issue slots, profiles/r3_valu_calibration.json).
-                    // The 1e4 start of the reference's running minimum never survives: dir is a unit vector, so one axis has
-                    // |invdir| <= sqrt(3) and its exit time is below 2.
-                    const f2 ixy = {rs.invdir[0], rs.invdir[1]};
-                    const f2 sxy = (f2){rs.pos[0], rs.pos[1]} * cube_sz;
-                    const f2 bxy = -(f2){__builtin_amdgcn_fractf(sxy.x), __builtin_amdgcn_fractf(sxy.y)} * ixy;
-                    const f2 axy = bxy + (f2){rs.exit_add[0], rs.exit_add[1]};
-                    const float b2 = -__builtin_amdgcn_fractf(rs.pos[2] * cube_sz) * rs.invdir[2];
-                    const float a2 = b2 + rs.exit_add[2];
-                    const float tm = __builtin_fminf(__builtin_fminf(axy.x, axy.y), a2);
-                    const float delta_t = tm * inv_cube + step_size;
-                    const float sigma = half_bits_to_float((uint16_t)w);
-                    if (sigma > sigma_thresh) {
-                        RTO_DBG_AT(3)
-                        const float delta = delta_t * rs.delta_scale * sigma;
-                        const float reach = rs.src + delta;
-                        if (reach >= rs.cur) {
-                            RTO_DBG_AT(4)
-                            uint32_t cnt = 0;
-                            do {
-                                ++cnt;
-                                ++rs.spp;
-                                rs.cur = s_dst[rs.spp * 256];
-                            } while (reach >= rs.cur);
-#ifdef RTO_HITS_STAGED
-                            // entry k of the ray goes to row k of its threshold column: thresholds 1..spp are consumed, and
-                            // k < spp (every hit crosses at least one threshold; row 0 never held one)
-                            s_dst[rs.nh * 256] = __uint_as_float(hit_pack<SPP>(slot, cnt));
-                            ++rs.nh;
+#ifdef RTO_LEAF_K
+                    pend_w = w;  // postponed: the lane waits at its leaf until enough lanes of the wave have reached one
+                    pend_slot = slot;
 #else
-                            hits[rs.hoff] = hit_pack<SPP>(slot, cnt);
-                            rs.hoff = rs.hnext;  // (the next free entry of this pixel's list)
-                            rs.hnext += hstride;
+#include "rto_march_leaf.inc"
 #endif
-                            if (rs.spp == (uint32_t)SPP) rs.tmax = -1.f;  // the last threshold: the ray ends
-                        }
-                        rs.src = reach;
-                    }
-                    rs.t += delta_t;
-                    active = rs.t < rs.tmax;
-                    if (active)
-                    {  // next position -> restart node (deepest ancestor shared with this step).  (Running this for rays that
-                       // just ended as well -- one divergent branch less per iteration -- measured 3 % SLOWER in one box:
-                       // the register allocator pays for the merged live ranges with a dozen copies.)
-                        RTO_DBG_AT(5)
-                        const f2 pxy = rs.cxy + (f2){rs.dir[0], rs.dir[1]} * rs.t;
-                        rs.pos[0] = clamp_unit(pxy.x);
-                        rs.pos[1] = clamp_unit(pxy.y);
-                        rs.pos[2] = clamp_unit(rs.cen[2] + rs.t * rs.dir[2]);
-                        const f2 qxy = (f2){rs.pos[0], rs.pos[1]} * 16777216.f;
-                        const uint32_t ix = (uint32_t)qxy.x;
-                        const uint32_t iy = (uint32_t)qxy.y;
-                        const uint32_t iz = (uint32_t)(rs.pos[2] * 16777216.f);
-                        const uint32_t diff = (ix ^ rs.pix) | (iy ^ rs.piy) | (iz ^ rs.piz);
-                        // deepest level whose cell still holds both points: leading equal bits of the 24-bit coordinates,
-                        // capped at the leaf's level (v_ffbh_u32 returns -1 for diff = 0; as an unsigned number that
-                        // loses the minimum as well)
-                        uint32_t lead;
-                        asm("v_ffbh_u32 %0, %1" : "=v"(lead) : "v"(diff));
-                        const uint32_t mu = lead - 8u;
-                        const int m = (int)(mu < (uint32_t)lvl ? mu : (uint32_t)lvl);
-                        rs.pix = ix;
-                        rs.piy = iy;
-                        rs.piz = iz;
-                        if (m < G) {
-                            rs.node = kGridNext;
-                        } else {
-                            rs.node = stack_g[m * 256];
-                            rs.prev_lvl = m;
-                        }
+                }
+            }
+#ifdef RTO_LEAF_K
+            {
+                // Experiment (VERDICT r3 task 3): the leaf branch -- the bulk of the loop body -- runs only once RTO_LEAF_K lanes
+                // wait at a leaf, or when no active lane is left that could still descend.
+                const bool at_leaf = active && pend_w != 0u;
+                const unsigned long long lm = __builtin_amdgcn_ballot_w64(at_leaf);
+                const unsigned long long dm = __builtin_amdgcn_ballot_w64(active && pend_w == 0u);
+                if (__popcll(lm) >= RTO_LEAF_K || dm == 0ULL) {
+                    if (at_leaf) {
+                        const uint32_t w = pend_w, slot = pend_slot;
+                        pend_w = 0u;
+#include "rto_march_leaf.inc"
                     }
                 }
             }
+#endif
         }
             active = rs.t < rs.tmax;
             {
@@ -1393,7 +1339,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
             }
         } while (n_active > exit_at);
     }
-#ifdef RTO_HITS_STAGED
+#ifndef RTO_HITS_DIRECT
     if (rs.nh) flush_hits<SPP>(rs, hits, s_dst, hstride);  // rays that ended after the last refill round
 #endif
 #ifdef RTO_DBG_COUNTERS

@@ -576,10 +576,17 @@ def main():
             ctx.select_frame(0)
             barrier()
             t0g = time.perf_counter()
-            frames_g = sharding.gather_frames(local, K * world, rank, world, dist=dist, device=dev if backend == "nccl" else None)
+            gather_err = None
+            try:
+                frames_g = sharding.gather_frames(local, K * world, rank, world, dist=dist, device=dev if backend == "nccl" else None)
+            except Exception as e:  # the untimed collective must not cost the run its measured line
+                frames_g, gather_err = None, repr(e)
+                print("[bench] rank %d: final gather failed: %s" % (rank, gather_err), file=sys.stderr)
             barrier()
             tg = time.perf_counter() - t0g
-            if rank == 0:
+            if rank == 0 and frames_g is None:
+                gather = {"error": gather_err, "backend": backend, "world": world}
+            elif rank == 0:
                 other = 1  # global frame 1 belongs to rank 1: (scene, pose) = pose_schedule(0, 1, world, ...)
                 sc_o, i_o = pose_schedule(0, 1, world, len(poses), n_scenes, "pose")
                 same = None

@@ -554,6 +554,13 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
     const int idx = y * cam.width + x;
 
     float out[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!STATS && fo.cull_marks) {  // (wave-uniform: a wave is one 8x8 tile)
+        const uint32_t t = (uint32_t)(y >> 3) * ((uint32_t)(cam.width + 7) >> 3) + (uint32_t)(x >> 3);
+        if (!(((fo.cull_marks[t >> 5] >> (t & 31u)) | fo.cull_marks[fo.cull_mask_words - 1]) & 1u)) {
+            write_pixel(fo, SIZE, idx, opt.background_brightness, out);  // no ray of this tile meets density: background
+            return;
+        }
+    }
     float dir[3], vdir[3], cen[3], invdir[3];
     ray_setup(x, y, cam, tree, dir, vdir, cen);
     float delta_scale, tmin, tmax;
@@ -853,6 +860,32 @@ RTO_DEV void mark_cell(const float4 cell, const FrameDesc& fd, const FrameBatch&
             const uint32_t t = (uint32_t)(ty * tiles_x + tx);
             mark(t >> 5, 1u << (t & 31u));
         }
+    }
+}
+
+// the same for ONE frame whose camera arrives as a kernel argument (rto_launch_renderer: no frame table): one workgroup =
+// kMarkCells cells, marks OR-ed into `mask` (zeroed on the stream before)
+__global__ void __launch_bounds__(256) mark_tiles_one_kernel(const TreeDev tree, const FrameDesc fd, const int width, const int height,
+                                                             const int mask_words, uint32_t* __restrict__ mask) {
+    extern __shared__ uint32_t s_mask[];
+    FrameBatch fb;
+    fb.width = width;
+    fb.height = height;
+    fb.mask_words = mask_words;
+    const bool lds = mask_words <= kMarkLdsWords;
+    if (lds) {
+        for (int i = threadIdx.x; i < mask_words; i += 256) s_mask[i] = 0u;
+        __syncthreads();
+    }
+    for (int c = (int)blockIdx.x * kMarkCells + (int)threadIdx.x; c < tree.n_occ_cells && c < ((int)blockIdx.x + 1) * kMarkCells; c += 256)
+        if (lds)
+            mark_cell(tree.occ_cells[c], fd, fb, [&](uint32_t w, uint32_t bits) { atomicOr(&s_mask[w], bits); });
+        else
+            mark_cell(tree.occ_cells[c], fd, fb, [&](uint32_t w, uint32_t bits) { atomicOr(mask + w, bits); });
+    if (lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < mask_words; i += 256)
+            if (s_mask[i]) atomicOr(mask + i, s_mask[i]);
     }
 }
 
@@ -1749,6 +1782,20 @@ static hipError_t launch_spp(int kernel, const TreeDev& tree, const CamDev& cam,
         const int64_t size = (int64_t)cam.width * cam.height;
         hipLaunchKernelGGL(render_generic<SPP>, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, stream, tree, cam,
                            opt, rng, fo);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_mark_tiles_one(const TreeDev& tree, const CamDev& cam, uint32_t* mask, int mask_words, hipStream_t stream) {
+    FrameDesc fd = {};
+    fd.fx = cam.fx;
+    fd.fy = cam.fy;
+    for (int i = 0; i < 12; ++i) fd.transform[i] = cam.transform[i];
+    if (hipMemsetAsync(mask, 0, (size_t)mask_words * sizeof(uint32_t), stream) != hipSuccess) return hipErrorLaunchFailure;
+    if (tree.n_occ_cells > 0) {
+        const dim3 grid((unsigned)((tree.n_occ_cells + kMarkCells - 1) / kMarkCells));
+        const size_t lds = mask_words <= kMarkLdsWords ? (size_t)mask_words * sizeof(uint32_t) : 0;
+        hipLaunchKernelGGL(mark_tiles_one_kernel, grid, dim3(256), lds, stream, tree, fd, cam.width, cam.height, mask_words, mask);
     }
     return hipGetLastError();
 }

@@ -128,6 +128,7 @@ struct rto_ctx {
     int last_n_queues = 0;                // of the last batched launch (rto_ctx_queue_stats)
     int64_t last_slots = 0;
     int batch_fallback = 0;               // tuning / test hook, see rto_ctx_set_tuning
+    bool cull_single = true;              // tuning "cull_single": the single-frame kernel culls too (0: round-3 behaviour)
     int marks_n = 0, marks_slot0 = 0;     // frames whose tile marks the last launch left in tile_mask (0: none), their first slot
     float marks_bg = 0.f;                 // ... and the background brightness of that launch
     // per-kernel event timing of the batched path (off by default)
@@ -1095,6 +1096,8 @@ int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value) {
         c->refill = value;
     } else if (k == "cull") {  // empty-space culling of the batched path (1 = on; same pixels either way)
         c->cull_on = value != 0;
+    } else if (k == "cull_single") {  // rto_launch_renderer's fast kernel skips the tiles no culling cell projects into (same pixels)
+        c->cull_single = value != 0;
     } else if (k == "frame_via_batch") {  // rto_launch_renderer as a batch of one (culling + tile marks); same pixels
         c->frame_via_batch = value != 0;
     } else if (k == "blocks_per_cu") {  // occupancy of the persistent traversal kernel: 0 = what fits, else a cap (1..8)
@@ -1269,7 +1272,32 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
     fo.stats = nullptr;
     fo.stat_marks = nullptr;
     fo.stat_mask_words = 0;
+    fo.cull_marks = nullptr;
+    fo.cull_mask_words = 0;
     bool keep_marks = false;
+    // Empty-space culling for the single-frame kernel as well (round 4, VERDICT r3 task 6): one small kernel projects the
+    // tree's culling cells into this camera (same bound and premises as the batched path, see launch_batch_at), and the
+    // waves of unmarked 8x8 tiles write the background without ray set-up, threshold draws or marching.  The marks stay
+    // on the context for the denoise stage (rto_ctx_tile_marks), like after a batched launch.
+    const bool cull_one = kernel == RTO_KERNEL_FAST && !ctx->stats_on && ctx->cull_on && ctx->cull_single && tree->dev.occ_cells &&
+                          o->sigma_thresh >= 0.f && !(tree->dev.ndc_width > 0.f);
+    if (cull_one) {
+        const int tiles = ((ctx->width + 7) / 8) * ((ctx->height + 7) / 8);
+        const int mask_words = (tiles + 31) / 32 + 1;
+        if (!ctx->tile_mask || ctx->mask_words != mask_words) {
+            if (ctx->tile_mask) {
+                HIP_TRY(hipDeviceSynchronize());
+                for (void* p : {(void*)ctx->tile_mask, (void*)ctx->qlist, (void*)ctx->qscratch}) HIP_TRY(hipFree(p));
+                ctx->tile_mask = ctx->qlist = ctx->qscratch = nullptr;
+            }
+            ctx->q_chunks_cap = 0;  // (a batched launch sizes its queue lists itself)
+            HIP_TRY(hipMalloc((void**)&ctx->tile_mask, (size_t)ctx->frames * mask_words * sizeof(uint32_t)));
+            ctx->mask_words = mask_words;
+        }
+        HIP_TRY(rto::launch_mark_tiles_one(tree->dev, cd, ctx->tile_mask, mask_words, stream));
+        fo.cull_marks = ctx->tile_mask;
+        fo.cull_mask_words = mask_words;
+    }
     if (ctx->stats_on) {
         if (kernel != RTO_KERNEL_FAST) return set_err(RTO_E_UNSUPPORTED, "work counters need the fast kernel");
         fo.stats = ctx->stats;
@@ -1282,9 +1310,14 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
         }
     }
 
-    if (!keep_marks) ctx->marks_n = 0;  // (the per-frame kernels mark no tiles)
+    if (!keep_marks) ctx->marks_n = 0;  // (the generic kernel and the counting instantiation mark no tiles)
     hipError_t e = rto::launch_render(kernel, o->spp, tree->dev, cd, od, ctx->rng, ctx->jump, fo, ctx->strip_rows, stream);
     if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("render launch failed: ") + hipGetErrorString(e));
+    if (cull_one) {  // the selected slot's marks, for rto_ctx_tile_marks / the culled denoise stage
+        ctx->marks_n = 1;
+        ctx->marks_slot0 = ctx->sel;
+        ctx->marks_bg = o->background_brightness;
+    }
     return RTO_OK;
 }
 

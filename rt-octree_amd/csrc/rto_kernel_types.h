@@ -155,6 +155,10 @@ struct FrameOut {
     // counting kernel then also reports the work of the rays the batched path really marches (stats[6..])
     const uint32_t* stat_marks;
     int stat_mask_words;
+    // single-frame culling (round 4): the tile marks of THIS frame (mark_tiles_one_kernel ran before on the stream); an 8x8 tile
+    // without its bit holds only rays that meet no density: its wave writes the background and is gone.  nullptr: march all.
+    const uint32_t* cull_marks;
+    int cull_mask_words;
 };
 // stats[0..5] = SURVEY 8d's units over EVERY ray (orc_stats order: rays, rays_in_box, steps, levels of a root-restart walk,
 // hit leaves, rays with a hit); stats[6..11] = the same frame as the batched path works through it: rays of marked tiles,

@@ -27,6 +27,10 @@ TileMap make_tile_map(int width, int height, int strip_rows);
 hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev& cam, const OptDev& opt,
                          const Pcg32& rng, const PcgJumpEntry* jump, const FrameOut& fo, int strip_rows, hipStream_t stream);
 
+// tile marks of ONE frame for the single-frame kernel's culling (FrameOut::cull_marks): zeroes `mask` ((tiles + 31) / 32 + 1
+// words) on the stream and projects the tree's culling cells into the camera
+hipError_t launch_mark_tiles_one(const TreeDev& tree, const CamDev& cam, uint32_t* mask, int mask_words, hipStream_t stream);
+
 // writes n frame descriptors (host memory, read before the call returns) into a device table on `stream`
 hipError_t launch_write_frames(const FrameDesc* host, int n, FrameDesc* dev_table, hipStream_t stream);
 

@@ -674,9 +674,13 @@ def main():
         # tail of a frame (a handful of long rays on an otherwise empty chip) overlaps the next frames' heads.
         D = max(1, min(8, args.ref_loop_inflight))
         if D > 1:
+            # frames in flight make skipped work count (throughput), so the pipelined contexts let the single-frame kernel cull
+            # (tuning key cull_single; same pixels: the last frame is compared with the sequential loop's below)
+            one.set_tuning("cull_single", 1)
             plane = [(one, stream, one_net, one_aux)]
             for _ in range(1, D):
                 c2 = tune(R.RenderContext(W, H, device=local_rank, frames=1))
+                c2.set_tuning("cull_single", 1)
                 plane.append((c2, torch.cuda.Stream(dev), lane_net(), torch.as_tensor(c2.batch_views()[0], device=dev)))
             done = [torch.cuda.Event() for _ in range(D)]
             npipe = max(nf, 4 * D)
@@ -761,7 +765,8 @@ def main():
     t_launch = kt["traverse_ms"] * 1e-3
     alg_gbps = alg_bytes_launch / t_launch / 1e9 if t_launch > 0 else 0.0
     # (ii): bytes the traversal kernel itself moves for the marched rays ...
-    m_trav_frame = (8 * march["grid_loads"] + 4 * march["node_loads"]        # node visits
+    wide = bool(getattr(tree, "wide_nodes", 0))  # the batched kernel walks the two-level image: one entry per two levels
+    m_trav_frame = (8 * march["grid_loads"] + 4 * march["wide_loads" if wide else "node_loads"]        # node visits
                     + 4 * args.spp * march["rays_in_box"]                     # sorted thresholds read back (sample_kernel wrote them)
                     + 4 * march["hit_entries"]                                # hit entries written
                     + 4 * marked_tiles) / count_steps                         # queue list entries
@@ -1043,7 +1048,8 @@ def main():
                                     "every tile) over traversal + shading time.  Cache-served re-reads count (algorithmic, not DRAM)",
         "marched_units_per_frame": dict({k: v / count_steps for k, v in march.items()},
                                         tiles_marked=marked_tiles / count_steps, tiles=all_tiles / count_steps,
-                                        loads_per_step=(march["grid_loads"] + march["node_loads"]) / max(march["steps"], 1)) if counted else None,
+                                        traversal_image="two-level (wide_loads)" if wide else "one-level (node_loads)",
+                                        loads_per_step=(march["grid_loads"] + march["wide_loads" if wide else "node_loads"]) / max(march["steps"], 1)) if counted else None,
         "survey_8d_every_ray_bytes_per_launch": alg_bytes_launch, "survey_8d_every_ray_gbps": alg_gbps,
         "survey_8d_every_ray_over_peak": frac_of(alg_gbps),
         "survey_8d_note": "root-restart walk, EVERY ray (SURVEY 8d formula: 4 B per level + 2 B per step + SH record per hit leaf + 48 B per "

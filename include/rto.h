@@ -92,6 +92,7 @@ typedef struct rto_tree_info {
     float ndc_width, ndc_height, ndc_focal;
     int max_depth;      /* deepest leaf level (levels of child[] visited to reach it) */
     int64_t device_bytes;
+    int64_t wide_nodes; /* nodes of the two-level traversal image the batched kernel walks (0: it walks the one-level image) */
 } rto_tree_info;
 
 typedef struct rto_tree rto_tree; /* opaque */
@@ -230,8 +231,18 @@ int rto_ctx_get_stats(rto_ctx* c, void* stream, uint64_t out[6], int reset);
  * The caller renders frames with rto_launch_renderer_batch, selects a slot and re-renders that slot's pose (same RNG) with
  * rto_launch_renderer: rays of tiles the batched launch culled are left out, and a node visit counts as the one load
  * render_persist issues for it.  out = {rays of marked tiles, their march steps, top-grid entries loaded (8 B each),
- * traversal-image words loaded (4 B each), hit entries written (4 B each), rays of marked tiles that entered the volume}. */
-int rto_ctx_get_march_stats(rto_ctx* c, void* stream, uint64_t out[6], int reset);
+ * traversal-image words loaded (4 B each), hit entries written (4 B each), rays of marked tiles that entered the volume,
+ * entries of the two-level traversal image loaded (4 B each: render_persist loads these INSTEAD of the traversal-image words
+ * when the tree has that image, rto_tree_info.wide_image), 0}. */
+int rto_ctx_get_march_stats(rto_ctx* c, void* stream, uint64_t out[8], int reset);
+
+/* Diagnostics, host only (no device): the two-level traversal image the batched kernel walks (a node of level G + 2p merged
+ * with its eight children: one load per two levels; derived from child[], n3tree.hpp / n3tree_query.hpp:22-47 is what it
+ * must answer like) built for a breadth-first child[] and walked for n points (24-bit fixed-point x, y, z each) exactly as
+ * the kernel walks it; out: the leaf's level, its slot in child[] / data[], its sigma bits, the number of wide nodes. */
+int rto_wide_image_probe(const int32_t* child, const uint16_t* sigma_bits, int64_t capacity, int max_depth, int top_levels,
+                         const uint32_t* points, int64_t n, int32_t* out_level, int64_t* out_slot, uint16_t* out_sigma,
+                         int64_t* out_wide_nodes);
 
 /* ---- the operator ---- */
 /* launch_renderer(tree, cam, options, ctx, stream, offscreen=true) (volrend.cu:236-285).

@@ -42,6 +42,7 @@ class CTreeInfo(C.Structure):
         ("basis_dim", C.c_int), ("scale", C.c_float * 3), ("offset", C.c_float * 3),
         ("use_ndc", C.c_int), ("ndc_width", C.c_float), ("ndc_height", C.c_float),
         ("ndc_focal", C.c_float), ("max_depth", C.c_int), ("device_bytes", C.c_int64),
+        ("wide_nodes", C.c_int64),
     ]
 
 
@@ -90,6 +91,7 @@ SYMBOLS = {
     "rto_ctx_enable_stats": (C.c_int, [_P, C.c_int]),
     "rto_ctx_get_stats": (C.c_int, [_P, _P, C.POINTER(C.c_uint64), C.c_int]),
     "rto_ctx_get_march_stats": (C.c_int, [_P, _P, C.POINTER(C.c_uint64), C.c_int]),
+    "rto_wide_image_probe": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, _P, C.c_int64, _P, _P, _P, C.POINTER(C.c_int64)]),
     "rto_launch_renderer": (C.c_int, [_P, C.POINTER(CCamera), C.POINTER(COptions), _P, _P]),
     "rto_launch_renderer_batch": (C.c_int, [_P, C.POINTER(CCamera), C.POINTER(C.c_int64), C.c_int, C.POINTER(COptions), _P, _P]),
     "rto_filtering_batch": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),

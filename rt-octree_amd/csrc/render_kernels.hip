@@ -564,7 +564,7 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
     float dir[3], vdir[3], cen[3], invdir[3];
     ray_setup(x, y, cam, tree, dir, vdir, cen);
     float delta_scale, tmin, tmax;
-    unsigned long long st_steps = 0, st_levels = 0, st_hits = 0, st_inbox = 0, st_grid = 0, st_words = 0;
+    unsigned long long st_steps = 0, st_levels = 0, st_hits = 0, st_inbox = 0, st_grid = 0, st_words = 0, st_wide = 0;
     if (ray_enter(tree, opt, dir, cen, 1e9f, invdir, delta_scale, tmin, tmax)) {
         if (STATS) st_inbox = 1;
         Pcg32 rng = rng_base;
@@ -627,13 +627,20 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
             } else {
                 node = lvl ? stack[lvl * 256] : 0u;
             }
+            int st_pair = -1;  // STATS: the pair of levels whose wide node the two-level image would have loaded last
             for (;;) {
                 if (!have_w) {
                     const int sh = 23 - lvl;
                     const uint32_t ci = (((ix >> sh) & 1u) << 2) | (((iy >> sh) & 1u) << 1) | ((iz >> sh) & 1u);
                     slot = node * 8u + ci;
                     w = tree.nodew[slot];
-                    if (STATS) ++st_words;
+                    if (STATS) {
+                        ++st_words;
+                        // render_persist on the two-level image loads ONE entry per pair of levels (G + 2p, G + 2p + 1)
+                        const int pr = (lvl - G) >> 1;
+                        if (pr != st_pair) ++st_wide;
+                        st_pair = pr;
+                    }
                 }
                 have_w = false;
                 if (nodew_is_leaf(w)) break;
@@ -732,6 +739,7 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
             atomicAdd(fo.stats + 9, st_words);
             atomicAdd(fo.stats + 10, st_hits);
             atomicAdd(fo.stats + 11, st_inbox);
+            atomicAdd(fo.stats + 12, st_wide);
         }
     }
 }
@@ -1042,13 +1050,36 @@ __global__ void __launch_bounds__(256) sample_kernel(const FrameBatch fb, const 
 // plane, entries 1.. as one contiguous run (4 * (n - 1) bytes of ONE 32-byte sector for SPP <= 9), back to back, instead of
 // one 4-byte store per hit at the moment it happens (71.6 M scattered dwords per 100 frames cost 2.48 GB of line-granular
 // HBM writes for 0.29 GB of payload: the L2 had evicted the sector long before the pixel's next entry arrived).
-template <int SPP>
-RTO_DEV void flush_hits(RayState& rs, uint32_t* __restrict__ hits, const float* s_col, uint32_t hstride) {
-    hits[rs.hoff] = __float_as_uint(s_col[0]);
+// hit index of the wide image -> the leaf's slot in data[] / shrec[] (what a hit entry names): an entry of a wide node is
+// child a of its octree node (when that is a leaf) or child b of that child; indices from wide_entries on are the slots of
+// leaves above the grid levels themselves
+RTO_DEV uint32_t wide_to_slot(const TreeDev& tree, uint32_t u) {
+    if (u >= tree.wide_entries) return u - tree.wide_entries;
+    const uint32_t wn = u >> 6, x2 = (u >> 4) & 3u, y2 = (u >> 2) & 3u, z2 = u & 3u;
+    const uint32_t a = (x2 >> 1) << 2 | (y2 >> 1) << 1 | (z2 >> 1), b = (x2 & 1u) << 2 | (y2 & 1u) << 1 | (z2 & 1u);
+    const uint32_t N = tree.worig[wn];
+    const uint32_t w0 = tree.nodew[N * 8u + a];
+    return nodew_is_leaf(w0) ? N * 8u + a : (N + w0) * 8u + b;
+}
+template <int SPP, bool WIDE>
+RTO_DEV void flush_hits(RayState& rs, const TreeDev& tree, uint32_t* __restrict__ hits, const float* s_col, uint32_t hstride) {
+    uint32_t e[SPP];
+#pragma unroll
+    for (int i = 0; i < SPP; ++i) {
+        e[i] = 0u;
+        if ((uint32_t)i < rs.nh) {
+            e[i] = __float_as_uint(s_col[i * 256]);
+            if constexpr (WIDE) {
+                constexpr uint32_t smask = (1u << hit_slot_bits(SPP)) - 1u;
+                e[i] = (e[i] & ~smask) | wide_to_slot(tree, e[i] & smask);  // (off the march loop: the ray has ended)
+            }
+        }
+    }
+    hits[rs.hoff] = e[0];
     uint32_t* tp = hits + rs.hnext;
 #pragma unroll
     for (int i = 1; i < SPP; ++i)
-        if ((uint32_t)i < rs.nh) tp[(uint32_t)(i - 1) * hstride] = __float_as_uint(s_col[i * 256]);
+        if ((uint32_t)i < rs.nh) tp[(uint32_t)(i - 1) * hstride] = e[i];
     rs.nh = 0;
 }
 
@@ -1057,7 +1088,7 @@ RTO_DEV void flush_hits(RayState& rs, uint32_t* __restrict__ hits, const float* 
 // at a leaf, takes its march step and picks the restart node of the next one -- instead of a nested
 // "descend until leaf" loop whose trip count is the maximum over the wave (measured: 1.4 loads per
 // lane-step on average, but ~4 per wave-step for the slowest lane).
-template <int SPP, int REFILL, int WPS>
+template <int SPP, int REFILL, int WPS, bool WIDE>
 __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, const OptDev opt, const FrameBatch fb,
                                                        unsigned long long* __restrict__ queue,
                                                        uint32_t* __restrict__ hits, const uint32_t chunk) {
@@ -1098,8 +1129,9 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     // Loop-invariant scalars pinned in SGPRs: hipcc otherwise re-loads them from the kernarg segment inside the descent loop (an s_load +
     // lgkmcnt(0) round trip per level).
     typedef const __attribute__((address_space(1))) uint32_t* gptr_t;  // keep global_load (not flat_load)
-    const uint32_t* nodew_p = tree.nodew;
-    const uint2* topgrid_p = tree.topgrid;
+    // WIDE: the two-level image and its top grid (rto_abi.cpp build_wide_image) instead of the one-level ones
+    const uint32_t* nodew_p = WIDE ? tree.widew : tree.nodew;
+    const uint2* topgrid_p = WIDE ? tree.topgrid2 : tree.topgrid;
     const uint32_t* __restrict__ qlist = fb.qlist;
     float step_size = opt.step_size, sigma_thresh = opt.sigma_thresh;
     asm volatile("" : "+s"(nodew_p), "+s"(topgrid_p), "+s"(step_size), "+s"(sigma_thresh));
@@ -1109,7 +1141,8 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     const gptr2_t topgrid = (gptr2_t)topgrid_p;
     const int G = tree.top_levels;  // grid bits per axis; the LDS stack holds node levels G.. (entry 0 = level G)
     if (G == 0) stack[0] = 0u;      // no top grid: level 0 is the root
-    uint32_t* const stack_g = stack - G * 256;  // indexed by node level (only ever with levels >= G)
+    // indexed by node level (only ever with levels >= G); WIDE: by the PAIR of levels (G + 2p, G + 2p + 1) a wide node spans
+    uint32_t* const stack_g = WIDE ? stack : stack - G * 256;
 
 #ifdef RTO_DBG_COUNTERS
     // per-branch occupancy of the march loop (tools/dbg_counters.py): for each branch, how many wave-level executions and
@@ -1180,7 +1213,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                 const uint32_t first = res_next;
                 res_next += take;
 #ifndef RTO_HITS_DIRECT
-                if (idle && rs.nh) flush_hits<SPP>(rs, hits, s_dst, hstride);  // the ended ray's hit list leaves in one go
+                if (idle && rs.nh) flush_hits<SPP, WIDE>(rs, tree, hits, s_dst, hstride);  // the ended ray's hit list leaves in one go
 #endif
                 if (idle) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32),
@@ -1262,10 +1295,19 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                 const bool grid = rs.node == kGridNext;
                 const uint32_t gs = 24u - (uint32_t)G;
                 const uint32_t key = (((rs.pix >> gs) << G | (rs.piy >> gs)) << G) | (rs.piz >> gs);
-                const uint32_t sh = 23u - (uint32_t)rs.prev_lvl;
-                uint32_t slot = (rs.node << 1) | __builtin_amdgcn_ubfe(rs.pix, sh, 1u);  // node * 8 + child digit,
-                slot = (slot << 1) | __builtin_amdgcn_ubfe(rs.piy, sh, 1u);                 // three v_lshl_or
-                slot = (slot << 1) | __builtin_amdgcn_ubfe(rs.piz, sh, 1u);
+                uint32_t slot;
+                if constexpr (WIDE) {
+                    // rs.prev_lvl = the pair p of the wide node about to be visited: two bits per axis, levels G + 2p and G + 2p + 1
+                    const uint32_t sh = (22u - (uint32_t)G) - 2u * (uint32_t)rs.prev_lvl;
+                    slot = (rs.node << 2) | __builtin_amdgcn_ubfe(rs.pix, sh, 2u);  // wide node * 64 + (x2 << 4 | y2 << 2 | z2)
+                    slot = (slot << 2) | __builtin_amdgcn_ubfe(rs.piy, sh, 2u);
+                    slot = (slot << 2) | __builtin_amdgcn_ubfe(rs.piz, sh, 2u);
+                } else {
+                    const uint32_t sh = 23u - (uint32_t)rs.prev_lvl;
+                    slot = (rs.node << 1) | __builtin_amdgcn_ubfe(rs.pix, sh, 1u);  // node * 8 + child digit,
+                    slot = (slot << 1) | __builtin_amdgcn_ubfe(rs.piy, sh, 1u);       // three v_lshl_or
+                    slot = (slot << 1) | __builtin_amdgcn_ubfe(rs.piz, sh, 1u);
+                }
                 uint32_t w;
 #ifdef RTO_DBG_GRIDUNIQ
                 {  // how many distinct top-grid cells / nodew lines does one wave-level load touch?
@@ -1326,8 +1368,12 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                 if (grid) {  // the iteration's one load: 8 bytes of the top grid ...
                     const u32x2 e = *pg;  // (through the L1 as well: non-temporal costs 15 %)
                     slot = e.x & kGridSlotMask;
-                    rs.prev_lvl = (int)(e.x >> kGridSlotBits);
-                    rs.node = slot >> 3;
+                    if constexpr (WIDE) {
+                        rs.prev_lvl = -1;  // (an internal entry names the wide node of pair 0: the descent below makes it 0)
+                    } else {
+                        rs.prev_lvl = (int)(e.x >> kGridSlotBits);
+                        rs.node = slot >> 3;
+                    }
                     w = e.y;
                 } else {  // ... or 4 bytes of the traversal image
                     w = *pn;  // (through the L1: a non-temporal load here costs 50 %)
@@ -1336,7 +1382,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                 if (grid) { RTO_DBG_AT(7) }
                 if ((int32_t)w >= -(1 << 30)) {  // internal: one level down
                     RTO_DBG_AT(1)
-                    rs.node += w;
+                    rs.node = WIDE ? w : rs.node + w;  // (WIDE: the absolute index of the wide node two levels down)
                     ++rs.prev_lvl;
                     stack_g[rs.prev_lvl * 256] = rs.node;
                 } else {  // leaf: the march step (rt_core.cuh:241-270)
@@ -1373,7 +1419,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
         } while (n_active > exit_at);
     }
 #ifndef RTO_HITS_DIRECT
-    if (rs.nh) flush_hits<SPP>(rs, hits, s_dst, hstride);  // rays that ended after the last refill round
+    if (rs.nh) flush_hits<SPP, WIDE>(rs, tree, hits, s_dst, hstride);  // rays that ended after the last refill round
 #endif
 #ifdef RTO_DBG_COUNTERS
 #pragma unroll
@@ -1819,7 +1865,7 @@ hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev&
 #ifndef RTO_WPS_DEFAULT
 #define RTO_WPS_DEFAULT 7
 #endif
-template <int SPP, int REFILL, int WPS>
+template <int SPP, int REFILL, int WPS, bool WIDE>
 static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                     const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
                                     int chunk_override, bool cull, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
@@ -1827,7 +1873,7 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
     // one does not pay for 128)
     const size_t lds = (size_t)(tree.max_depth + 1 - tree.top_levels + SPP + 1) * 256 * sizeof(uint32_t) +
                        sizeof(float) * kCamFloats * (size_t)fb.n;
-    const void* fn = reinterpret_cast<const void*>(&render_persist<SPP, REFILL, WPS>);
+    const void* fn = reinterpret_cast<const void*>(&render_persist<SPP, REFILL, WPS, WIDE>);
     OccupancyCache local;
     if (!occ) occ = &local;
     occ->lds_refused = false;
@@ -1844,7 +1890,7 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
             }
         }
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_persist<SPP, REFILL, WPS>, 256, lds) != hipSuccess || nb < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_persist<SPP, REFILL, WPS, WIDE>, 256, lds) != hipSuccess || nb < 1)
             nb = 2;
         occ->blocks_per_cu = nb > 8 ? 8 : nb;
         occ->fn = fn;
@@ -1883,7 +1929,7 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
     // this context ended
     if (hipMemsetAsync(queue, 0, kQueueWords * sizeof(unsigned long long), stream) != hipSuccess) return hipErrorLaunchFailure;
     if (ev) (void)hipEventRecord(ev[1], stream);
-    hipLaunchKernelGGL((render_persist<SPP, REFILL, WPS>), dim3(grid), dim3(256), lds, stream, tree, opt, fb, queue, hits, chunk);
+    hipLaunchKernelGGL((render_persist<SPP, REFILL, WPS, WIDE>), dim3(grid), dim3(256), lds, stream, tree, opt, fb, queue, hits, chunk);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
     if (ev) (void)hipEventRecord(ev[2], stream);
 #ifndef RTO_SHADE_P
@@ -1921,14 +1967,14 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
                                    int refill, bool cull, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
     const int chunk_override = (refill / 1000) * 64;  // tuning: refill = 1000 * tiles_per_dequeue + threshold
     refill %= 1000;
-    if constexpr (SPP == 6) {  // tuning instantiations only for the benchmark configuration
-#define RTO_F(R, O) return launch_batch_impl<SPP, R, O>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream)
-        switch (refill) {  // A/B set kept for tools/ab_tuning.py: 100 * waves/SIMD + refill threshold
+    const bool wide = tree.widew != nullptr;
+    if constexpr (SPP == 6) {  // tuning instantiations only for the benchmark configuration (and its usual two-level image)
+#define RTO_F(R, O) return launch_batch_impl<SPP, R, O, true>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream)
+        if (wide) switch (refill) {  // A/B set kept for tools/ab_tuning.py: 100 * waves/SIMD + refill threshold
             case 808: RTO_F(8, 8);
             case 816: RTO_F(16, 8);
             case 832: RTO_F(32, 8);
             case 724: RTO_F(24, 7);
-            case 732: RTO_F(32, 7);
             case 740: RTO_F(40, 7);
             case 632: RTO_F(32, 6);
             case 432: RTO_F(32, 4);
@@ -1943,7 +1989,11 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
     // measured with the real knob, tuning key blocks_per_cu: 1 / 2 / 3 / 4 / 5 / 6 workgroups per CU take 26.2 / 14.4 /
     // 10.6 / 8.8 / 7.8 / 7.35 ms per 100 frames -- round 2's "4 to 8 waves within 2 %" compared __launch_bounds__ hints,
     // which change the register budget, not the number of resident waves).
-    return launch_batch_impl<SPP, 32, RTO_WPS_DEFAULT>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream);
+    // The two-level traversal image when the tree has one (always, unless it would not fit its index space or the device's
+    // memory: rto_abi.cpp build_wide_image), else the one-level image: the same pixels either way.
+    if (wide)
+        return launch_batch_impl<SPP, 32, RTO_WPS_DEFAULT, true>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream);
+    return launch_batch_impl<SPP, 32, RTO_WPS_DEFAULT, false>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream);
 }
 
 hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,

@@ -70,6 +70,9 @@ int device_of(const void* p) {
 // a hit-list entry packs {slot, count - 1}: at this SPP the tree's leaf slots must fit hit_slot_bits(spp) bits
 // (strictly: the all-ones entry terminates a list)
 bool slots_fit_spp(int64_t n_slots, int spp) { return n_slots < (int64_t(1) << rto::hit_slot_bits(spp)); }
+// a hit entry names a leaf slot -- or, inside the batched traversal, an entry of the two-level image (a slightly larger index
+// space: TreeDev::wide_entries + the slots above the grid levels): both must fit the entry's slot bits at this SPP
+bool tree_fits_spp(const rto_tree* tree, int spp);
 
 bool spp_supported(int spp) {  // volrend.cu:266-278
     return spp == 1 || spp == 2 || spp == 3 || spp == 4 || spp == 6 || spp == 8 || spp == 16 || spp == 32;
@@ -85,6 +88,7 @@ struct rto_tree {
     void* d_child = nullptr;
     void* d_nodew = nullptr;
     void* d_topgrid = nullptr;
+    void *d_widew = nullptr, *d_worig = nullptr, *d_grid2 = nullptr;  // two-level traversal image (build_wide_image)
     void* d_shrec = nullptr;  // aligned copy of the SH coefficients (shading)
     void* d_recidx = nullptr; // RTO_TREE_COMPACT_RECORDS: slot -> record of d_shrec
     void* d_occ = nullptr;    // culling cells (TreeDev::occ_cells)
@@ -128,7 +132,9 @@ struct rto_ctx {
     int last_n_queues = 0;                // of the last batched launch (rto_ctx_queue_stats)
     int64_t last_slots = 0;
     int batch_fallback = 0;               // tuning / test hook, see rto_ctx_set_tuning
-    bool cull_single = true;              // tuning "cull_single": the single-frame kernel culls too (0: round-3 behaviour)
+    bool cull_single = false;             // tuning "cull_single": the single-frame kernel culls too.  Off by default: a LONE frame waits
+                                          // for its longest rays (marked tiles), and the two extra launches cost it 14 us (0.375 ->
+                                          // 0.389 ms); with several frames in flight the skipped work is throughput (+6 %)
     int marks_n = 0, marks_slot0 = 0;     // frames whose tile marks the last launch left in tile_mask (0: none), their first slot
     float marks_bg = 0.f;                 // ... and the background brightness of that launch
     // per-kernel event timing of the batched path (off by default)
@@ -355,6 +361,120 @@ void relay_tree(const std::vector<int64_t>& order, const int32_t* child, const u
     }
 }
 
+// ---- two-level ("wide") traversal image for the batched traversal kernel (round 4) ----
+// The persistent kernel visits one node per loop iteration; 0.65 of its 1.65 visits per march step are descents through
+// internal nodes.  A wide node merges an octree node at level L = G + 2p (G = top-grid levels) with its eight children:
+// 64 words, indexed by TWO bits per axis of the sample point, each holding what the two-level walk below that node ends in --
+//   a leaf at level L (replicated into its 8 entries) or L + 1:  kLeafTag | level << 16 | sigma fp16   (the level rides in the
+//                                                                 word because the entry no longer says which it was)
+//   an internal node at level L + 2:                              the absolute index of ITS wide node
+// so a walk costs one load per TWO levels.  Entry layout inside a wide node: (x2 << 4) | (y2 << 2) | z2 with x2 = the two
+// bits (level L, level L + 1) of x: the eight entries below one child of the node share a 128-byte half.  Derived data:
+// every (point -> leaf level, sigma, original leaf slot) answer equals the walk over child[] (tests/test_wide_image.py).
+// worig[wide node] = its octree node, for translating a hit entry back to the leaf's slot in data[] / shrec[].
+struct WideImage {
+    std::vector<uint32_t> widew, worig;
+    std::vector<uint32_t> grid2;  // {slot-or-unified-hit-index | level << kGridSlotBits, word} per top-grid cell
+    uint32_t n_wide = 0;
+};
+
+template <class SigmaBits>
+bool build_wide_image(const int32_t* child, int64_t capacity, int max_depth, int G, SigmaBits sigma_bits, WideImage& out) {
+    // node ranges of the levels (the tree is stored breadth-first: a level's nodes are contiguous)
+    std::vector<int64_t> start(1, 0), end(1, 1);
+    for (int l = 0; l < 64; ++l) {
+        int64_t hi = end[(size_t)l];
+        for (int64_t n = start[(size_t)l]; n < end[(size_t)l]; ++n)
+            for (int s = 0; s < 8; ++s) {
+                const int32_t c = child[n * 8 + s];
+                if (c != 0 && n + c + 1 > hi) hi = n + c + 1;
+                if (c != 0 && n + c < end[(size_t)l]) return false;  // not breadth-first after all
+            }
+        if (hi == end[(size_t)l]) break;  // no children: the last level
+        start.push_back(end[(size_t)l]);
+        end.push_back(hi);
+        if (hi > capacity) return false;
+    }
+    const int n_levels = (int)start.size();
+    if (n_levels > 25 || G >= n_levels) return false;
+    std::vector<int64_t> pair_base;  // first wide node of pair p
+    int64_t n_wide = 0;
+    for (int L = G; L < n_levels; L += 2) {
+        pair_base.push_back(n_wide);
+        n_wide += end[(size_t)L] - start[(size_t)L];
+    }
+    if (n_wide * 64 + start[(size_t)G] * 8 >= (int64_t(1) << rto::kGridSlotBits)) return false;
+    out.n_wide = (uint32_t)n_wide;
+    out.widew.assign((size_t)n_wide * 64, 0u);
+    out.worig.assign((size_t)n_wide, 0u);
+    auto leafw = [&](int level, int64_t slot) { return rto::kLeafTag | ((uint32_t)level << 16) | (uint32_t)sigma_bits(slot); };
+    auto entry = [](int a, int b) {  // child digits (x most significant) at level L and L + 1 -> position in the wide node
+        const int x2 = ((a >> 2) & 1) << 1 | ((b >> 2) & 1), y2 = ((a >> 1) & 1) << 1 | ((b >> 1) & 1), z2 = (a & 1) << 1 | (b & 1);
+        return x2 << 4 | y2 << 2 | z2;
+    };
+    for (size_t p = 0; p < pair_base.size(); ++p) {
+        const int L = G + 2 * (int)p;
+        for (int64_t N = start[(size_t)L]; N < end[(size_t)L]; ++N) {
+            const int64_t wn = pair_base[p] + (N - start[(size_t)L]);
+            out.worig[(size_t)wn] = (uint32_t)N;
+            uint32_t* w = out.widew.data() + (size_t)wn * 64;
+            for (int a = 0; a < 8; ++a) {
+                const int32_t c = child[N * 8 + a];
+                if (c == 0) {
+                    const uint32_t lw = leafw(L, N * 8 + a);
+                    for (int b = 0; b < 8; ++b) w[entry(a, b)] = lw;
+                    continue;
+                }
+                const int64_t C = N + c;
+                for (int b = 0; b < 8; ++b) {
+                    const int32_t c2 = child[C * 8 + b];
+                    if (c2 == 0) {
+                        w[entry(a, b)] = leafw(L + 1, C * 8 + b);
+                    } else {
+                        const int64_t D = C + c2;  // level L + 2: the first level of the next pair
+                        if (L + 2 >= n_levels || D < start[(size_t)L + 2] || D >= end[(size_t)L + 2]) return false;
+                        w[entry(a, b)] = (uint32_t)(pair_base[p + 1] + (D - start[(size_t)L + 2]));
+                    }
+                }
+            }
+        }
+    }
+    // the top grid again, its words in the wide image's terms (see build_topgrid_kernel): a leaf above level G keeps its
+    // level in the word and gets the hit index n_wide * 64 + slot (a hit entry names a wide entry or, from here on, such a leaf)
+    if (G > 0) {
+        const uint32_t cells = 1u << (3 * G), mask = (1u << G) - 1u;
+        out.grid2.assign((size_t)cells * 2, 0u);
+        for (uint32_t key = 0; key < cells; ++key) {
+            const uint32_t cx = key >> (2 * G), cy = (key >> G) & mask, cz = key & mask;
+            int64_t node = 0, slot = 0;
+            int32_t c = 0;
+            int lvl = 0;
+            for (;;) {
+                const int sh = G - 1 - lvl;
+                const uint32_t ci = (((cx >> sh) & 1u) << 2) | (((cy >> sh) & 1u) << 1) | ((cz >> sh) & 1u);
+                slot = node * 8 + ci;
+                c = child[slot];
+                if (c == 0 || lvl == G - 1) break;
+                node += c;
+                ++lvl;
+            }
+            uint32_t x, y;
+            if (c == 0) {
+                x = (uint32_t)(n_wide * 64 + slot) | ((uint32_t)lvl << rto::kGridSlotBits);
+                y = leafw(lvl, slot);
+            } else {  // internal at level G - 1: its child is a level-G node = a wide node of pair 0
+                const int64_t D = node + c;
+                if (D < start[(size_t)G] || D >= end[(size_t)G]) return false;
+                x = (uint32_t)lvl << rto::kGridSlotBits;
+                y = (uint32_t)(D - start[(size_t)G]);
+            }
+            out.grid2[(size_t)key * 2] = x;
+            out.grid2[(size_t)key * 2 + 1] = y;
+        }
+    }
+    return true;
+}
+
 int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, int N, int data_dim,
                 const rto::DataFormat& fmt, const float scale[3], const float offset[3], int device,
                 rto_tree** out, const rto::HostTree* quant = nullptr, int flags = 0) {
@@ -517,6 +637,39 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
         dev_bytes += gbytes;
     }
 
+    if (t->fast_ok && !getenv("RTO_NO_WIDE")) {  // the two-level traversal image of the batched kernel (build_wide_image)
+        WideImage wi;
+        bool ok;
+        if (quant) {
+            const uint16_t* qs = quant->q_sigma;
+            ok = build_wide_image(child, capacity, max_depth, top_levels, [&](int64_t sl) { return qs[sl]; }, wi);
+        } else {
+            const size_t dd = (size_t)data_dim;
+            ok = build_wide_image(child, capacity, max_depth, top_levels, [&](int64_t sl) { return data[(size_t)sl * dd + dd - 1]; }, wi);
+        }
+        if (ok) {
+            const size_t wb = wi.widew.size() * 4, ob = wi.worig.size() * 4, gb = wi.grid2.size() * 4;
+            bool up = hipMalloc(&t->d_widew, wb) == hipSuccess && hipMalloc(&t->d_worig, ob) == hipSuccess &&
+                      hipMemcpy(t->d_widew, wi.widew.data(), wb, hipMemcpyHostToDevice) == hipSuccess &&
+                      hipMemcpy(t->d_worig, wi.worig.data(), ob, hipMemcpyHostToDevice) == hipSuccess;
+            if (up && gb)
+                up = hipMalloc(&t->d_grid2, gb) == hipSuccess && hipMemcpy(t->d_grid2, wi.grid2.data(), gb, hipMemcpyHostToDevice) == hipSuccess;
+            if (up) {
+                t->dev.widew = (const uint32_t*)t->d_widew;
+                t->dev.worig = (const uint32_t*)t->d_worig;
+                t->dev.topgrid2 = (const uint2*)t->d_grid2;
+                t->dev.wide_entries = wi.n_wide * 64u;
+                dev_bytes += wb + ob + gb;
+            } else {  // not enough memory: the kernel walks the one-level image
+                (void)hipGetLastError();
+                for (void** q : {&t->d_widew, &t->d_worig, &t->d_grid2}) {
+                    if (*q) (void)hipFree(*q);
+                    *q = nullptr;
+                }
+            }
+        }
+    }
+
     if (t->fast_ok && !quant && fmt.format == RTO_FMT_SH && (fmt.basis_dim == 9 || fmt.basis_dim == 16) &&
         !(flags & RTO_TREE_COMPACT)) {
         // aligned copy of the SH coefficients for the shading kernels (+ 64 / 128 B per slot)
@@ -612,12 +765,19 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
     inf.ndc_width = inf.ndc_height = inf.ndc_focal = 0.f;
     inf.max_depth = max_depth;
     inf.device_bytes = (int64_t)dev_bytes;
+    inf.wide_nodes = d.widew ? (int64_t)(d.wide_entries / 64u) : 0;
     *out = t;
     return RTO_OK;
 }
 
 // child[] / data[] of a tree that dropped them at upload, back on the device for the generic kernel (same leaf values:
 // tests/test_render_parity.py::test_generic_kernel_on_a_tree_without_reference_arrays)
+bool tree_fits_spp(const rto_tree* tree, int spp) {
+    const int64_t n_slots = tree->info.capacity * tree->dev.N3;
+    const int64_t wide = tree->dev.widew ? (int64_t)tree->dev.wide_entries + n_slots / 8 : 0;  // (upper bound of the top slots)
+    return slots_fit_spp(n_slots > wide ? n_slots : wide, spp);
+}
+
 int ensure_reference_arrays(const rto_tree* tree) {
     if (!tree->reference_dropped) return RTO_OK;
     rto_tree* t = const_cast<rto_tree*>(tree);  // derived, lazily materialised state of a logically const tree
@@ -869,6 +1029,8 @@ void rto_tree_free(rto_tree* t) {
     if (t->d_child) (void)hipFree(t->d_child);
     if (t->d_nodew) (void)hipFree(t->d_nodew);
     if (t->d_topgrid) (void)hipFree(t->d_topgrid);
+    for (void* q : {t->d_widew, t->d_worig, t->d_grid2})
+        if (q) (void)hipFree(q);
     if (t->d_shrec) (void)hipFree(t->d_shrec);
     if (t->d_recidx) (void)hipFree(t->d_recidx);
     if (t->d_occ) (void)hipFree(t->d_occ);
@@ -1077,6 +1239,61 @@ extern "C" int rto_debug_read_queue(rto_ctx* c, uint64_t out[24]) {
 extern "C" int rto_debug_zero_queue(rto_ctx* c) { return hipMemset(c->queue + 2, 0, 48) == hipSuccess ? 0 : -4; }
 #endif
 
+// Host-only check of the two-level traversal image (no device needed): builds it for child[] (breadth-first node order) and
+// walks it for n points given as 24-bit fixed-point coordinates, exactly as render_persist does (top grid of the wide image,
+// two bits per axis per wide node, hit index -> leaf slot as flush_hits translates it).  out_level / out_slot / out_sigma:
+// the leaf each point lies in.  tests/test_wide_image.py compares them with the plain walk over child[].
+int rto_wide_image_probe(const int32_t* child, const uint16_t* sigma_bits, int64_t capacity, int max_depth, int top_levels,
+                         const uint32_t* points, int64_t n, int32_t* out_level, int64_t* out_slot, uint16_t* out_sigma,
+                         int64_t* out_wide_nodes) {
+    if (!child || !sigma_bits || !points || !out_level || !out_slot || !out_sigma || capacity < 1 || n < 0)
+        return set_err(RTO_E_INVALID, "rto_wide_image_probe: null argument");
+    const int G = top_levels;
+    WideImage wi;
+    if (!build_wide_image(child, capacity, max_depth, G, [&](int64_t sl) { return sigma_bits[sl]; }, wi))
+        return set_err(RTO_E_UNSUPPORTED, "rto_wide_image_probe: the tree has no two-level image (not breadth-first, too deep or too large)");
+    if (out_wide_nodes) *out_wide_nodes = wi.n_wide;
+    // the one-level image's words, for the hit-index translation (nodew: internal = child offset, leaf = tag)
+    auto nodew_leaf = [&](int64_t slot) { return child[slot] == 0; };
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t ix = points[i * 3], iy = points[i * 3 + 1], iz = points[i * 3 + 2];
+        uint32_t w = 0, u = 0, node = 0;  // (render_persist: rs.node = G > 0 ? kGridNext : 0, rs.prev_lvl = 0)
+        int pr = 0;
+        bool grid = G > 0;
+        for (;;) {
+            if (grid) {
+                const uint32_t gs = 24u - (uint32_t)G;
+                const uint32_t key = (((ix >> gs) << G | (iy >> gs)) << G) | (iz >> gs);
+                u = wi.grid2[(size_t)key * 2] & rto::kGridSlotMask;
+                w = wi.grid2[(size_t)key * 2 + 1];
+                pr = -1;
+                grid = false;
+            } else {
+                const uint32_t sh = (22u - (uint32_t)G) - 2u * (uint32_t)pr;
+                u = (((node << 2 | ((ix >> sh) & 3u)) << 2 | ((iy >> sh) & 3u)) << 2) | ((iz >> sh) & 3u);
+                w = wi.widew[u];
+            }
+            if (rto::nodew_is_leaf(w)) break;
+            node = w;  // internal: the wide node two levels down
+            ++pr;
+        }
+        // hit index -> leaf slot (render_kernels.hip wide_to_slot)
+        int64_t slot;
+        if (u >= wi.n_wide * 64u) {
+            slot = (int64_t)(u - wi.n_wide * 64u);
+        } else {
+            const uint32_t wn = u >> 6, x2 = (u >> 4) & 3u, y2 = (u >> 2) & 3u, z2 = u & 3u;
+            const uint32_t a = (x2 >> 1) << 2 | (y2 >> 1) << 1 | (z2 >> 1), b = (x2 & 1u) << 2 | (y2 & 1u) << 1 | (z2 & 1u);
+            const int64_t N = wi.worig[wn];
+            slot = nodew_leaf(N * 8 + a) ? N * 8 + a : (N + child[N * 8 + a]) * 8 + b;
+        }
+        out_level[i] = (int32_t)((w >> 16) & 31u);
+        out_slot[i] = slot;
+        out_sigma[i] = (uint16_t)(w & 0xffffu);
+    }
+    return RTO_OK;
+}
+
 int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value) {
     if (!c || !key) return set_err(RTO_E_INVALID, "rto_ctx_set_tuning: null argument");
     const std::string k(key);
@@ -1191,13 +1408,13 @@ int rto_ctx_enable_stats(rto_ctx* c, int enable) {
     return RTO_OK;
 }
 
-int rto_ctx_get_march_stats(rto_ctx* c, void* stream_, uint64_t out[6], int reset) {
+int rto_ctx_get_march_stats(rto_ctx* c, void* stream_, uint64_t out[8], int reset) {
     if (!c || !out) return set_err(RTO_E_INVALID, "rto_ctx_get_march_stats: null argument");
     if (!c->stats) return set_err(RTO_E_INVALID, "rto_ctx_get_march_stats: counters were never enabled");
     DeviceGuard guard(c->device);
     hipStream_t stream = (hipStream_t)stream_;
-    HIP_TRY(hipMemcpyAsync(out, c->stats + 6, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-    if (reset) HIP_TRY(hipMemsetAsync(c->stats + 6, 0, 6 * sizeof(uint64_t), stream));
+    HIP_TRY(hipMemcpyAsync(out, c->stats + 6, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    if (reset) HIP_TRY(hipMemsetAsync(c->stats + 6, 0, 8 * sizeof(uint64_t), stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return RTO_OK;
 }
@@ -1239,7 +1456,7 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
     if (!(cam->fx != 0.f) || !(cam->fy != 0.f)) return set_err(RTO_E_INVALID, "camera focal length is zero");
 
     int kernel = ctx->kernel;
-    const bool fast_here = tree->fast_ok && slots_fit_spp(tree->info.capacity * tree->dev.N3, o->spp);
+    const bool fast_here = tree->fast_ok && tree_fits_spp(tree, o->spp);
     if (kernel == RTO_KERNEL_AUTO) kernel = fast_here ? RTO_KERNEL_FAST : RTO_KERNEL_GENERIC;
     if (kernel == RTO_KERNEL_FAST && !fast_here)
         return set_err(RTO_E_UNSUPPORTED, "fast kernel needs an N == 2 tree of depth <= 24 whose leaf slots fit 31 - ceil(log2 spp) bits "
@@ -1388,7 +1605,7 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");
     ctx->marks_n = 0;  // whatever happens below, the tile marks of an earlier launch no longer describe this context's frames
-    if (!tree->fast_ok || !slots_fit_spp(tree->info.capacity * tree->dev.N3, o->spp) || ctx->batch_fallback == 1) {
+    if (!tree->fast_ok || !tree_fits_spp(tree, o->spp) || ctx->batch_fallback == 1) {
         // No traversal image (N != 2, depth > 24, >= 2^29 leaf slots: the top-grid entry's budget) or more slots than a
         // hit-list entry can name at this SPP (2^28 at spp <= 8, 2^26 at spp 32): the same frames, one launch of the
         // generic kernel each -- same images, without the batching gain.

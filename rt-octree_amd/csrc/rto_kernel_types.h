@@ -48,6 +48,14 @@ struct TreeDev {
     // above level G costs this one 8-byte, L2-resident load.  nullptr / 0 when absent.
     const uint2* topgrid;
     int top_levels;
+    // Two-level traversal image of the batched kernel (rto_abi.cpp build_wide_image; nullptr: absent).  widew[wide node * 64 +
+    // (x2 << 4 | y2 << 2 | z2)]: leaf = kLeafTag | level << 16 | sigma fp16, internal = index of the wide node two levels
+    // down; topgrid2 = the top grid in the same terms; worig[wide node] = its octree node; wide_entries = wide nodes * 64
+    // (hit indices at and above it name the slots of leaves above the grid levels)
+    const uint32_t* widew;
+    const uint2* topgrid2;
+    const uint32_t* worig;
+    uint32_t wide_entries;
     // Aligned copy of the SH coefficients for shading (dense SH9 / SH16 trees, N == 2; SH25 gains nothing from it and
     // keeps data[]): per slot the 3 B coefficients in data[]'s order, zero-padded to 64 B (SH9) / 128 B (SH16) so that
     // a record is ONE 128-byte line fetched by 16-byte loads; nullptr when absent (shading then reads data[]).  When it
@@ -163,7 +171,8 @@ struct FrameOut {
 // stats[0..5] = SURVEY 8d's units over EVERY ray (orc_stats order: rays, rays_in_box, steps, levels of a root-restart walk,
 // hit leaves, rays with a hit); stats[6..11] = the same frame as the batched path works through it: rays of marked tiles,
 // their march steps, top-grid entries loaded (8 B each), traversal-image words loaded (4 B each), hit entries written,
-// rays of marked tiles that entered the volume
-constexpr int kStatsWords = 12;
+// rays of marked tiles that entered the volume, entries of the two-level image loaded (4 B each: what render_persist loads
+// instead of the traversal-image words when the tree has that image)
+constexpr int kStatsWords = 14;
 
 }  // namespace rto

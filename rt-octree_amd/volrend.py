@@ -172,6 +172,7 @@ class N3Tree:
         self.ndc_width, self.ndc_height, self.ndc_focal = info.ndc_width, info.ndc_height, info.ndc_focal
         self.max_depth = info.max_depth
         self.device_bytes = info.device_bytes
+        self.wide_nodes = info.wide_nodes
 
     def set_ndc(self, width, height, focal):
         """main_headless.cpp:400-405: tree.use_ndc = true; ndc_width/height/focal."""
@@ -324,7 +325,7 @@ class RenderContext:
         return self._timer
 
     def set_tuning(self, key, value):
-        """performance knobs ("strip_rows", "refill", "tile_order", "xcd_queues", "tile_major", "tile_block", "blocks_per_cu", "cull");
+        """performance knobs ("strip_rows", "refill", "tile_order", "xcd_queues", "tile_major", "tile_block", "blocks_per_cu", "cull", "cull_single");
         results never change"""
         check(lib().rto_ctx_set_tuning(self._h, key.encode("ascii"), int(value)))
 
@@ -357,9 +358,9 @@ class RenderContext:
         check(lib().rto_ctx_enable_stats(self._h, 2 if (on and marched) else int(bool(on))))
 
     def get_march_stats(self, reset=True, stream=None):
-        out = (C.c_uint64 * 6)()
+        out = (C.c_uint64 * 8)()
         check(lib().rto_ctx_get_march_stats(self._h, _stream_ptr(stream), out, int(bool(reset))))
-        keys = ("rays", "steps", "grid_loads", "node_loads", "hit_entries", "rays_in_box")
+        keys = ("rays", "steps", "grid_loads", "node_loads", "hit_entries", "rays_in_box", "wide_loads")
         return {k: int(out[i]) for i, k in enumerate(keys)}
 
     def get_stats(self, reset=True, stream=None):

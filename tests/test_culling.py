@@ -167,7 +167,7 @@ def test_march_counters_count_the_batched_paths_own_work():
 
 
 def test_single_frame_kernel_culls_and_renders_the_same_pixels():
-    """round 4 (VERDICT r3 task 6): rto_launch_renderer's fast kernel skips the 8x8 tiles no culling cell projects into --
+    """round 4 (VERDICT r3 task 6; tuning key cull_single, off by default): rto_launch_renderer's fast kernel skips the 8x8 tiles no culling cell projects into --
     frames bit-identical with the tuning key off, with the generic kernel and with the oracle, over the same stress
     poses as the batched path; the marks it leaves serve the culled denoise stage (slot = the selected one)."""
     tree = synth.make_tree(depth_limit=8, basis_dim=9, seed=21, shell=2.0)

@@ -190,11 +190,14 @@ def test_one_call_denoise_equals_the_separate_calls(scene, mode):
     net.denoise(ctx, n, fmode)
     torch.cuda.synchronize()
     assert_bits_equal(images(ctx, n).cpu().numpy(), want.cpu().numpy(), "rto_denoise after a batched launch, " + mode)
-    # a single frame into slot 2: its own marks (round 4: the single-frame kernel culls too), same pixels as slot 2 of the
-    # batch (same camera, same RNG jump)
+    # a single frame into slot 2, with its own marks (round 4: the single-frame kernel culls too when asked), same pixels as
+    # slot 2 of the batch (same camera, same RNG jump)
     ctx.select_frame(2)
     ctx.rng_seed()
     ctx.rng_advance(2 << 32)
+    R.launch_renderer(dt, cams[2], opt, ctx)
+    assert ctx.tile_marks() is None  # (default: the lone frame does not cull)
+    ctx.set_tuning("cull_single", 1)
     R.launch_renderer(dt, cams[2], opt, ctx)
     assert ctx.tile_marks()[2:4] == (2, 1)  # first slot 2, one frame
     torch.as_tensor(ctx.batch_views()[2], device="cuda:0")[2].fill_(-7.0)

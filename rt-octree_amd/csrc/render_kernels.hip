@@ -1357,12 +1357,24 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     const uint32_t hsh = key * 0x9E3779B1u;
                     const uint32_t glv = 2u + (hsh >> 30);
                     slot = (key << 3) & kGridSlotMask;
-                    rs.prev_lvl = (int)glv;
-                    rs.node = slot >> 3;
-                    w = (glv == 5u && (hsh & 0x100u)) ? 1u : (kLeafTag | ((hsh & 0x600u) ? 0u : 0x4D00u));
+                    const uint32_t sg = (hsh & 0x600u) ? 0u : 0x4D00u;
+                    if constexpr (WIDE) {  // (leaf words carry their level; an internal word is the wide node below)
+                        rs.prev_lvl = -1;
+                        w = (glv == 5u && (hsh & 0x100u)) ? ((hsh >> 8) & 0xffffu) | 1u : (kLeafTag | glv << 16 | sg);
+                    } else {
+                        rs.prev_lvl = (int)glv;
+                        rs.node = slot >> 3;
+                        w = (glv == 5u && (hsh & 0x100u)) ? 1u : (kLeafTag | sg);
+                    }
                 } else {
                     const uint32_t hsh = slot * 0x9E3779B1u;
-                    w = (rs.prev_lvl < 9 && (hsh >> 29) < 3u) ? 1u : (kLeafTag | ((hsh & 0x600u) ? 0u : 0x4D00u));
+                    const uint32_t sg = (hsh & 0x600u) ? 0u : 0x4D00u;
+                    if constexpr (WIDE) {  // two pairs below the grid (levels 6..9), leaves at either level of a pair
+                        const uint32_t lv = (uint32_t)G + 2u * (uint32_t)rs.prev_lvl + ((hsh >> 27) & 1u);
+                        w = (rs.prev_lvl < 1 && (hsh >> 29) < 5u) ? ((hsh >> 8) & 0xffffu) | 1u : (kLeafTag | lv << 16 | sg);
+                    } else {
+                        w = (rs.prev_lvl < 9 && (hsh >> 29) < 3u) ? 1u : (kLeafTag | sg);
+                    }
                 }
 #else
                 if (grid) {  // the iteration's one load: 8 bytes of the top grid ...

@@ -206,3 +206,35 @@ def test_single_frame_kernel_culls_and_renders_the_same_pixels():
             aux_o, rgba_o, _ = orc.render_frame(ht, ocam, orc.default_options(spp=6), orc.rng(frame=100 + i))
             assert_bits_equal(got["cull"][0], aux_o, "aux vs oracle, pose %d" % i)
     assert culled_some >= 8  # the orbit poses see an object in empty space: tiles were really skipped
+
+
+def test_two_level_and_one_level_traversal_images_render_the_same_frames(monkeypatch):
+    """round 4: the batched kernel walks the two-level image (one load per two levels); a tree uploaded without it
+    (RTO_NO_WIDE, or a tree too large for the image's index space) walks the one-level image -- the same frames, bit for bit,
+    and the oracle's."""
+    tree = synth.make_tree(depth_limit=8, basis_dim=9, seed=21, shell=2.0)
+    ht, dt_wide = make_pair(tree)
+    monkeypatch.setenv("RTO_NO_WIDE", "1")
+    dt_narrow = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+    monkeypatch.delenv("RTO_NO_WIDE")
+    assert dt_wide.wide_nodes == tree.stats["levels"][6] and dt_narrow.wide_nodes == 0
+    assert dt_wide.device_bytes > dt_narrow.device_bytes
+    W, H = 200, 136
+    poses = _poses()
+    cams = []
+    for p in poses:
+        c = R.Camera(W, H, 260.0, 260.0)
+        c.set_c2w(p)
+        cams.append(c)
+    ctx = R.RenderContext(W, H, frames=len(cams))
+    jumps = list(range(100, 100 + len(cams)))
+    for spp in (6, 32):
+        a, _ = _render(dt_wide, cams, spp, True, ctx, jumps)
+        b, _ = _render(dt_narrow, cams, spp, True, ctx, jumps)
+        for f in range(len(cams)):
+            assert_bits_equal(a[f][0], b[f][0], "aux, frame %d, spp %d" % (f, spp))
+            assert_bits_equal(a[f][1], b[f][1], "image, frame %d, spp %d" % (f, spp))
+        for f in (0, 12, 13):
+            ocam = orc.camera(W, H, 260.0, 260.0, cams[f].transform.reshape(-1))
+            aux_o, _, _ = orc.render_frame(ht, ocam, orc.default_options(spp=spp), orc.rng(frame=jumps[f]))
+            assert_bits_equal(a[f][0], aux_o, "aux vs oracle, frame %d, spp %d" % (f, spp))

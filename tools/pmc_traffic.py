@@ -53,7 +53,7 @@ def main():
         # the traversal loop itself with both gathers stubbed (-DRTO_STUB_LOADS): what ITS instruction stream sustains with no
         # memory in the way; the ceiling quoted is the larger of the two
         import glob
-        stubs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r3_*_stubbed_loads_pmc.json")))  # (the latest bundle's)
+        stubs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_stubbed_loads_pmc.json")))  # (the latest bundle's)
         stub = stubs[-1] if stubs else ""
         vc = doc["valu_ceiling"]
         vc["ceiling_insts_per_clk_per_simd"] = vc["traversal_mix_insts_per_clk_per_simd"]

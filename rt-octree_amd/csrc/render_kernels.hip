@@ -534,10 +534,21 @@ RTO_DEV void shade_leaf_packed(const TreeDev& tree, uint32_t slot, const float* 
     out[3] += cnt;
 }
 
+// hit index of the wide image -> the leaf's slot in data[] / shrec[] (what a hit entry names): an entry of a wide node is
+// child a of its octree node (when that is a leaf) or child b of that child; indices from wide_entries on are the slots of
+// leaves above the grid levels themselves
+RTO_DEV uint32_t wide_to_slot(const TreeDev& tree, uint32_t u) {
+    if (u >= tree.wide_entries) return u - tree.wide_entries;
+    const uint32_t wn = u >> 6, x2 = (u >> 4) & 3u, y2 = (u >> 2) & 3u, z2 = u & 3u;
+    const uint32_t a = (x2 >> 1) << 2 | (y2 >> 1) << 1 | (z2 >> 1), b = (x2 & 1u) << 2 | (y2 & 1u) << 1 | (z2 & 1u);
+    const uint32_t N = tree.worig[wn];
+    const uint32_t w0 = tree.nodew[N * 8u + a];
+    return nodew_is_leaf(w0) ? N * 8u + a : (N + w0) * 8u + b;
+}
 // STATS: also count the units of SURVEY 8(d)'s algorithmic-byte formula (march steps, descent
 // levels a root-restart walk would visit, distinct hit leaves, ...) into fo.stats.  Separate
 // instantiation; the timed kernel carries none of it.
-template <int SPP, bool STATS>
+template <int SPP, bool STATS, bool WIDE>
 __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const CamDev cam, const OptDev opt,
                                                     const Pcg32 rng_base, const PcgJumpEntry* __restrict__ jump,
                                                     const TileMap tm, const FrameOut fo) {
@@ -611,6 +622,37 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
             lvl = lvl < prev_lvl ? lvl : prev_lvl;
             uint32_t node, w, slot;
             bool have_w = false;
+            if constexpr (WIDE) {
+                // the two-level image (rto_abi.cpp build_wide_image; round 4): one load per TWO levels below the grid -- a lone
+                // frame waits for the dependent-load chains of its longest rays, and this shortens every one of them
+                int pr = 0;  // the pair of levels (G + 2 pr, G + 2 pr + 1) the wide node `node` spans
+                if (lvl < G) {
+                    const uint32_t gs = 24u - (uint32_t)G;
+                    const uint32_t key = (((ix >> gs) << G | (iy >> gs)) << G) | (iz >> gs);
+                    const uint2 e = tree.topgrid2[key];
+                    slot = e.x & kGridSlotMask;  // (the hit index of a leaf above the grid levels)
+                    w = e.y;
+                    have_w = true;
+                    pr = -1;
+                    node = 0u;
+                } else {
+                    pr = (lvl - G) >> 1;
+                    node = (pr | G) ? stack[pr * 256] : 0u;  // (no grid and pair 0: the root)
+                }
+                for (;;) {
+                    if (!have_w) {
+                        const int sh = 22 - G - 2 * pr;
+                        slot = (((node << 2 | ((ix >> sh) & 3u)) << 2 | ((iy >> sh) & 3u)) << 2) | ((iz >> sh) & 3u);
+                        w = tree.widew[slot];
+                    }
+                    have_w = false;
+                    if (nodew_is_leaf(w)) break;
+                    node = w;  // the wide node two levels down
+                    ++pr;
+                    stack[pr * 256] = node;
+                }
+                lvl = (int)((w >> 16) & 31u);  // a leaf word of the wide image carries its level
+            } else {
             if (lvl < G) {
                 // restart above the shortcut levels: ONE 8-byte lookup replaces the walk over node levels
                 // 0..G-1 (a chain of dependent loads -- what a lone frame's long rays wait for) and
@@ -647,6 +689,7 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
                 node += w;  // two's complement add of the relative offset
                 ++lvl;
                 stack[lvl * 256] = node;
+            }
             }
             pix = ix;
             piy = iy;
@@ -698,7 +741,8 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
 #pragma unroll
             for (int i = 0; i < SPP; ++i) {
                 if (i < (int)sh_nums) {
-                    const uint32_t slot = hit_slot<SPP>(hits[i]);
+                    uint32_t slot = hit_slot<SPP>(hits[i]);
+                    if constexpr (WIDE) slot = wide_to_slot(tree, slot);  // hit index of the wide image -> the leaf's slot
                     const float cnt = (float)hit_count<SPP>(hits[i]);
                     if (tree.format == 1 && tree.data_dim == 28)
                         shade_leaf_packed<28>(tree, slot, basis_fn, cnt, out);
@@ -1050,17 +1094,6 @@ __global__ void __launch_bounds__(256) sample_kernel(const FrameBatch fb, const 
 // plane, entries 1.. as one contiguous run (4 * (n - 1) bytes of ONE 32-byte sector for SPP <= 9), back to back, instead of
 // one 4-byte store per hit at the moment it happens (71.6 M scattered dwords per 100 frames cost 2.48 GB of line-granular
 // HBM writes for 0.29 GB of payload: the L2 had evicted the sector long before the pixel's next entry arrived).
-// hit index of the wide image -> the leaf's slot in data[] / shrec[] (what a hit entry names): an entry of a wide node is
-// child a of its octree node (when that is a leaf) or child b of that child; indices from wide_entries on are the slots of
-// leaves above the grid levels themselves
-RTO_DEV uint32_t wide_to_slot(const TreeDev& tree, uint32_t u) {
-    if (u >= tree.wide_entries) return u - tree.wide_entries;
-    const uint32_t wn = u >> 6, x2 = (u >> 4) & 3u, y2 = (u >> 2) & 3u, z2 = u & 3u;
-    const uint32_t a = (x2 >> 1) << 2 | (y2 >> 1) << 1 | (z2 >> 1), b = (x2 & 1u) << 2 | (y2 & 1u) << 1 | (z2 & 1u);
-    const uint32_t N = tree.worig[wn];
-    const uint32_t w0 = tree.nodew[N * 8u + a];
-    return nodew_is_leaf(w0) ? N * 8u + a : (N + w0) * 8u + b;
-}
 template <int SPP, bool WIDE>
 RTO_DEV void flush_hits(RayState& rs, const TreeDev& tree, uint32_t* __restrict__ hits, const float* s_col, uint32_t hstride) {
     uint32_t e[SPP];
@@ -1832,10 +1865,12 @@ static hipError_t launch_spp(int kernel, const TreeDev& tree, const CamDev& cam,
         const TileMap tm = make_tile_map(cam.width, cam.height, strip_rows);
         const size_t lds = (size_t)(tree.max_depth + 1) * 256 * sizeof(uint32_t);
         const dim3 grid(8 * tm.per_xcd), block(256);
-        if (fo.stats)
-            hipLaunchKernelGGL((render_fast<SPP, true>), grid, block, lds, stream, tree, cam, opt, rng, jump, tm, fo);
+        if (fo.stats)  // (the counting instantiation walks the one-level image: its units are defined on that walk)
+            hipLaunchKernelGGL((render_fast<SPP, true, false>), grid, block, lds, stream, tree, cam, opt, rng, jump, tm, fo);
+        else if (tree.widew)
+            hipLaunchKernelGGL((render_fast<SPP, false, true>), grid, block, lds, stream, tree, cam, opt, rng, jump, tm, fo);
         else
-            hipLaunchKernelGGL((render_fast<SPP, false>), grid, block, lds, stream, tree, cam, opt, rng, jump, tm, fo);
+            hipLaunchKernelGGL((render_fast<SPP, false, false>), grid, block, lds, stream, tree, cam, opt, rng, jump, tm, fo);
     } else {
         const int64_t size = (int64_t)cam.width * cam.height;
         hipLaunchKernelGGL(render_generic<SPP>, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, stream, tree, cam,

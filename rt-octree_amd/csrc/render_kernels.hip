@@ -534,17 +534,19 @@ RTO_DEV void shade_leaf_packed(const TreeDev& tree, uint32_t slot, const float* 
     out[3] += cnt;
 }
 
-// hit index of the wide image -> the leaf's slot in data[] / shrec[] (what a hit entry names): an entry of a wide node is
-// child a of its octree node (when that is a leaf) or child b of that child; indices from wide_entries on are the slots of
-// leaves above the grid levels themselves
+// hit index of the wide image (= the index of the leaf's entry) -> the leaf's slot in data[] / shrec[] (what a hit entry
+// names): a grid cell's leaf through wgslot; an entry of a wide node is child a of its octree node (when that is a leaf) or
+// child b of that child
 RTO_DEV uint32_t wide_to_slot(const TreeDev& tree, uint32_t u) {
-    if (u >= tree.wide_entries) return u - tree.wide_entries;
-    const uint32_t wn = u >> 6, x2 = (u >> 4) & 3u, y2 = (u >> 2) & 3u, z2 = u & 3u;
+    const uint32_t pad = tree.wide_grid_nodes * 64u;
+    if (u < pad) return tree.wgslot[u];  // a leaf cell of the top grid
+    const uint32_t v = u - pad, wn = v >> 6, x2 = (v >> 4) & 3u, y2 = (v >> 2) & 3u, z2 = v & 3u;
     const uint32_t a = (x2 >> 1) << 2 | (y2 >> 1) << 1 | (z2 >> 1), b = (x2 & 1u) << 2 | (y2 & 1u) << 1 | (z2 & 1u);
     const uint32_t N = tree.worig[wn];
     const uint32_t w0 = tree.nodew[N * 8u + a];
     return nodew_is_leaf(w0) ? N * 8u + a : (N + w0) * 8u + b;
 }
+
 // STATS: also count the units of SURVEY 8(d)'s algorithmic-byte formula (march steps, descent
 // levels a root-restart walk would visit, distinct hit leaves, ...) into fo.stats.  Separate
 // instantiation; the timed kernel carries none of it.
@@ -607,6 +609,7 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
         int prev_lvl = 0;
         uint32_t* stack = s_stack + tid;
         const int G = tree.top_levels;  // 0: no top grid
+        if (WIDE && G == 0) stack[0] = 0u;
 
         while (t < tmax) {
             float pos[3] = {cen[0] + t * dir[0], cen[1] + t * dir[1], cen[2] + t * dir[2]};
@@ -625,32 +628,26 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
             if constexpr (WIDE) {
                 // the two-level image (rto_abi.cpp build_wide_image; round 4): one load per TWO levels below the grid -- a lone
                 // frame waits for the dependent-load chains of its longest rays, and this shortens every one of them
-                int pr = 0;  // the pair of levels (G + 2 pr, G + 2 pr + 1) the wide node `node` spans
-                if (lvl < G) {
-                    const uint32_t gs = 24u - (uint32_t)G;
-                    const uint32_t key = (((ix >> gs) << G | (iy >> gs)) << G) | (iz >> gs);
-                    const uint2 e = tree.topgrid2[key];
-                    slot = e.x & kGridSlotMask;  // (the hit index of a leaf above the grid levels)
-                    w = e.y;
-                    have_w = true;
-                    pr = -1;
-                    node = 0u;
-                } else {
+                // (node, off): (0, 24 - G) = the top grid, whose cells are indexed by G bits per axis; else the wide node of the
+                // pair (G + 2 pr, G + 2 pr + 1), two bits per axis from bit 22 - G - 2 pr on.  One array holds both.
+                int pr = -1;
+                node = 0u;
+                if (lvl >= G) {
                     pr = (lvl - G) >> 1;
-                    node = (pr | G) ? stack[pr * 256] : 0u;  // (no grid and pair 0: the root)
+                    node = stack[pr * 256];
+                    if (node == 0u) pr = -1;  // (no grid levels, first step: stack[0] still holds the 0 it was given)
                 }
                 for (;;) {
-                    if (!have_w) {
-                        const int sh = 22 - G - 2 * pr;
-                        slot = (((node << 2 | ((ix >> sh) & 3u)) << 2 | ((iy >> sh) & 3u)) << 2) | ((iz >> sh) & 3u);
-                        w = tree.widew[slot];
-                    }
-                    have_w = false;
+                    const uint32_t b = node ? 2u : (uint32_t)G, msk = (1u << b) - 1u;
+                    const uint32_t off = node ? (uint32_t)(22 - G - 2 * pr) : 24u - (uint32_t)G;
+                    slot = (((node << b | ((ix >> off) & msk)) << b | ((iy >> off) & msk)) << b) | ((iz >> off) & msk);
+                    w = tree.widew[slot];
                     if (nodew_is_leaf(w)) break;
                     node = w;  // the wide node two levels down
                     ++pr;
                     stack[pr * 256] = node;
                 }
+                (void)have_w;
                 lvl = (int)((w >> 16) & 31u);  // a leaf word of the wide image carries its level
             } else {
             if (lvl < G) {
@@ -820,7 +817,8 @@ struct RayState {
     uint32_t hoff, hnext;  // index of this pixel's next free hit entry in the hand-off buffer, and of the one behind it
                            // (staged hit lists, the default: of its entries 0 and 1, fixed for the ray's life)
     uint32_t nh;           // staged hit lists: hit entries of this ray parked in LDS, not yet written out
-    uint32_t node;  // node about to be visited; kGridNext = the top grid is visited next
+    uint32_t node;  // node about to be visited; kGridNext = the top grid is visited next (two-level image: 0 = the grid)
+    uint32_t woff;  // two-level image: lowest of the coordinate bits that index the node about to be visited
     float cxy __attribute__((ext_vector_type(2)));  // cen[0], cen[1] as a register pair for the packed march arithmetic
     // _dda_unit's max(t1, t1 + invdir) per axis is t1 + (invdir > 0 ? invdir : 0): the sign of invdir is the ray's, not the
     // step's (exit_add below)
@@ -1164,7 +1162,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     typedef const __attribute__((address_space(1))) uint32_t* gptr_t;  // keep global_load (not flat_load)
     // WIDE: the two-level image and its top grid (rto_abi.cpp build_wide_image) instead of the one-level ones
     const uint32_t* nodew_p = WIDE ? tree.widew : tree.nodew;
-    const uint2* topgrid_p = WIDE ? tree.topgrid2 : tree.topgrid;
+    const uint2* topgrid_p = tree.topgrid;  // (WIDE: unused -- the grid cells are the first entries of the two-level image)
     const uint32_t* __restrict__ qlist = fb.qlist;
     float step_size = opt.step_size, sigma_thresh = opt.sigma_thresh;
     asm volatile("" : "+s"(nodew_p), "+s"(topgrid_p), "+s"(step_size), "+s"(sigma_thresh));
@@ -1299,7 +1297,8 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                                 rs.pix = (uint32_t)(rs.pos[0] * 16777216.f);
                                 rs.piy = (uint32_t)(rs.pos[1] * 16777216.f);
                                 rs.piz = (uint32_t)(rs.pos[2] * 16777216.f);
-                                rs.node = G > 0 ? kGridNext : 0u;
+                                rs.node = WIDE ? 0u : (G > 0 ? kGridNext : 0u);
+                                rs.woff = 24u - (uint32_t)G;
                             }
                         } else {
                             rs.tmax = -1.f;  // missed the box (ray_enter wrote a tmax that the stale t might undercut)
@@ -1325,23 +1324,49 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
             if (active) {
 #endif
                 RTO_DBG_AT(0)
+                uint32_t slot, w;
+                if constexpr (WIDE) {
+                    // Round 4: ONE array holds the top grid and the two-level ("wide") nodes below it (rto_abi.cpp
+                    // build_wide_image), so a node visit is ONE uniform load: entry = ((node << b | x bits) << b | y bits) << b |
+                    // z bits, b bits per axis from bit rs.woff on -- (node, b, woff) = (0, G, 24 - G) at the grid,
+                    // (node number, 2, 22 - G - 2 p) at the wide node of the levels (G + 2p, G + 2p + 1).  v_bfe_u32 and
+                    // v_lshl_or_b32 take the per-lane widths: no grid / node case split, no second address, no branch pair
+                    // around two loads (the one-level walk below spends 19 VALU + 7 SALU where this spends 10 VALU).
+                    const uint32_t b = rs.node ? 2u : (uint32_t)G;
+                    slot = (rs.node << b) | __builtin_amdgcn_ubfe(rs.pix, rs.woff, b);
+                    slot = (slot << b) | __builtin_amdgcn_ubfe(rs.piy, rs.woff, b);
+                    slot = (slot << b) | __builtin_amdgcn_ubfe(rs.piz, rs.woff, b);
+                    if (rs.node == 0u) { RTO_DBG_AT(7) }
+#ifdef RTO_STUB_LOADS
+                    {   // calibration build (tools/calibrate_valu.sh): the gather replaced by a hash of its address
+                        const uint32_t hsh = slot * 0x9E3779B1u;
+                        const uint32_t sg = (hsh & 0x600u) ? 0u : 0x4D00u;
+                        if (rs.node == 0u) {
+                            const uint32_t glv = 2u + (hsh >> 30);
+                            w = (glv == 5u && (hsh & 0x100u)) ? ((hsh >> 8) & 0xffffu) | 1u : (kLeafTag | glv << 16 | sg);
+                        } else {  // two pairs below the grid (levels G .. G + 3), leaves at either level of a pair
+                            const uint32_t lv = 22u - rs.woff + ((hsh >> 27) & 1u);
+                            w = (rs.woff == 22u - (uint32_t)G && (hsh >> 29) < 5u) ? ((hsh >> 8) & 0xffffu) | 1u : (kLeafTag | lv << 16 | sg);
+                        }
+                    }
+#else
+                    w = nodew[slot];  // (through the L1: non-temporal loads cost 15-50 %)
+#endif
+                    if ((int32_t)w >= -(1 << 30)) {  // internal: two levels down (from the grid: into the level-G node)
+                        RTO_DBG_AT(1)
+                        rs.node = w;
+                        stack[(((24u - (uint32_t)G) - rs.woff) >> 1) * 256u] = w;  // row p + 1 of the pair it spans (grid: row 0)
+                        rs.woff -= 2u;
+                    }
+                }
+                if constexpr (!WIDE) {
                 const bool grid = rs.node == kGridNext;
                 const uint32_t gs = 24u - (uint32_t)G;
                 const uint32_t key = (((rs.pix >> gs) << G | (rs.piy >> gs)) << G) | (rs.piz >> gs);
-                uint32_t slot;
-                if constexpr (WIDE) {
-                    // rs.prev_lvl = the pair p of the wide node about to be visited: two bits per axis, levels G + 2p and G + 2p + 1
-                    const uint32_t sh = (22u - (uint32_t)G) - 2u * (uint32_t)rs.prev_lvl;
-                    slot = (rs.node << 2) | __builtin_amdgcn_ubfe(rs.pix, sh, 2u);  // wide node * 64 + (x2 << 4 | y2 << 2 | z2)
-                    slot = (slot << 2) | __builtin_amdgcn_ubfe(rs.piy, sh, 2u);
-                    slot = (slot << 2) | __builtin_amdgcn_ubfe(rs.piz, sh, 2u);
-                } else {
-                    const uint32_t sh = 23u - (uint32_t)rs.prev_lvl;
-                    slot = (rs.node << 1) | __builtin_amdgcn_ubfe(rs.pix, sh, 1u);  // node * 8 + child digit,
-                    slot = (slot << 1) | __builtin_amdgcn_ubfe(rs.piy, sh, 1u);       // three v_lshl_or
-                    slot = (slot << 1) | __builtin_amdgcn_ubfe(rs.piz, sh, 1u);
-                }
-                uint32_t w;
+                const uint32_t sh = 23u - (uint32_t)rs.prev_lvl;
+                slot = (rs.node << 1) | __builtin_amdgcn_ubfe(rs.pix, sh, 1u);  // node * 8 + child digit,
+                slot = (slot << 1) | __builtin_amdgcn_ubfe(rs.piy, sh, 1u);       // three v_lshl_or
+                slot = (slot << 1) | __builtin_amdgcn_ubfe(rs.piz, sh, 1u);
 #ifdef RTO_DBG_GRIDUNIQ
                 {  // how many distinct top-grid cells / nodew lines does one wave-level load touch?
                     unsigned long long rem = __ballot(grid);
@@ -1391,34 +1416,20 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     const uint32_t glv = 2u + (hsh >> 30);
                     slot = (key << 3) & kGridSlotMask;
                     const uint32_t sg = (hsh & 0x600u) ? 0u : 0x4D00u;
-                    if constexpr (WIDE) {  // (leaf words carry their level; an internal word is the wide node below)
-                        rs.prev_lvl = -1;
-                        w = (glv == 5u && (hsh & 0x100u)) ? ((hsh >> 8) & 0xffffu) | 1u : (kLeafTag | glv << 16 | sg);
-                    } else {
-                        rs.prev_lvl = (int)glv;
-                        rs.node = slot >> 3;
-                        w = (glv == 5u && (hsh & 0x100u)) ? 1u : (kLeafTag | sg);
-                    }
+                    rs.prev_lvl = (int)glv;
+                    rs.node = slot >> 3;
+                    w = (glv == 5u && (hsh & 0x100u)) ? 1u : (kLeafTag | sg);
                 } else {
                     const uint32_t hsh = slot * 0x9E3779B1u;
                     const uint32_t sg = (hsh & 0x600u) ? 0u : 0x4D00u;
-                    if constexpr (WIDE) {  // two pairs below the grid (levels 6..9), leaves at either level of a pair
-                        const uint32_t lv = (uint32_t)G + 2u * (uint32_t)rs.prev_lvl + ((hsh >> 27) & 1u);
-                        w = (rs.prev_lvl < 1 && (hsh >> 29) < 5u) ? ((hsh >> 8) & 0xffffu) | 1u : (kLeafTag | lv << 16 | sg);
-                    } else {
-                        w = (rs.prev_lvl < 9 && (hsh >> 29) < 3u) ? 1u : (kLeafTag | sg);
-                    }
+                    w = (rs.prev_lvl < 9 && (hsh >> 29) < 3u) ? 1u : (kLeafTag | sg);
                 }
 #else
                 if (grid) {  // the iteration's one load: 8 bytes of the top grid ...
                     const u32x2 e = *pg;  // (through the L1 as well: non-temporal costs 15 %)
                     slot = e.x & kGridSlotMask;
-                    if constexpr (WIDE) {
-                        rs.prev_lvl = -1;  // (an internal entry names the wide node of pair 0: the descent below makes it 0)
-                    } else {
-                        rs.prev_lvl = (int)(e.x >> kGridSlotBits);
-                        rs.node = slot >> 3;
-                    }
+                    rs.prev_lvl = (int)(e.x >> kGridSlotBits);
+                    rs.node = slot >> 3;
                     w = e.y;
                 } else {  // ... or 4 bytes of the traversal image
                     w = *pn;  // (through the L1: a non-temporal load here costs 50 %)
@@ -1427,10 +1438,12 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                 if (grid) { RTO_DBG_AT(7) }
                 if ((int32_t)w >= -(1 << 30)) {  // internal: one level down
                     RTO_DBG_AT(1)
-                    rs.node = WIDE ? w : rs.node + w;  // (WIDE: the absolute index of the wide node two levels down)
+                    rs.node += w;
                     ++rs.prev_lvl;
                     stack_g[rs.prev_lvl * 256] = rs.node;
-                } else {  // leaf: the march step (rt_core.cuh:241-270)
+                }
+                }  // (!WIDE)
+                if ((int32_t)w < -(1 << 30)) {  // leaf: the march step (rt_core.cuh:241-270)
 #ifdef RTO_LEAF_K
                     pend_w = w;  // postponed: the lane waits at its leaf until enough lanes of the wave have reached one
                     pend_slot = slot;

@@ -372,10 +372,13 @@ void relay_tree(const std::vector<int64_t>& order, const int32_t* child, const u
 // bits (level L, level L + 1) of x: the eight entries below one child of the node share a 128-byte half.  Derived data:
 // every (point -> leaf level, sigma, original leaf slot) answer equals the walk over child[] (tests/test_wide_image.py).
 // worig[wide node] = its octree node, for translating a hit entry back to the leaf's slot in data[] / shrec[].
+// ONE array holds the top grid and the wide nodes: entries [0, 8^G) are the grid cells (the "root node": G bits per axis),
+// padded to whole nodes of 64; wide node k is node number grid_nodes + k of that array.  A walk is then uniform -- entry index
+// = ((node << b | x bits) << b | y bits) << b | z bits with (node, b) = (0, G) at the grid and (node number, 2) below -- and an
+// entry's index doubles as the hit index of its leaf.  gslot[grid cell] = the slot of a leaf cell above the grid levels.
 struct WideImage {
-    std::vector<uint32_t> widew, worig;
-    std::vector<uint32_t> grid2;  // {slot-or-unified-hit-index | level << kGridSlotBits, word} per top-grid cell
-    uint32_t n_wide = 0;
+    std::vector<uint32_t> widew, worig, gslot;
+    uint32_t n_wide = 0, grid_nodes = 0;
 };
 
 template <class SigmaBits>
@@ -403,9 +406,12 @@ bool build_wide_image(const int32_t* child, int64_t capacity, int max_depth, int
         pair_base.push_back(n_wide);
         n_wide += end[(size_t)L] - start[(size_t)L];
     }
-    if (n_wide * 64 + start[(size_t)G] * 8 >= (int64_t(1) << rto::kGridSlotBits)) return false;
+    const int64_t grid_cells = int64_t(1) << (3 * G);
+    const int64_t grid_nodes = (grid_cells + 63) / 64;
+    if ((grid_nodes + n_wide) * 64 >= (int64_t(1) << rto::kGridSlotBits)) return false;
     out.n_wide = (uint32_t)n_wide;
-    out.widew.assign((size_t)n_wide * 64, 0u);
+    out.grid_nodes = (uint32_t)grid_nodes;
+    out.widew.assign((size_t)(grid_nodes + n_wide) * 64, rto::kLeafTag);  // (padding reads as an empty leaf of level 0; never indexed)
     out.worig.assign((size_t)n_wide, 0u);
     auto leafw = [&](int level, int64_t slot) { return rto::kLeafTag | ((uint32_t)level << 16) | (uint32_t)sigma_bits(slot); };
     auto entry = [](int a, int b) {  // child digits (x most significant) at level L and L + 1 -> position in the wide node
@@ -417,7 +423,7 @@ bool build_wide_image(const int32_t* child, int64_t capacity, int max_depth, int
         for (int64_t N = start[(size_t)L]; N < end[(size_t)L]; ++N) {
             const int64_t wn = pair_base[p] + (N - start[(size_t)L]);
             out.worig[(size_t)wn] = (uint32_t)N;
-            uint32_t* w = out.widew.data() + (size_t)wn * 64;
+            uint32_t* w = out.widew.data() + (size_t)(grid_nodes + wn) * 64;
             for (int a = 0; a < 8; ++a) {
                 const int32_t c = child[N * 8 + a];
                 if (c == 0) {
@@ -433,18 +439,21 @@ bool build_wide_image(const int32_t* child, int64_t capacity, int max_depth, int
                     } else {
                         const int64_t D = C + c2;  // level L + 2: the first level of the next pair
                         if (L + 2 >= n_levels || D < start[(size_t)L + 2] || D >= end[(size_t)L + 2]) return false;
-                        w[entry(a, b)] = (uint32_t)(pair_base[p + 1] + (D - start[(size_t)L + 2]));
+                        w[entry(a, b)] = (uint32_t)(grid_nodes + pair_base[p + 1] + (D - start[(size_t)L + 2]));
                     }
                 }
             }
         }
     }
-    // the top grid again, its words in the wide image's terms (see build_topgrid_kernel): a leaf above level G keeps its
-    // level in the word and gets the hit index n_wide * 64 + slot (a hit entry names a wide entry or, from here on, such a leaf)
-    if (G > 0) {
-        const uint32_t cells = 1u << (3 * G), mask = (1u << G) - 1u;
-        out.grid2.assign((size_t)cells * 2, 0u);
-        for (uint32_t key = 0; key < cells; ++key) {
+    // the top grid in the same terms (see build_topgrid_kernel): cell -> where its root path over levels 0..G-1 ends
+    {
+        const uint32_t mask = (1u << G) - 1u;
+        out.gslot.assign((size_t)grid_cells, 0u);
+        for (uint32_t key = 0; key < (uint32_t)grid_cells; ++key) {
+            if (G == 0) {  // no grid levels: the one cell is the whole volume, below it the root's wide node
+                out.widew[0] = (uint32_t)grid_nodes;
+                break;
+            }
             const uint32_t cx = key >> (2 * G), cy = (key >> G) & mask, cz = key & mask;
             int64_t node = 0, slot = 0;
             int32_t c = 0;
@@ -458,18 +467,14 @@ bool build_wide_image(const int32_t* child, int64_t capacity, int max_depth, int
                 node += c;
                 ++lvl;
             }
-            uint32_t x, y;
             if (c == 0) {
-                x = (uint32_t)(n_wide * 64 + slot) | ((uint32_t)lvl << rto::kGridSlotBits);
-                y = leafw(lvl, slot);
+                out.widew[key] = leafw(lvl, slot);
+                out.gslot[key] = (uint32_t)slot;
             } else {  // internal at level G - 1: its child is a level-G node = a wide node of pair 0
                 const int64_t D = node + c;
                 if (D < start[(size_t)G] || D >= end[(size_t)G]) return false;
-                x = (uint32_t)lvl << rto::kGridSlotBits;
-                y = (uint32_t)(D - start[(size_t)G]);
+                out.widew[key] = (uint32_t)(grid_nodes + (D - start[(size_t)G]));
             }
-            out.grid2[(size_t)key * 2] = x;
-            out.grid2[(size_t)key * 2 + 1] = y;
         }
     }
     return true;
@@ -648,17 +653,18 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
             ok = build_wide_image(child, capacity, max_depth, top_levels, [&](int64_t sl) { return data[(size_t)sl * dd + dd - 1]; }, wi);
         }
         if (ok) {
-            const size_t wb = wi.widew.size() * 4, ob = wi.worig.size() * 4, gb = wi.grid2.size() * 4;
-            bool up = hipMalloc(&t->d_widew, wb) == hipSuccess && hipMalloc(&t->d_worig, ob) == hipSuccess &&
-                      hipMemcpy(t->d_widew, wi.widew.data(), wb, hipMemcpyHostToDevice) == hipSuccess &&
-                      hipMemcpy(t->d_worig, wi.worig.data(), ob, hipMemcpyHostToDevice) == hipSuccess;
-            if (up && gb)
-                up = hipMalloc(&t->d_grid2, gb) == hipSuccess && hipMemcpy(t->d_grid2, wi.grid2.data(), gb, hipMemcpyHostToDevice) == hipSuccess;
+            const size_t wb = wi.widew.size() * 4, ob = wi.worig.size() * 4, gb = wi.gslot.size() * 4;
+            const bool up = hipMalloc(&t->d_widew, wb) == hipSuccess && hipMalloc(&t->d_worig, ob) == hipSuccess &&
+                            hipMalloc(&t->d_grid2, gb) == hipSuccess &&
+                            hipMemcpy(t->d_widew, wi.widew.data(), wb, hipMemcpyHostToDevice) == hipSuccess &&
+                            hipMemcpy(t->d_worig, wi.worig.data(), ob, hipMemcpyHostToDevice) == hipSuccess &&
+                            hipMemcpy(t->d_grid2, wi.gslot.data(), gb, hipMemcpyHostToDevice) == hipSuccess;
             if (up) {
                 t->dev.widew = (const uint32_t*)t->d_widew;
                 t->dev.worig = (const uint32_t*)t->d_worig;
-                t->dev.topgrid2 = (const uint2*)t->d_grid2;
+                t->dev.wgslot = (const uint32_t*)t->d_grid2;
                 t->dev.wide_entries = wi.n_wide * 64u;
+                t->dev.wide_grid_nodes = wi.grid_nodes;
                 dev_bytes += wb + ob + gb;
             } else {  // not enough memory: the kernel walks the one-level image
                 (void)hipGetLastError();
@@ -774,7 +780,7 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
 // tests/test_render_parity.py::test_generic_kernel_on_a_tree_without_reference_arrays)
 bool tree_fits_spp(const rto_tree* tree, int spp) {
     const int64_t n_slots = tree->info.capacity * tree->dev.N3;
-    const int64_t wide = tree->dev.widew ? (int64_t)tree->dev.wide_entries + n_slots / 8 : 0;  // (upper bound of the top slots)
+    const int64_t wide = tree->dev.widew ? (int64_t)tree->dev.wide_entries + (int64_t)tree->dev.wide_grid_nodes * 64 : 0;
     return slots_fit_spp(n_slots > wide ? n_slots : wide, spp);
 }
 
@@ -1257,32 +1263,24 @@ int rto_wide_image_probe(const int32_t* child, const uint16_t* sigma_bits, int64
     auto nodew_leaf = [&](int64_t slot) { return child[slot] == 0; };
     for (int64_t i = 0; i < n; ++i) {
         const uint32_t ix = points[i * 3], iy = points[i * 3 + 1], iz = points[i * 3 + 2];
-        uint32_t w = 0, u = 0, node = 0;  // (render_persist: rs.node = G > 0 ? kGridNext : 0, rs.prev_lvl = 0)
-        int pr = 0;
-        bool grid = G > 0;
+        // render_persist's walk: (node, off) = (0, 24 - G) at the grid, (node number, 22 - G - 2 p) at pair p below;
+        // entry = ((node << b | x bits) << b | y bits) << b | z bits with b = node ? 2 : G bits per axis from bit `off` on
+        uint32_t w = 0, u = 0, node = 0, off = 24u - (uint32_t)G;
         for (;;) {
-            if (grid) {
-                const uint32_t gs = 24u - (uint32_t)G;
-                const uint32_t key = (((ix >> gs) << G | (iy >> gs)) << G) | (iz >> gs);
-                u = wi.grid2[(size_t)key * 2] & rto::kGridSlotMask;
-                w = wi.grid2[(size_t)key * 2 + 1];
-                pr = -1;
-                grid = false;
-            } else {
-                const uint32_t sh = (22u - (uint32_t)G) - 2u * (uint32_t)pr;
-                u = (((node << 2 | ((ix >> sh) & 3u)) << 2 | ((iy >> sh) & 3u)) << 2) | ((iz >> sh) & 3u);
-                w = wi.widew[u];
-            }
+            const uint32_t b = node ? 2u : (uint32_t)G, m = (1u << b) - 1u;
+            u = (((node << b | ((ix >> off) & m)) << b | ((iy >> off) & m)) << b) | ((iz >> off) & m);
+            w = wi.widew[u];
             if (rto::nodew_is_leaf(w)) break;
-            node = w;  // internal: the wide node two levels down
-            ++pr;
+            node = w;  // internal: the node two levels down (from the grid: the level-G node's)
+            off -= 2u;
         }
         // hit index -> leaf slot (render_kernels.hip wide_to_slot)
         int64_t slot;
-        if (u >= wi.n_wide * 64u) {
-            slot = (int64_t)(u - wi.n_wide * 64u);
+        const uint32_t pad = wi.grid_nodes * 64u;
+        if (u < pad) {
+            slot = (int64_t)wi.gslot[u];
         } else {
-            const uint32_t wn = u >> 6, x2 = (u >> 4) & 3u, y2 = (u >> 2) & 3u, z2 = u & 3u;
+            const uint32_t v = u - pad, wn = v >> 6, x2 = (v >> 4) & 3u, y2 = (v >> 2) & 3u, z2 = v & 3u;
             const uint32_t a = (x2 >> 1) << 2 | (y2 >> 1) << 1 | (z2 >> 1), b = (x2 & 1u) << 2 | (y2 & 1u) << 1 | (z2 & 1u);
             const int64_t N = wi.worig[wn];
             slot = nodew_leaf(N * 8 + a) ? N * 8 + a : (N + child[N * 8 + a]) * 8 + b;

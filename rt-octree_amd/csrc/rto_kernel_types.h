@@ -48,14 +48,16 @@ struct TreeDev {
     // above level G costs this one 8-byte, L2-resident load.  nullptr / 0 when absent.
     const uint2* topgrid;
     int top_levels;
-    // Two-level traversal image of the batched kernel (rto_abi.cpp build_wide_image; nullptr: absent).  widew[wide node * 64 +
-    // (x2 << 4 | y2 << 2 | z2)]: leaf = kLeafTag | level << 16 | sigma fp16, internal = index of the wide node two levels
-    // down; topgrid2 = the top grid in the same terms; worig[wide node] = its octree node; wide_entries = wide nodes * 64
-    // (hit indices at and above it name the slots of leaves above the grid levels)
+    // Two-level traversal image (rto_abi.cpp build_wide_image; nullptr: absent).  ONE array: entries [0, 8^G) are the top-grid
+    // cells, padded to wide_grid_nodes nodes of 64; wide node k is node wide_grid_nodes + k.  Entry of a node: index
+    // (x2 << 4 | y2 << 2 | z2), two bits per axis; of the grid: (x << 2G | y << G | z).  A word: leaf = kLeafTag | level << 16 |
+    // sigma fp16, internal = the NODE NUMBER of the wide node below (two levels down; from the grid: the level-G node's).  An
+    // entry's index is also the hit index of its leaf: wgslot[grid cell] / worig[wide node] translate it to the leaf's slot.
     const uint32_t* widew;
-    const uint2* topgrid2;
+    const uint32_t* wgslot;
     const uint32_t* worig;
-    uint32_t wide_entries;
+    uint32_t wide_entries;     // wide nodes * 64
+    uint32_t wide_grid_nodes;  // nodes of 64 entries the grid part occupies
     // Aligned copy of the SH coefficients for shading (dense SH9 / SH16 trees, N == 2; SH25 gains nothing from it and
     // keeps data[]): per slot the 3 B coefficients in data[]'s order, zero-padded to 64 B (SH9) / 128 B (SH16) so that
     // a record is ONE 128-byte line fetched by 16-byte loads; nullptr when absent (shading then reads data[]).  When it

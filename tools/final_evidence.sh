@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-3 evidence bundle (run on the GPU box from the repo root): bash tools/final_evidence.sh [tag] -> gpurun_out/<tag>_*
+# Evidence bundle of a round (run on the GPU box from the repo root): bash tools/final_evidence.sh [tag] -> gpurun_out/<tag>_*
 # Order matters: (1) the traversal loop with its gathers stubbed -> the VALU ceiling of THIS code's instruction stream,
 # (2) kernel trace + counter passes of the real kernels (tools/profile_round.sh) -> <tag>_pmc_traffic.json, installed as
 # profiles/pmc_traffic.json in this copy of the tree, (3) the plain bench lines, which then carry those counters
 # (a line run before (2) says traffic_stale).  Copy gpurun_out/<tag>_* into profiles/ afterwards.
-T=${1:-r3_m}
+T=${1:-r4_p}
 O=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 STUB=$PWD/rt-octree_amd/lib_ab/librto_1.so   # tools/ab_variants.sh build "" "-DRTO_STUB_LOADS"

@@ -176,6 +176,47 @@ def test_batched_fallback_on_a_tree_that_released_its_reference_arrays(hook):
     assert ctx.tile_marks() is not None
 
 
+def _chain_tree(depth, seed, basis=4):
+    """a hand-built deep, narrow octree: every node refines ONE child (towards a corner that moves with the level), the other
+    seven are leaves of random density -- `depth` node levels with 8 * depth slots: the two-level image then has pairs well
+    beyond the two of the bench tree, at both parities of (depth - grid levels)"""
+    rs = np.random.RandomState(seed)
+    child = np.zeros((depth, 2, 2, 2), np.int32)
+    dd = 3 * basis + 1
+    data = np.zeros((depth, 2, 2, 2, dd), np.float16)
+    data[..., :dd - 1] = rs.normal(0, 0.4, (depth, 2, 2, 2, dd - 1))
+    data[..., dd - 1] = rs.uniform(0, 40, (depth, 2, 2, 2)) * (rs.uniform(size=(depth, 2, 2, 2)) < 0.7)
+    for lvl in range(depth - 1):
+        a, b, c = (lvl * 5 + seed) & 1, (lvl * 3 + (seed >> 1)) & 1, (lvl + (seed >> 2)) & 1
+        child[lvl, a, b, c] = 1  # the next node in breadth-first order
+    return synth.SynthTree(child, data, np.full(3, 1 / 3.0, np.float32), np.full(3, 0.5, np.float32), "SH%d" % basis, depth, {})
+
+
+@pytest.mark.parametrize("depth", [9, 12, 13, 17, 24])
+def test_deep_narrow_trees_walk_the_two_level_image_bit_exact(depth):
+    """depths up to the 24 levels the fixed-point coordinates allow: up to 9 pairs of levels below the grid, odd and even;
+    batched and single-frame kernels against the oracle, and against the same tree without the two-level image"""
+    tree = _chain_tree(depth, seed=depth)
+    ht, dt = make_pair(tree)
+    assert dt.max_depth == depth and dt.wide_nodes == len(range(6, depth, 2))
+    cams, ocams = [], []
+    for i, pos in enumerate([(2.2, 1.7, 1.9), (-1.9, 2.4, 0.8), (0.4, 0.3, 2.9)]):
+        ocam, cam = cameras(56, 40, synth.look_at_c2w(pos, target=(0.1 * i, -0.1, 0.05)))
+        cams.append(cam)
+        ocams.append(ocam)
+    ctx = R.RenderContext(56, 40, frames=3)
+    opt = R.RenderOptions(spp=8, denoise=False)
+    R.launch_renderer_batch(dt, cams, opt, ctx, rng_jumps=[3, 4, 5])
+    for i in range(3):
+        aux_o, rgba_o, _ = oracle_frame(ht, ocams[i], 8, frame=3 + i)
+        ctx.select_frame(i)
+        assert_bits_equal(ctx.download_aux(), aux_o, "batched aux %d" % i)
+        assert_bits_equal(ctx.download_image(), rgba_o, "batched image %d" % i)
+        assert aux_o[3].max() > 0
+    aux_f, _, _ = hip_frame(dt, cams[0], 8, frame=3, kernel=R.KERNEL_FAST)
+    assert_bits_equal(aux_f, oracle_frame(ht, ocams[0], 8, frame=3)[0], "single-frame kernel")
+
+
 @pytest.mark.parametrize("depth,basis", [(1, 4), (2, 4), (3, 9), (8, 9)])
 def test_batched_path_on_shallow_and_deep_trees(depth, basis):
     """no top grid (depth < 3), a shallow grid, a deeper tree; SPP 1 and 32; a negative sigma_thresh makes even

@@ -151,7 +151,7 @@ def workload_id(args, W, H):
             (1920, 1080, 6, 25, 10, False, 1.12, 1160.0, 2.6): "c4"}.get(key)
 
 
-KERNEL_SOURCES = ("render_kernels.hip", "rto_kernel_types.h", "rto_device_math.h", "rto_launch.h")
+KERNEL_SOURCES = ("render_kernels.hip", "rto_march_leaf.inc", "rto_kernel_types.h", "rto_device_math.h", "rto_launch.h")
 
 
 def kernel_code_id():

@@ -21,7 +21,13 @@
  *
  * Threading: handles are thread-compatible, not thread-safe -- one rto_ctx (and one rto_guidance_net) per host thread
  * and per stream at a time: a context owns the hand-off buffers, ray queues and frame table of the launch in flight,
- * and two batched launches of one context on different streams would share them.
+ * and two batched launches of one context on different streams would share them.  Two more places hold lazily built,
+ * shared state: (1) a tree whose upload released child[] / data[] (dense SH9 / SH16, the default) rebuilds them under a lock
+ * at the FIRST launch that selects the generic kernel (rto_ctx_set_kernel(RTO_KERNEL_GENERIC), N != 2, the per-frame
+ * fallback of a batched launch) -- make that first launch before other threads render the same tree, or load the tree with
+ * RTO_TREE_KEEP_REFERENCE; (2) the *_culled denoise entry points measure the network's background tile once per background
+ * brightness, synchronising the stream and rewriting the handle's copy of it -- work queued on ANOTHER stream with the
+ * previous brightness must have finished (one network handle per stream, as above, makes that automatic).
  *
  * Error convention: every function returning int returns RTO_OK (0) or a negative RTO_E_* code;
  * rto_last_error() gives the message for the calling thread.  The library never calls exit()

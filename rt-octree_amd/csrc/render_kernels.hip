@@ -1192,6 +1192,11 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
 #ifdef RTO_LEAF_K
     uint32_t pend_w = 0u, pend_slot = 0u;  // the leaf word / slot a lane waits at (0: none; a leaf word carries kLeafTag)
 #endif
+    // Two pairs of levels below the grid at most (a tree of depth <= G + 4: the NeRF-synthetic PlenOctrees' 9-10 levels) and the
+    // ancestor "stack" is two registers: the restart node then comes from a select, not from an LDS read on the path of
+    // every iteration (-2 % in one box, profiles/r4_r_ab_regstack.txt).  Deeper trees keep the LDS rows.  (wave-uniform)
+    uint32_t stk0 = 0u, stk1 = 0u;
+    const bool regstack = WIDE && (tree.max_depth - G + 1) / 2 <= 2;
     RayState rs;
     // a lane marches a ray while rs.t < rs.tmax: that comparison IS the lane's state (an ended ray has t >= tmax or
     // tmax = -1), so the wave-level count of marching lanes is the ballot of one v_cmp instead of a loop-carried flag
@@ -1355,7 +1360,12 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     if ((int32_t)w >= -(1 << 30)) {  // internal: two levels down (from the grid: into the level-G node)
                         RTO_DBG_AT(1)
                         rs.node = w;
-                        stack[(((24u - (uint32_t)G) - rs.woff) >> 1) * 256u] = w;  // row p + 1 of the pair it spans (grid: row 0)
+                        if (regstack) {  // (wave-uniform) two pairs at most: the ancestor "stack" is two registers
+                            const bool first = rs.woff == 24u - (uint32_t)G;
+                            stk0 = first ? w : stk0;
+                            stk1 = first ? stk1 : w;
+                        } else
+                            stack[(((24u - (uint32_t)G) - rs.woff) >> 1) * 256u] = w;  // row p + 1 of the pair it spans (grid: row 0)
                         rs.woff -= 2u;
                     }
                 }

@@ -1932,8 +1932,11 @@ hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev&
     }
 }
 
+// Waves per SIMD the default instantiation is built for.  Round 3: 7 (72 VGPRs).  Round 4: 8 (64 VGPRs; the spills this forces are
+// in the ray set-up) -- with the shorter two-level loop one more resident wave is worth more than the spills cost: C2 4.69 -> 4.57,
+// C4 13.27 -> 12.71, C5 2.96 -> 2.88 ms per 100 frames in one box (profiles/r4_u_ab_wps8.txt).  Tuning key refill = 732: the 7-wave build.
 #ifndef RTO_WPS_DEFAULT
-#define RTO_WPS_DEFAULT 7
+#define RTO_WPS_DEFAULT 8
 #endif
 template <int SPP, int REFILL, int WPS, bool WIDE>
 static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
@@ -2045,6 +2048,7 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
             case 816: RTO_F(16, 8);
             case 832: RTO_F(32, 8);
             case 724: RTO_F(24, 7);
+            case 732: RTO_F(32, 7);
             case 740: RTO_F(40, 7);
             case 632: RTO_F(32, 6);
             case 432: RTO_F(32, 4);

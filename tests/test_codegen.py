@@ -37,8 +37,8 @@ def test_the_two_gathers_of_a_node_visit_are_issued_back_to_back(tmp_path):
     """the ONE-level walk (trees without the two-level image): top-grid entry and slot word are issued back to back"""
     text = device_asm("render_kernels.hip")
     for spp in (1, 6):  # the benchmark's instantiations (C5, C2 / C4)
-        m = re.search(r"^_ZN3rto14render_persistILi%dELi32ELi7ELb0EEE[^\n]*\n(.*?)s_endpgm" % spp, text, re.S | re.M)
-        assert m, "render_persist<%d,32,7,false> not found in the assembly" % spp
+        m = re.search(r"^_ZN3rto14render_persistILi%dELi32ELi8ELb0EEE[^\n]*\n(.*?)s_endpgm" % spp, text, re.S | re.M)
+        assert m, "render_persist<%d,32,8,false> not found in the assembly" % spp
         body = [ln.split(";")[0].strip() for ln in m.group(1).splitlines()]
         body = [ln for ln in body if ln and not ln.startswith(".") or ln.startswith(".LBB")]
         grid = max(i for i, ln in enumerate(body) if ln.startswith("global_load_dwordx2"))  # the top-grid entry
@@ -55,8 +55,8 @@ def test_the_two_level_walk_has_one_gather_per_node_visit(tmp_path):
     entry, no second address computation anywhere in the kernel"""
     text = device_asm("render_kernels.hip")
     for spp in (1, 6):
-        m = re.search(r"^_ZN3rto14render_persistILi%dELi32ELi7ELb1EEE[^\n]*\n(.*?)s_endpgm" % spp, text, re.S | re.M)
-        assert m, "render_persist<%d,32,7,true> not found in the assembly" % spp
+        m = re.search(r"^_ZN3rto14render_persistILi%dELi32ELi8ELb1EEE[^\n]*\n(.*?)s_endpgm" % spp, text, re.S | re.M)
+        assert m, "render_persist<%d,32,8,true> not found in the assembly" % spp
         assert "global_load_dwordx2" not in m.group(1)
 
 

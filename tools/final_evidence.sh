@@ -4,7 +4,7 @@
 # (2) kernel trace + counter passes of the real kernels (tools/profile_round.sh) -> <tag>_pmc_traffic.json, installed as
 # profiles/pmc_traffic.json in this copy of the tree, (3) the plain bench lines, which then carry those counters
 # (a line run before (2) says traffic_stale).  Copy gpurun_out/<tag>_* into profiles/ afterwards.
-T=${1:-r4_p}
+T=${1:-r4_z}
 O=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 STUB=$PWD/rt-octree_amd/lib_ab/librto_1.so   # tools/ab_variants.sh build "" "-DRTO_STUB_LOADS"

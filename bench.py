@@ -839,7 +839,7 @@ def main():
                            "note": "frac = (L1-hit lines / ceiling + L2-served lines / ceiling + lines from beyond L2 / ceiling) / "
                                    "kernel clocks, at the rates tools/probe_ceiling.py measured for DEPENDENT scattered dword loads, "
                                    "the traversal's shape (profiles/r2_probe_ceiling.json: one gather in flight per wave, so these are "
-                                   "latency x concurrency figures -- taken at 7 waves per SIMD like the kernel -- not the L1's throughput "
+                                   "latency x concurrency figures -- taken at 6-8 waves per SIMD like the kernel -- not the L1's throughput "
                                    "limit, and the kernel may pass them where its gathers overlap better than the probe's); frac_lower "
                                    "prices the same lines at the rates of four independent gathers in flight per wave."}
         except Exception as e:  # a malformed profile must not break the bench line

@@ -456,3 +456,30 @@ def test_cli_llff_dataset_end_to_end(tmp_path):
     from PIL import Image
     img = np.array(Image.open(os.path.join(out, "img_000.png")))
     assert img[..., :3].std() > 1.0  # the NDC frustum actually sees the scene (not a flat background)
+
+
+@pytest.mark.gpu
+def test_config_c1_one_pose_400x400_spp1_no_denoiser(tmp_path):
+    """BASELINE.json configs[0] at its own size: tree.npz, ONE test pose, 400x400, SPP 1, no denoiser (no --ts_module: the
+    reference would abort without one, main_headless.cpp:455-456 -- documented deviation), 100 warm-up frames as the
+    reference runs them (main_headless.cpp:469-479).  The CPU N3Tree traversal of that config is the oracle: the CLI's PNG
+    must decode to its RGBA8 bytes, through the batched kernels (default) and one launch per frame (--batch 1)."""
+    import orc
+    from PIL import Image
+    tree = synth.make_tree(depth_limit=7, basis_dim=16, seed=20230418)
+    tp = tree.save_npz(str(tmp_path / "tree.npz"))
+    poses = synth.orbit_poses(200)[:1]
+    pp = synth.write_transforms_json(str(tmp_path / "transforms_test.json"), poses)
+    op = synth.write_opt_json(str(tmp_path / "opt.json"), denoise=False, spp=1)
+    ht = orc.HostTree(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+    fx = synth.blender_focal(400)
+    cam = orc.camera(400, 400, fx, fx, poses[0][:3, :4].T.reshape(-1))
+    aux, rgba, st = orc.render_frame(ht, cam, orc.default_options(spp=1), orc.rng(frame=100))
+    assert st["rays"] == 160000 and st["hit_rays"] > 5000
+    for extra in ([], ["--batch", "1"]):
+        out = str(tmp_path / ("out" + "_".join(extra)))
+        r = _run([tp, pp, "--options", op, "-w", "400", "-h", "400", "-o", out] + extra)
+        assert r.returncode == 0, r.stderr
+        assert re.search(r"FPS:    [0-9.]+", r.stdout)
+        got = np.array(Image.open(os.path.join(out, "r_0.png")))
+        assert got.shape == (400, 400, 4) and np.array_equal(got, orc.rgba8(rgba)), extra

@@ -1109,7 +1109,19 @@ def main():
         "psnr": psnr,
         "cpu_baseline": cpu,
     }
-    print(json.dumps(out))
+    def finite(o):  # strict JSON: no NaN / Infinity tokens in the driver's line
+        if isinstance(o, float):
+            return o if np.isfinite(o) else None
+        if isinstance(o, dict):
+            return {k: finite(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [finite(v) for v in o]
+        if isinstance(o, (np.floating, np.integer)):
+            return finite(o.item())
+        return o
+
+    print(json.dumps(finite(out), allow_nan=False))
+    sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

@@ -1272,40 +1272,20 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
 #pragma unroll
                         for (int i = 0; i < 12; ++i) cam.transform[i] = fd[2 + i];
                         float vdir[3];
+                        ray_setup(x, y, cam, tree, rs.dir, vdir, rs.cen);
                         float tmin;
                         {   // where this pixel's next hit entry goes (hoff) and the one after it (hnext): hit_index
                             const uint32_t fbase = (uint32_t)frame * (uint32_t)SPP * SIZE, pixel = (uint32_t)(y * W + x);
                             rs.hoff = fbase + hit_index<SPP>(pixel, 0u, SIZE);
                             rs.hnext = fbase + hit_index<SPP>(pixel, SPP > 1 ? 1u : 0u, SIZE);
                         }
-#ifdef RTO_EARLY_THR
-                        // the pixel's sorted thresholds are requested BEFORE the ray set-up's arithmetic (a few hundred
-                        // instructions with double-precision parts): their round trip then runs under it instead of after it,
-                        // while the wave's marching lanes wait for this round to end
-                        constexpr int NE = SPP <= 8 ? SPP : 1;
-                        uint32_t thr[NE];
-                        thr[0] = hits[rs.hoff];
-                        {
-                            const uint32_t* tp0 = hits + rs.hnext;
-#pragma unroll
-                            for (int i = 1; i < NE; ++i) thr[i] = tp0[(uint32_t)(i - 1) * hstride];
-                        }
-                        asm volatile("" : "+v"(thr[0]));
-#endif
-                        ray_setup(x, y, cam, tree, rs.dir, vdir, rs.cen);
                         if (ray_enter(tree, opt, rs.dir, rs.cen, 1e9f, rs.invdir, rs.delta_scale, tmin, rs.tmax)) {
                             // sorted thresholds of this pixel (sample_kernel left them in the hand-off
                             // buffer, where the ray's hit list will overwrite them)
-                            const uint32_t* tp = hits + rs.hnext;
-#ifdef RTO_EARLY_THR
-                            rs.cur = __uint_as_float(thr[0]);
-#pragma unroll
-                            for (int i = 1; i < SPP; ++i) s_dst[i * 256] = __uint_as_float(i < NE ? thr[i < NE ? i : 0] : tp[(uint32_t)(i - 1) * hstride]);
-#else
                             rs.cur = __uint_as_float(hits[rs.hoff]);
+                            const uint32_t* tp = hits + rs.hnext;
 #pragma unroll
                             for (int i = 1; i < SPP; ++i) s_dst[i * 256] = __uint_as_float(tp[(uint32_t)(i - 1) * hstride]);
-#endif
                             s_dst[SPP * 256] = 3.402823466e+38f;
                             rs.spp = 0;
                             rs.src = 0;

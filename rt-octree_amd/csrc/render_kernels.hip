@@ -19,6 +19,12 @@
 //   render_persist<SPP>  N == 2, up to 128 frames per launch (the throughput path): persistent waves,
 //                        ray compaction, one ray queue per XCD; sample_kernel before it (thresholds)
 //                        and shade_kernel after it (SH colour + pixel epilogue).
+// Since round 4 render_fast and render_persist walk the TWO-LEVEL traversal image when the tree has one
+// (TreeDev::widew, rto_abi.cpp build_wide_image): top-grid cells and nodes merged with their eight children in
+// ONE array, so that a node visit is one uniform 4-byte load resolving two levels; a ray's hit entries name
+// entries of that image, wait in LDS while it marches and are translated to leaf slots and written once, when
+// it has ended (flush_hits).  The one-level image (nodew + topgrid) serves the counting instantiation and trees
+// whose two-level image would not fit; both give the same pixels.
 //
 // Why the descent can be done on integers (SURVEY.md section 7 "hard parts"): after the clamp to
 // [0, 1-1e-6] every operation of the reference descent (x*=2; floor; x-=floor) is exact in fp32,

@@ -616,6 +616,8 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
         uint32_t* stack = s_stack + tid;
         const int G = tree.top_levels;  // 0: no top grid
         if (WIDE && G == 0) stack[0] = 0u;
+        uint32_t stk0 = 0u, stk1 = 0u;
+        const bool regstack = WIDE && (tree.max_depth - G + 1) / 2 <= 2;  // (uniform) pairs of levels below the grid
 
         while (t < tmax) {
             float pos[3] = {cen[0] + t * dir[0], cen[1] + t * dir[1], cen[2] + t * dir[2]};
@@ -636,12 +638,14 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
                 // frame waits for the dependent-load chains of its longest rays, and this shortens every one of them
                 // (node, off): (0, 24 - G) = the top grid, whose cells are indexed by G bits per axis; else the wide node of the
                 // pair (G + 2 pr, G + 2 pr + 1), two bits per axis from bit 22 - G - 2 pr on.  One array holds both.
+                // With two pairs of levels below the grid at most (regstack: a tree of depth <= G + 4) the ancestor stack is two
+                // registers: no LDS round trip on the dependent chain of a step.
                 int pr = -1;
                 node = 0u;
                 if (lvl >= G) {
                     pr = (lvl - G) >> 1;
-                    node = stack[pr * 256];
-                    if (node == 0u) pr = -1;  // (no grid levels, first step: stack[0] still holds the 0 it was given)
+                    node = regstack ? (pr ? stk1 : stk0) : stack[pr * 256];
+                    if (node == 0u) pr = -1;  // (no grid levels, first step: the stack still holds the 0 it was given)
                 }
                 for (;;) {
                     const uint32_t b = node ? 2u : (uint32_t)G, msk = (1u << b) - 1u;
@@ -651,7 +655,12 @@ __global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const Cam
                     if (nodew_is_leaf(w)) break;
                     node = w;  // the wide node two levels down
                     ++pr;
-                    stack[pr * 256] = node;
+                    if (regstack) {
+                        stk0 = pr == 0 ? node : stk0;
+                        stk1 = pr == 0 ? stk1 : node;
+                    } else {
+                        stack[pr * 256] = node;
+                    }
                 }
                 (void)have_w;
                 lvl = (int)((w >> 16) & 31u);  // a leaf word of the wide image carries its level

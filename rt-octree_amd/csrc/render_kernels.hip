@@ -556,8 +556,11 @@ RTO_DEV uint32_t wide_to_slot(const TreeDev& tree, uint32_t u) {
 // STATS: also count the units of SURVEY 8(d)'s algorithmic-byte formula (march steps, descent
 // levels a root-restart walk would visit, distinct hit leaves, ...) into fo.stats.  Separate
 // instantiation; the timed kernel carries none of it.
+#ifndef RTO_FAST_WPS
+#define RTO_FAST_WPS 4
+#endif
 template <int SPP, bool STATS, bool WIDE>
-__global__ void __launch_bounds__(256) render_fast(const TreeDev tree, const CamDev cam, const OptDev opt,
+__global__ void __launch_bounds__(256, RTO_FAST_WPS) render_fast(const TreeDev tree, const CamDev cam, const OptDev opt,
                                                     const Pcg32 rng_base, const PcgJumpEntry* __restrict__ jump,
                                                     const TileMap tm, const FrameOut fo) {
     extern __shared__ uint32_t s_stack[];  // [max_depth][256] ancestor node indices, level-major

@@ -556,11 +556,15 @@ RTO_DEV uint32_t wide_to_slot(const TreeDev& tree, uint32_t u) {
 // STATS: also count the units of SURVEY 8(d)'s algorithmic-byte formula (march steps, descent
 // levels a root-restart walk would visit, distinct hit leaves, ...) into fo.stats.  Separate
 // instantiation; the timed kernel carries none of it.
+// Waves per SIMD render_fast is built for.  A lone frame does not care (it waits for its longest rays on a nearly empty chip);
+// callers with several frames in flight do: 5 waves (96 VGPRs; the spills are in the shading tail) lift the pipelined reference
+// loop from 5.65 k to 6.07 k frames/s with the sequential one unchanged, 6 waves give 6.1 k and cost the lone frame 1 %
+// (profiles/r4_w_ab_fast_wps.txt).  The large-SPP instantiations keep 4 (their threshold / hit arrays live in registers).
 #ifndef RTO_FAST_WPS
-#define RTO_FAST_WPS 4
+#define RTO_FAST_WPS 5
 #endif
 template <int SPP, bool STATS, bool WIDE>
-__global__ void __launch_bounds__(256, RTO_FAST_WPS) render_fast(const TreeDev tree, const CamDev cam, const OptDev opt,
+__global__ void __launch_bounds__(256, SPP <= 8 ? RTO_FAST_WPS : 4) render_fast(const TreeDev tree, const CamDev cam, const OptDev opt,
                                                     const Pcg32 rng_base, const PcgJumpEntry* __restrict__ jump,
                                                     const TileMap tm, const FrameOut fo) {
     extern __shared__ uint32_t s_stack[];  // [max_depth][256] ancestor node indices, level-major

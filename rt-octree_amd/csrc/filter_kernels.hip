@@ -370,7 +370,18 @@ __global__ void __launch_bounds__(256, 2) filter_backward(const float4* __restri
 // Guard: E must not underflow inside a window.  GuidanceNet ends in ReLU6, so g lies in [0, 6]; for
 // arbitrary maps a tile whose in-image range of g_l exceeds 80 takes the per-pixel-maximum route below
 // (workgroup-uniform branch, taps read from global memory: slow, correct).
-constexpr int kFastW = 32, kFastH = 32, kFastRows = 4;  // outputs per workgroup; rows per thread
+// Outputs per workgroup: 32 x RTO_FAST_H.  Rounds 2-3: 32 x 32 (51 KB of LDS, 3 workgroups per CU).  Round 4: 32 x 16 (31 KB, 4 per CU) --
+// since the culling only a third of the tiles is computed and those pay one exposed memory latency each, so residency counts for more
+// than the halo re-reads (1.56 -> 1.88 staged pixels per output), and a finer tile also qualifies as "sees only background" more often:
+// 0.937 -> 0.856 ms per 100 frames of the bench scene in one box (profiles/r4_y_ab_filter_tile.txt).  The fill tile (rto_guidance_abi.cpp
+// ensure_fill_tile: 32 x 32 measured on a synthetic frame) covers two such workgroups; a workgroup copies its first RTO_FAST_H rows.
+#ifndef RTO_FAST_H
+#define RTO_FAST_H 16
+#endif
+#ifndef RTO_FAST_WGS
+#define RTO_FAST_WGS 4
+#endif
+constexpr int kFastW = 32, kFastH = RTO_FAST_H, kFastRows = RTO_FAST_H / 8;  // outputs per workgroup; rows per thread
 
 template <int S, int SW>
 RTO_DEV void box_rows(const float4* __restrict__ s_p, int base, float4 (&acc)[kFastRows]) {
@@ -438,7 +449,7 @@ __device__ __noinline__ float4 filter_level_wide(const float* __restrict__ g_, c
 // instead of 4 strided dword loads, the weights by softmax_weights4 on the logits -- the same values as the fp32
 // maps hold, so the same output bit for bit.
 template <int L, bool PACKED>
-__global__ void __launch_bounds__(256, 3) filter_fast(const float* __restrict__ weight,    // [n][L][H][W]
+__global__ void __launch_bounds__(256, RTO_FAST_WGS) filter_fast(const float* __restrict__ weight,    // [n][L][H][W]
                                                      const float* __restrict__ guidance,  // [n][L][H][W]
                                                      const float4* __restrict__ img_in,   // [n][H][W]
                                                      float4* __restrict__ img_out,        // [n][H][W]

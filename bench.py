@@ -79,7 +79,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-denoise", action="store_true", help="config C5: raw SPP render only")
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores)")
-    ap.add_argument("--ref-loop-frames", type=int, default=48,
+    ap.add_argument("--ref-loop-frames", type=int, default=96,
                     help="frames of the one-frame-per-launch pass reported as reference_loop (0 = skip)")
     ap.add_argument("--ref-loop-inflight", type=int, default=4,
                     help="frames in flight in the pipelined variant of the reference loop (1 = skip it)")

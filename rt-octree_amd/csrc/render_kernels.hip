@@ -79,6 +79,9 @@ RTO_DEV void ray_setup(int x, int y, const CamDev& cam, const TreeDev& tree, flo
 }
 
 // rt_core.cuh:206-222: scale dir, invdir, slab test.  returns false when the ray misses the box.
+// SEQ: one axis after the other (scheduling barriers): the three double-precision reciprocals and slab tests interleaved keep
+// ~30 VGPRs busy, which the reservoir kernel -- it sets a tile up while its lanes hold rays in flight -- does not have
+template <bool SEQ = false>
 RTO_DEV bool ray_enter(const TreeDev& tree, const OptDev& opt, float* dir, const float* cen, float tmax_bg,
                        float* invdir, float& delta_scale, float& tmin, float& tmax) {
     dir[0] *= tree.scale[0];
@@ -90,7 +93,10 @@ RTO_DEV bool ray_enter(const TreeDev& tree, const OptDev& opt, float* dir, const
     dir[2] *= delta_scale;
     tmax_bg /= delta_scale;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) invdir[i] = 1.f / (dir[i] + 1e-9);  // double
+    for (int i = 0; i < 3; ++i) {
+        invdir[i] = 1.f / (dir[i] + 1e-9);  // double
+        if (SEQ) __builtin_amdgcn_sched_barrier(0);
+    }
     tmin = 0.0;
     tmax = 1e4;
 #pragma unroll
@@ -99,6 +105,7 @@ RTO_DEV bool ray_enter(const TreeDev& tree, const OptDev& opt, float* dir, const
         const float t2 = (opt.render_bbox[i + 3] - 1e-6 - cen[i]) * invdir[i];
         tmin = f_max(tmin, f_min(t1, t2));
         tmax = f_min(tmax, f_max(t1, t2));
+        if (SEQ) __builtin_amdgcn_sched_barrier(0);
     }
     tmax = f_min(tmax, tmax_bg);
     return !(tmax < 0 || tmin > tmax);
@@ -396,7 +403,8 @@ __global__ void rebuild_reference_kernel(const uint16_t* __restrict__ shrec, con
         has = r != kNoRecord;
         src = r;
     }
-    data[i] = k < data_dim - 1 ? (has ? shrec[src * rec + k] : (uint16_t)0) : (leaf ? (uint16_t)(w & 0xffffu) : (uint16_t)0);
+    // (shrec == nullptr: entry-ordered records -- rebuild_reference_wide_kernel fills the coefficients in afterwards)
+    data[i] = k < data_dim - 1 ? (has && shrec ? shrec[src * rec + k] : (uint16_t)0) : (leaf ? (uint16_t)(w & 0xffffu) : (uint16_t)0);
     if (k == 0) child[slot] = leaf ? 0 : (int32_t)w;
 }
 
@@ -551,6 +559,52 @@ RTO_DEV uint32_t wide_to_slot(const TreeDev& tree, uint32_t u) {
     const uint32_t N = tree.worig[wn];
     const uint32_t w0 = tree.nodew[N * 8u + a];
     return nodew_is_leaf(w0) ? N * 8u + a : (N + w0) * 8u + b;
+}
+
+// the aligned coefficient records in the order of the two-level image's entries (TreeDev::rec_by_entry): record e = the 3 B
+// coefficients of the leaf that entry e of widew names, zero-padded to `rec` halves; entries that are internal nodes (or
+// padding) keep zeros.  One thread per half.  Derived data: the same fp16 values.
+__global__ void build_shrec_wide_kernel(const TreeDev tree, const uint16_t* __restrict__ data, int64_t n_entries, int rec,
+                                        uint16_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_entries * rec) return;
+    const uint32_t e = (uint32_t)(i / rec);
+    const int k = (int)(i - (int64_t)e * rec);
+    uint16_t v = 0;
+    if (nodew_is_leaf(tree.widew[e]) && k < tree.data_dim - 1) {
+        const uint32_t pad = tree.wide_grid_nodes * 64u, cells = 1u << (3 * tree.top_levels);
+        if (e >= pad || e < cells) v = data[(uint64_t)wide_to_slot(tree, e) * tree.data_dim + k];
+    }
+    out[i] = v;
+}
+
+// ... and back: the coefficients of data[] from entry-ordered records (rebuild_reference_kernel wrote child[], sigma and
+// zeros before).  A first-level leaf's 8 entries write the same values to the same place.
+__global__ void rebuild_reference_wide_kernel(const TreeDev tree, int64_t n_entries, int rec, uint16_t* __restrict__ data) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_entries * rec) return;
+    const uint32_t e = (uint32_t)(i / rec);
+    const int k = (int)(i - (int64_t)e * rec);
+    if (k >= tree.data_dim - 1 || !nodew_is_leaf(tree.widew[e])) return;
+    const uint32_t pad = tree.wide_grid_nodes * 64u, cells = 1u << (3 * tree.top_levels);
+    if (e < pad && e >= cells) return;  // padding behind the grid cells
+    data[(uint64_t)wide_to_slot(tree, e) * tree.data_dim + k] = tree.shrec[(uint64_t)e * rec + k];
+}
+
+// entry of the two-level image that holds the point (ix, iy, iz) (24-bit fixed point): the walk of render_fast, from the grid
+RTO_DEV uint32_t wide_entry_of(const TreeDev& tree, uint32_t ix, uint32_t iy, uint32_t iz) {
+    const int G = tree.top_levels;
+    uint32_t node = 0u, slot;
+    int pr = -1;
+    for (;;) {
+        const uint32_t b = node ? 2u : (uint32_t)G, msk = (1u << b) - 1u;
+        const uint32_t off = node ? (uint32_t)(22 - G - 2 * pr) : 24u - (uint32_t)G;
+        slot = (((node << b | ((ix >> off) & msk)) << b | ((iy >> off) & msk)) << b) | ((iz >> off) & msk);
+        const uint32_t w = tree.widew[slot];
+        if (nodew_is_leaf(w)) return slot;
+        node = w;
+        ++pr;
+    }
 }
 
 // STATS: also count the units of SURVEY 8(d)'s algorithmic-byte formula (march steps, descent
@@ -742,7 +796,9 @@ __global__ void __launch_bounds__(256, SPP <= 8 ? RTO_FAST_WPS : 4) render_fast(
 #pragma unroll
                         for (int i = 0; i < SPP; ++i) dst[i] = dst[i + 1];
                     } while (src + delta >= dst[0]);
-                    const uint32_t h = hit_pack<SPP>(slot, cnt);
+                    // (the counting instantiation walks the one-level image; a tree whose records follow the two-level image's
+                    //  entries needs the leaf's entry there: found by that image's walk -- this kernel is never timed)
+                    const uint32_t h = hit_pack<SPP>(!WIDE && tree.rec_by_entry ? wide_entry_of(tree, ix, iy, iz) : slot, cnt);
 #pragma unroll
                     for (int i = 0; i < SPP; ++i) hits[i] = (i == (int)sh_nums) ? h : hits[i];
                     ++sh_nums;
@@ -761,7 +817,8 @@ __global__ void __launch_bounds__(256, SPP <= 8 ? RTO_FAST_WPS : 4) render_fast(
             for (int i = 0; i < SPP; ++i) {
                 if (i < (int)sh_nums) {
                     uint32_t slot = hit_slot<SPP>(hits[i]);
-                    if constexpr (WIDE) slot = wide_to_slot(tree, slot);  // hit index of the wide image -> the leaf's slot
+                    if constexpr (WIDE)
+                        if (!tree.rec_by_entry) slot = wide_to_slot(tree, slot);  // hit index of the wide image -> the leaf's slot
                     const float cnt = (float)hit_count<SPP>(hits[i]);
                     if (tree.format == 1 && tree.data_dim == 28)
                         shade_leaf_packed<28>(tree, slot, basis_fn, cnt, out);
@@ -1115,7 +1172,8 @@ __global__ void __launch_bounds__(256) sample_kernel(const FrameBatch fb, const 
 // one 4-byte store per hit at the moment it happens (71.6 M scattered dwords per 100 frames cost 2.48 GB of line-granular
 // HBM writes for 0.29 GB of payload: the L2 had evicted the sector long before the pixel's next entry arrived).
 template <int SPP, bool WIDE>
-RTO_DEV void flush_hits(RayState& rs, const TreeDev& tree, uint32_t* __restrict__ hits, const float* s_col, uint32_t hstride) {
+RTO_DEV void flush_hits(RayState& rs, const TreeDev& tree, uint32_t* __restrict__ hits, const float* s_col, uint32_t hstride,
+                        bool translate = true) {
     uint32_t e[SPP];
 #pragma unroll
     for (int i = 0; i < SPP; ++i) {
@@ -1124,7 +1182,8 @@ RTO_DEV void flush_hits(RayState& rs, const TreeDev& tree, uint32_t* __restrict_
             e[i] = __float_as_uint(s_col[i * 256]);
             if constexpr (WIDE) {
                 constexpr uint32_t smask = (1u << hit_slot_bits(SPP)) - 1u;
-                e[i] = (e[i] & ~smask) | wide_to_slot(tree, e[i] & smask);  // (off the march loop: the ray has ended)
+                // (off the march loop: the ray has ended; !translate: the shading kernel does it, FrameBatch::res_flags)
+                if (translate) e[i] = (e[i] & ~smask) | wide_to_slot(tree, e[i] & smask);
             }
         }
     }
@@ -1219,6 +1278,11 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     // every iteration (-2 % in one box, profiles/r4_r_ab_regstack.txt).  Deeper trees keep the LDS rows.  (wave-uniform)
     uint32_t stk0 = 0u, stk1 = 0u;
     const bool regstack = WIDE && (tree.max_depth - G + 1) / 2 <= 2;
+#ifdef RTO_HITS_DIRECT
+    constexpr bool kHitsDirect = true;
+#else
+    constexpr bool kHitsDirect = false;
+#endif
     RayState rs;
     // a lane marches a ray while rs.t < rs.tmax: that comparison IS the lane's state (an ended ray has t >= tmax or
     // tmax = -1), so the wave-level count of marching lanes is the ballot of one v_cmp instead of a loop-carried flag
@@ -1271,7 +1335,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                 const uint32_t first = res_next;
                 res_next += take;
 #ifndef RTO_HITS_DIRECT
-                if (idle && rs.nh) flush_hits<SPP, WIDE>(rs, tree, hits, s_dst, hstride);  // the ended ray's hit list leaves in one go
+                if (idle && rs.nh) flush_hits<SPP, WIDE>(rs, tree, hits, s_dst, hstride, !tree.rec_by_entry);  // the ended ray's hit list leaves in one go
 #endif
                 if (idle) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32),
@@ -1509,7 +1573,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
         } while (n_active > exit_at);
     }
 #ifndef RTO_HITS_DIRECT
-    if (rs.nh) flush_hits<SPP, WIDE>(rs, tree, hits, s_dst, hstride);  // rays that ended after the last refill round
+    if (rs.nh) flush_hits<SPP, WIDE>(rs, tree, hits, s_dst, hstride, !tree.rec_by_entry);  // rays that ended after the last refill round
 #endif
 #ifdef RTO_DBG_COUNTERS
 #pragma unroll
@@ -1520,6 +1584,339 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     }
 #endif
 }
+
+// ------------------------------------------------------------------ persistent kernel with a ray reservoir (round 5)
+//
+// render_persist_res: render_persist on the two-level image with the ray SET-UP taken out of the refill round.
+// render_persist sets a ray up (~600 instructions: camera transform, normalisations, the double-precision
+// reciprocals and slab test of rt_core.cuh:206-222) inside the refill round, for the idle lanes only -- so a round is
+// only worth its price once half the wave idles (REFILL = 32), and on average a quarter of a wave's lanes hold no ray
+// (48 of 64 live, 31 lanes per VALU instruction: VERDICT r4).  Here a wave sets up ONE WHOLE 8x8 TILE at a time, all
+// 64 lanes busy, camera in SGPRs (a tile is one frame: scalar loads), and parks the rays that enter the volume,
+// compacted, as 10-dword records in a wave-private reservoir in LDS (field-major: [field][record], conflict-free).
+// A refill round then only copies records into idle lanes (10 LDS reads + the thresholds) and is affordable at
+// KREF = 8..16 idle lanes: ~56-60 lanes of a wave march.  Per-ray arithmetic is unchanged; results are bit-identical.
+//
+// Record (dwords): dir[3] (scaled + renormalised, rt_core.cuh:206-208), invdir[3], delta_scale, tmin, tmax, pixel
+// index (y * W + x); with the NDC warp (LLFF) also cen[3] -- without it the origin is the same for every ray of a
+// frame and travels in SGPRs.
+// thresholds I .. N-1 of a pixel (tp: its entry 1 in the hand-off buffer) into rows I .. N-1 of the wave's columns, LDS-direct
+template <int I, int N>
+RTO_DEV void dma_thresholds(const __attribute__((address_space(1))) uint32_t* tp, uint32_t hstride,
+                            __attribute__((address_space(3))) uint32_t* rows) {
+    if constexpr (I < N) {
+        // (a pixel's entries 1.. are consecutive: the immediate offset addresses them.  The hardware adds that offset to the
+        //  LDS address as well as to the memory address -- tools/probes/lds_dma_probe.hip, profiles/r5_c_lds_dma_probe.txt --
+        //  so the row base is moved back by as much)
+        if (kHitsLayout != 0)
+            __builtin_amdgcn_global_load_lds(tp, rows + I * 256 - (I - 1), 4, 4 * (I - 1), 0);
+        else
+            __builtin_amdgcn_global_load_lds(tp + (uint32_t)(I - 1) * hstride, rows + I * 256, 4, 0, 0);
+        dma_thresholds<I + 1, N>(tp, hstride, rows);
+    }
+}
+
+#define RTO_RES_LDS_DMA_WAIT 1
+template <int SPP, int KREF, int WPS, bool DIRECT>
+__global__ void __launch_bounds__(256, WPS) render_persist_res(const TreeDev tree, const OptDev opt, const FrameBatch fb,
+                                                           unsigned long long* __restrict__ queue,
+                                                           uint32_t* __restrict__ hits, const uint32_t chunk) {
+    constexpr bool WIDE = true;
+    constexpr bool kHitsDirect = DIRECT;  // one store per hit at the moment it happens
+    // LDS rows of 256 dwords (a lane's column = dword tid of each row), all at compile-time offsets from ONE per-lane address:
+    //   [0, SPP]            sorted thresholds / parked hit entries (row SPP: the FLT_MAX sentinel, rt_core.cuh:192)
+    //   [SPP+1]             frame << 25 | pixel of the lane's ray (where its hit list goes: read once, when the ray has ended)
+    //   [SPP+2, SPP+11]     reservoir: field f of record r of wave w at dword f * 256 + w * 64 + r
+    //   [SPP+12, ...)       ancestor stack rows (none with the register stack), then 3 more reservoir rows (cen) with the NDC warp
+    extern __shared__ uint32_t s_mem[];
+    constexpr int kPidRow = SPP + 1, kResRow = SPP + 2, kStackRow = SPP + 12;
+    const int tid = threadIdx.x;
+    const int G = tree.top_levels;
+    uint32_t stk0 = 0u, stk1 = 0u;
+    const bool regstack = (tree.max_depth - G + 1) / 2 <= 2;  // (wave-uniform) see render_persist
+    const int stack_rows = regstack ? 0 : tree.max_depth + 1 - G;
+    float* const s_dst = reinterpret_cast<float*>(s_mem) + tid;
+    uint32_t* const stack = s_mem + kStackRow * 256 + tid;
+    uint32_t* const stack_g = stack;  // (rto_march_leaf.inc names it; unused on the two-level image)
+    const bool ndc = tree.ndc_width > 0;
+    __shared__ int s_qstart[kMaxQueues + 1];
+    __shared__ uint32_t s_qcount[kMaxQueues];
+#pragma unroll
+    for (int k = 0; k <= kMaxQueues; ++k)
+        if (tid == 64 + k) s_qstart[k] = fb.qstart[k];
+#pragma unroll
+    for (int k = 0; k < kMaxQueues; ++k)
+        if (tid == 128 + k) s_qcount[k] = k < fb.n_queues ? fb.qcount[k] : 0u;
+    s_dst[SPP * 256] = 3.402823466e+38f;  // no hit entry ever lands in this row (entry k < spp <= SPP)
+    if (G == 0 && !regstack) stack[0] = 0u;
+    __syncthreads();
+
+    const int W = fb.width, H = fb.height;
+    const uint32_t SIZE = (uint32_t)W * (uint32_t)H;
+    const uint32_t hstride = hit_stride(SIZE);
+    const uint32_t n_queues = (uint32_t)fb.n_queues;
+    uint32_t cur_q = n_queues > 1 ? ((uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % n_queues) : 0u;
+    uint32_t q_tried = 0, res_off = 0;
+
+    typedef const __attribute__((address_space(1))) uint32_t* gptr_t;
+    const uint32_t* nodew_p = tree.widew;
+    const uint32_t* __restrict__ qlist = fb.qlist;
+    float step_size = opt.step_size, sigma_thresh = opt.sigma_thresh;
+    asm volatile("" : "+s"(nodew_p), "+s"(step_size), "+s"(sigma_thresh));
+    const gptr_t nodew = (gptr_t)nodew_p;
+
+#ifdef RTO_DBG_COUNTERS
+    unsigned dbg_w[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    RayState rs;
+    rs.t = 0.f;
+    rs.tmax = -1.f;
+    rs.nh = 0;
+    const bool prefetch = (fb.res_flags & kResPrefetch) != 0;
+    const bool lds_dma = (fb.res_flags & kResLdsDma) != 0;
+    bool drained = false;                    // queues and reservoir exhausted (wave-uniform)
+    uint32_t res_next = 0, res_end = 0;      // the wave's private run of queue entries, in rays (64 per tile slot)
+    uint32_t rec_pos = 0, rec_cnt = 0;       // records [rec_pos, rec_cnt) of the reservoir wait for a lane (wave-uniform)
+    uint32_t rec_frame = 0;                  // frame of the reservoir's tile
+    float rec_cen0 = 0.f, rec_cen1 = 0.f, rec_cen2 = 0.f;  // its ray origin in tree space (no NDC warp)
+
+    // a ray's parked hit entries leave for the hand-off buffer: entry 0 into the dense plane, entries 1.. as one run (they name
+    // entries of the two-level image: the shading kernel translates, FrameBatch::res_flags & kResHitsWide)
+    auto flush = [&]() {
+        if (fb.res_flags & 8) {  // TIMING EXPERIMENT ONLY (wrong pixels): no hit list leaves the kernel
+            rs.nh = 0;
+            return;
+        }
+        const uint32_t pid = __float_as_uint(s_dst[kPidRow * 256]);  // (the launcher keeps W * H < 2^25)
+        const uint32_t fbase = (pid >> 25) * (uint32_t)SPP * SIZE, pixel = pid & 0x1ffffffu;
+        hits[fbase + hit_index<SPP>(pixel, 0u, SIZE)] = __float_as_uint(s_dst[0]);
+        uint32_t* tp = hits + fbase + hit_index<SPP>(pixel, SPP > 1 ? 1u : 0u, SIZE);
+#pragma unroll
+        for (int i = 1; i < SPP; ++i)
+            if ((uint32_t)i < rs.nh) tp[(uint32_t)(i - 1) * hstride] = __float_as_uint(s_dst[i * 256]);
+        rs.nh = 0;
+    };
+
+    for (;;) {
+        bool refilling = false;  // a round that has begun fills EVERY idle lane, across tiles (wave-uniform)
+        for (;;) {
+            if (drained) break;
+            const bool idle = !(rs.t < rs.tmax);
+            const unsigned long long need = __builtin_amdgcn_ballot_w64(idle);
+            const int n_need = __popcll(need);
+            if (n_need == 0 || (!refilling && n_need < KREF)) break;
+            refilling = true;
+            if (rec_pos == rec_cnt) {  // ---- the reservoir is empty: set up the next tile of the queue, all 64 lanes
+                if (res_next == res_end) {
+                    for (;;) {  // own queue first, then the others in turn (wave-uniform)
+                        const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane(s_qstart[cur_q]);
+                        const uint32_t qtotal = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_qcount[cur_q]) * 64u;
+                        unsigned long long base = 0;
+                        if ((tid & 63) == 0) base = atomicAdd(queue + 8 + 8 * cur_q, (unsigned long long)chunk);
+                        const uint32_t base32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+                        if (base32 < qtotal) {
+                            res_next = base32;
+                            res_end = base32 + chunk < qtotal ? base32 + chunk : qtotal;
+                            res_off = t0 * (uint32_t)fb.n;
+                            break;
+                        }
+                        if (++q_tried >= n_queues) {
+                            drained = true;
+                            break;
+                        }
+                        cur_q = cur_q + 1 == n_queues ? 0u : cur_q + 1;
+                    }
+                    if (drained) break;
+                }
+                const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)qlist[res_off + (res_next >> 6)]);
+                res_next += 64u;
+                const int frame = (int)(entry >> 20);
+                // Everything the set-up derives from launch constants is derived HERE, per tile: left alone, the compiler hoists
+                // those values (0.5 W, bbox +- 1e-6 in double, the NDC factors, lane & 7 ...) out of the kernel's loops into
+                // ~18 VGPRs that the march loop then has to spill around (the empty asm statements make the inputs opaque)
+                uint32_t ln = (uint32_t)tid;
+                int Wl = W, Hl = H;
+                OptDev o2 = opt;
+                TreeDev t2 = tree;
+                asm volatile("" : "+v"(ln), "+s"(Wl), "+s"(Hl));
+#pragma unroll
+                for (int i = 0; i < 6; ++i) asm volatile("" : "+s"(o2.render_bbox[i]));
+                asm volatile("" : "+s"(t2.ndc_width), "+s"(t2.ndc_height), "+s"(t2.ndc_focal));
+                const int x = (int)(entry & 1023u) * 8 + (int)(ln & 7u);
+                const int y = (int)((entry >> 10) & 1023u) * 8 + (int)((ln >> 3) & 7u);
+                RTO_DBG_AT(6)
+                // wave-uniform index into a table nobody writes while the kernel runs: the constant address space makes these
+                // scalar loads (the camera of the tile in 14 SGPRs)
+                typedef const __attribute__((address_space(4))) float* cptr_t;
+                const cptr_t fd = (cptr_t)(const void*)(fb.f + frame);
+                static_assert(offsetof(FrameDesc, fx) == 0 && offsetof(FrameDesc, transform) == 8, "fx, fy, transform[12] lead a FrameDesc");
+                CamDev cam;
+                cam.width = Wl;
+                cam.height = Hl;
+                cam.fx = fd[0];
+                cam.fy = fd[1];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) cam.transform[i] = fd[2 + i];
+                if (prefetch && x < Wl && y < Hl) {
+                    // touch this pixel's thresholds: the refill rounds that hand the tile's rays out find them in the L2
+                    // instead of waiting for HBM with the whole wave (the values are not used here)
+                    const uint32_t pixel = (uint32_t)(y * Wl + x), fbase = (uint32_t)frame * (uint32_t)SPP * SIZE;
+                    uint32_t d0 = hits[fbase + hit_index<SPP>(pixel, 0u, SIZE)], d1 = 0u, d2 = 0u;
+                    if (SPP > 1) d1 = hits[fbase + hit_index<SPP>(pixel, 1u, SIZE)];
+                    if (SPP > 2) d2 = hits[fbase + hit_index<SPP>(pixel, (uint32_t)(SPP - 1), SIZE)];
+                    asm volatile("" ::"v"(d0), "v"(d1), "v"(d2));
+                }
+                float dir[3], vdir[3], cen[3], invdir[3], delta_scale, tmin, tmax;
+                ray_setup(x, y, cam, t2, dir, vdir, cen);
+                bool ok = ray_enter<true>(t2, o2, dir, cen, 1e9f, invdir, delta_scale, tmin, tmax);
+                // (a ray with tmin >= tmax takes no step -- `while (t < tmax)`, rt_core.cuh:241 -- and leaves its list empty)
+                ok = ok && x < Wl && y < Hl && tmin < tmax;
+                const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
+                const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(okm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okm, 0u));
+                if (ok) {
+                    float* r = reinterpret_cast<float*>(s_mem) + kResRow * 256 + (ln & 0xc0u) + slot;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        r[i * 256] = dir[i];
+                        r[(3 + i) * 256] = invdir[i];
+                    }
+                    r[6 * 256] = delta_scale;
+                    r[7 * 256] = tmin;
+                    r[8 * 256] = tmax;
+                    r[9 * 256] = __uint_as_float((uint32_t)(y * Wl + x));
+                    if (ndc) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) r[(10 + stack_rows + i) * 256] = cen[i];
+                    }
+                }
+                rec_pos = 0;
+                rec_cnt = (uint32_t)__popcll(okm);
+                rec_frame = (uint32_t)frame;
+                rec_cen0 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cen[0])));
+                rec_cen1 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cen[1])));
+                rec_cen2 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cen[2])));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (rec_cnt == 0u) continue;
+            }
+            // ---- hand records to the idle lanes (ballot + prefix sum)
+            const uint32_t avail = rec_cnt - rec_pos;
+            const uint32_t take = (uint32_t)n_need < avail ? (uint32_t)n_need : avail;
+            if (!DIRECT && idle && rs.nh) flush();  // the ended ray's hit list leaves in one go
+            if (idle) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                if (rank < take) {
+                    uint32_t lt = (uint32_t)tid;
+                    asm volatile("" : "+v"(lt));  // (derive the wave's reservoir address here, not in a register held across the kernel)
+                    const float* r = reinterpret_cast<const float*>(s_mem) + kResRow * 256 + (lt & 0xc0u) + (rec_pos + rank);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        rs.dir[i] = r[i * 256];
+                        rs.invdir[i] = r[(3 + i) * 256];
+                    }
+                    rs.delta_scale = r[6 * 256];
+                    rs.t = r[7 * 256];
+                    rs.tmax = r[8 * 256];
+                    const uint32_t pixel = __float_as_uint(r[9 * 256]);
+                    rs.cen[0] = rec_cen0;
+                    rs.cen[1] = rec_cen1;
+                    rs.cen[2] = rec_cen2;
+                    if (ndc) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) rs.cen[i] = r[(10 + stack_rows + i) * 256];
+                    }
+                    if (!DIRECT) s_dst[kPidRow * 256] = __uint_as_float(rec_frame << 25 | pixel);
+                    const uint32_t fbase = rec_frame * (uint32_t)SPP * SIZE;
+                    const uint32_t hoff = fbase + hit_index<SPP>(pixel, 0u, SIZE), hnext = fbase + hit_index<SPP>(pixel, SPP > 1 ? 1u : 0u, SIZE);
+                    if (DIRECT) {
+                        rs.hoff = hoff;
+                        rs.hnext = hnext;
+                    }
+                    // sorted thresholds of this pixel (sample_kernel left them in the hand-off buffer, where the ray's hit
+                    // list will overwrite them)
+                    rs.cur = (fb.res_flags & 16) ? 1.0f : __uint_as_float(hits[hoff]);  // (16: TIMING EXPERIMENT ONLY, no threshold loads)
+                    const uint32_t* tp = hits + hnext;
+                    if (fb.res_flags & 16) {
+                    } else if (lds_dma) {
+                        // thresholds 1.. straight from memory into this lane's column (global_load_lds_dword: lane L of the wave
+                        // writes dword L of the row M0 points at -- exactly its column), no VGPR round trip and NO WAIT here:
+                        // the loads are in flight while the wave marches on; vmcnt is in order, so the first node word that
+                        // arrives after this round proves them landed (the hit branch waits explicitly before it reads a row)
+                        typedef const __attribute__((address_space(1))) uint32_t* gp_t;
+                        typedef __attribute__((address_space(3))) uint32_t* lp_t;
+                        dma_thresholds<1, SPP>((gp_t)tp, hstride, (lp_t)(s_mem + __builtin_amdgcn_readfirstlane((int)(lt & 0xc0u))));
+                    } else {
+#pragma unroll
+                        for (int i = 1; i < SPP; ++i) s_dst[i * 256] = __uint_as_float(tp[(uint32_t)(i - 1) * hstride]);
+                    }
+                    rs.spp = 0;
+                    rs.src = 0;
+                    rs.cxy.x = rs.cen[0];
+                    rs.cxy.y = rs.cen[1];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) rs.exit_add[i] = rs.invdir[i] > 0.f ? rs.invdir[i] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) rs.pos[i] = clamp_unit(rs.cen[i] + rs.t * rs.dir[i]);
+                    rs.pix = (uint32_t)(rs.pos[0] * 16777216.f);
+                    rs.piy = (uint32_t)(rs.pos[1] * 16777216.f);
+                    rs.piz = (uint32_t)(rs.pos[2] * 16777216.f);
+                    rs.node = 0u;
+                    rs.woff = 24u - (uint32_t)G;
+                }
+            }
+            rec_pos += take;
+        }
+        bool active = rs.t < rs.tmax;
+        if (__builtin_amdgcn_ballot_w64(active) == 0ULL) {
+            if (drained) break;
+            continue;
+        }
+        const int exit_at = drained ? 0 : 64 - KREF;
+        int n_active;
+        do {
+            if (active) {  // ---- one node visit for every active lane (see render_persist)
+                RTO_DBG_AT(0)
+                uint32_t slot, w;
+                const uint32_t b = rs.node ? 2u : (uint32_t)G;
+                slot = (rs.node << b) | __builtin_amdgcn_ubfe(rs.pix, rs.woff, b);
+                slot = (slot << b) | __builtin_amdgcn_ubfe(rs.piy, rs.woff, b);
+                slot = (slot << b) | __builtin_amdgcn_ubfe(rs.piz, rs.woff, b);
+                if (rs.node == 0u) { RTO_DBG_AT(7) }
+                w = nodew[slot];
+                if ((int32_t)w >= -(1 << 30)) {  // internal: two levels down (from the grid: into the level-G node)
+                    RTO_DBG_AT(1)
+                    rs.node = w;
+                    if (regstack) {
+                        const bool first = rs.woff == 24u - (uint32_t)G;
+                        stk0 = first ? w : stk0;
+                        stk1 = first ? stk1 : w;
+                    } else
+                        stack[(((24u - (uint32_t)G) - rs.woff) >> 1) * 256u] = w;
+                    rs.woff -= 2u;
+                }
+                if ((int32_t)w < -(1 << 30)) {  // leaf: the march step (rt_core.cuh:241-270)
+#include "rto_march_leaf.inc"
+                }
+            }
+            active = rs.t < rs.tmax;
+            {
+                const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
+                asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n_active) : "s"(am) : "scc");
+            }
+        } while (n_active > exit_at);
+    }
+    if (!DIRECT && rs.nh) flush();  // rays that ended after the last refill round
+#ifdef RTO_DBG_COUNTERS
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int wi = i == 0 ? 16 + 1 : i, li = i == 0 ? 16 + 2 : 8 + i;
+        if (dbg_w[i]) atomicAdd(queue + wi, (unsigned long long)dbg_w[i]);
+        if (dbg_l[i]) atomicAdd(queue + li, (unsigned long long)dbg_l[i]);
+    }
+#endif
+}
+#undef RTO_RES_LDS_DMA_WAIT
 
 // One hit leaf of a quantised tree, shaded straight from the codebooks (TreeDev::qrec / qcolors): the
 // coefficients are the very fp16 values N3Tree::load_npz would have expanded (n3tree.cpp:310-339),
@@ -1786,7 +2183,9 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
             float basis_fn[RTO_BASIS_MAX_DEV];
             ray_basis(tree, opt, vdir, basis_fn);
             float o[4];
-            leaf_contrib<MODE>(tree, hit_slot<SPP>(he), basis_fn, (float)hit_count<SPP>(he), o);
+            uint32_t leaf = hit_slot<SPP>(he);
+            if (fb.res_flags & kResHitsWide) leaf = wide_to_slot(tree, leaf);  // (block-uniform) the traversal left entries of the two-level image
+            leaf_contrib<MODE>(tree, leaf, basis_fn, (float)hit_count<SPP>(he), o);
             s_c[wv][j] = o[0];
             s_c[wv][kShadeCap + j] = o[1];
             s_c[wv][2 * kShadeCap + j] = o[2];
@@ -1812,7 +2211,7 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
         __builtin_amdgcn_wave_barrier();
     }
 
-    FrameOut fo;
+    FrameOut fo = {};
     fo.aux = fd.aux;
     fo.image = fd.image;
     fo.stats = nullptr;
@@ -1875,6 +2274,18 @@ hipError_t launch_build_shrec(const uint16_t* data, int64_t n_slots, int data_di
                               hipStream_t stream) {
     const int64_t n = n_slots * rec;
     hipLaunchKernelGGL(build_shrec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data, n_slots, data_dim, rec, recidx, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_shrec_wide(const TreeDev& tree, const uint16_t* data, int64_t n_entries, int rec, uint16_t* out, hipStream_t stream) {
+    const int64_t n = n_entries * rec;
+    hipLaunchKernelGGL(build_shrec_wide_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tree, data, n_entries, rec, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_rebuild_reference_wide(const TreeDev& tree, int64_t n_entries, int rec, uint16_t* data, hipStream_t stream) {
+    const int64_t n = n_entries * rec;
+    hipLaunchKernelGGL(rebuild_reference_wide_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tree, n_entries, rec, data);
     return hipGetLastError();
 }
 
@@ -1942,14 +2353,16 @@ hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev&
                          const Pcg32& rng, const PcgJumpEntry* jump, const FrameOut& fo, int strip_rows,
                          hipStream_t stream) {
     switch (spp) {  // volrend.cu:266-278
+#ifndef RTO_DEV_SPP6_ONLY
         case 1: return launch_spp<1>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
         case 2: return launch_spp<2>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
         case 3: return launch_spp<3>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
         case 4: return launch_spp<4>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
-        case 6: return launch_spp<6>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
         case 8: return launch_spp<8>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
         case 16: return launch_spp<16>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
         case 32: return launch_spp<32>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
+#endif
+        case 6: return launch_spp<6>(kernel, tree, cam, opt, rng, jump, fo, strip_rows, stream);
         default: return hipErrorInvalidValue;
     }
 }
@@ -1960,15 +2373,28 @@ hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev&
 #ifndef RTO_WPS_DEFAULT
 #define RTO_WPS_DEFAULT 8
 #endif
-template <int SPP, int REFILL, int WPS, bool WIDE>
-static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
+template <int SPP, int REFILL, int WPS, bool WIDE, int RES = 0>  // RES: 0 render_persist, 1 render_persist_res, 2 ... with direct hit stores
+static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb_in, int res_flags,
                                     const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
                                     int chunk_override, bool cull, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
     // dynamic LDS: ancestor stack + thresholds per lane, then the frame table of THIS batch (96 B per frame: a batch of
     // one does not pay for 128)
-    const size_t lds = (size_t)(tree.max_depth + 1 - tree.top_levels + SPP + 1) * 256 * sizeof(uint32_t) +
-                       sizeof(float) * kCamFloats * (size_t)fb.n;
-    const void* fn = reinterpret_cast<const void*>(&render_persist<SPP, REFILL, WPS, WIDE>);
+    // (RES, the reservoir kernel: no frame table -- a tile's camera arrives by scalar loads --, no stack rows when the ancestor
+    //  stack lives in registers, 10 dwords per lane of ray records, 13 with the NDC warp)
+    const bool res_regstack = (tree.max_depth - tree.top_levels + 1) / 2 <= 2;
+    const size_t lds = RES ? (size_t)(SPP + 2 + 10 + (res_regstack ? 0 : tree.max_depth + 1 - tree.top_levels) + (tree.ndc_width > 0 ? 3 : 0)) * 256 * sizeof(uint32_t)
+                           : (size_t)(tree.max_depth + 1 - tree.top_levels + SPP + 1) * 256 * sizeof(uint32_t) + sizeof(float) * kCamFloats * (size_t)fb_in.n;
+    auto kern = [] {
+        if constexpr (RES)
+            return &render_persist_res<SPP, REFILL, WPS, RES == 2>;
+        else
+            return &render_persist<SPP, REFILL, WPS, WIDE>;
+    }();
+    FrameBatch fb = fb_in;
+    // (the reservoir kernel never translates its hit entries: they name their records directly, TreeDev::rec_by_entry, or the
+    //  shading kernel translates)
+    fb.res_flags = RES ? ((res_flags & ~kResHitsWide) | (tree.rec_by_entry ? 0 : kResHitsWide)) : 0;
+    const void* fn = reinterpret_cast<const void*>(kern);
     OccupancyCache local;
     if (!occ) occ = &local;
     occ->lds_refused = false;
@@ -1985,7 +2411,7 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
             }
         }
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_persist<SPP, REFILL, WPS, WIDE>, 256, lds) != hipSuccess || nb < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1)
             nb = 2;
         occ->blocks_per_cu = nb > 8 ? 8 : nb;
         occ->fn = fn;
@@ -2024,7 +2450,7 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
     // this context ended
     if (hipMemsetAsync(queue, 0, kQueueWords * sizeof(unsigned long long), stream) != hipSuccess) return hipErrorLaunchFailure;
     if (ev) (void)hipEventRecord(ev[1], stream);
-    hipLaunchKernelGGL((render_persist<SPP, REFILL, WPS, WIDE>), dim3(grid), dim3(256), lds, stream, tree, opt, fb, queue, hits, chunk);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, tree, opt, fb, queue, hits, chunk);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
     if (ev) (void)hipEventRecord(ev[2], stream);
 #ifndef RTO_SHADE_P
@@ -2060,11 +2486,14 @@ template <int SPP>
 static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                    const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
                                    int refill, bool cull, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
-    const int chunk_override = (refill / 1000) * 64;  // tuning: refill = 1000 * tiles_per_dequeue + threshold
+    // tuning: refill = 100000 * reservoir-kernel flags (kResPrefetch | kResHitsWide) + 1000 * tiles_per_dequeue + threshold
+    const int res_flags = refill / 100000;
+    refill %= 100000;
+    const int chunk_override = (refill / 1000) * 64;
     refill %= 1000;
     const bool wide = tree.widew != nullptr;
     if constexpr (SPP == 6) {  // tuning instantiations only for the benchmark configuration (and its usual two-level image)
-#define RTO_F(R, O) return launch_batch_impl<SPP, R, O, true>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream)
+#define RTO_F(R, O) return launch_batch_impl<SPP, R, O, true>(tree, opt, fb, 0, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream)
         if (wide) switch (refill) {  // A/B set kept for tools/ab_tuning.py: 100 * waves/SIMD + refill threshold
             case 808: RTO_F(8, 8);
             case 816: RTO_F(16, 8);
@@ -2079,6 +2508,28 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
             default: break;
         }
 #undef RTO_F
+#define RTO_R(K, O) return launch_batch_impl<SPP, K, O, true, 1>(tree, opt, fb, res_flags, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream)
+#define RTO_D(K, O) return launch_batch_impl<SPP, K, O, true, 2>(tree, opt, fb, res_flags, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream)
+        if (wide) switch (refill) {  // the reservoir kernel (round 5): 900 + idle-lane threshold at 8 waves per SIMD, 500 + at 7; 400 + / 300 + = direct hit stores
+            case 908: RTO_R(8, 8);
+            case 912: RTO_R(12, 8);
+            case 916: RTO_R(16, 8);
+            case 924: RTO_R(24, 8);
+            case 932: RTO_R(32, 8);
+            case 508: RTO_R(8, 7);
+            case 512: RTO_R(12, 7);
+            case 516: RTO_R(16, 7);
+            case 524: RTO_R(24, 7);
+            case 532: RTO_R(32, 7);
+            case 408: RTO_D(8, 8);
+            case 416: RTO_D(16, 8);
+            case 308: RTO_D(8, 7);
+            case 316: RTO_D(16, 7);
+            case 324: RTO_D(24, 7);
+            default: break;
+        }
+#undef RTO_D
+#undef RTO_R
     }
     // Refill once half the lanes are idle (larger refill rounds waste fewer issue slots on the partially filled ray set-up:
     // 32 idle lanes beat 16 by 4 %); registers budgeted for RTO_WPS_DEFAULT waves per SIMD.  Occupancy matters (round 3,
@@ -2087,23 +2538,36 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
     // which change the register budget, not the number of resident waves).
     // The two-level traversal image when the tree has one (always, unless it would not fit its index space or the device's
     // memory: rto_abi.cpp build_wide_image), else the one-level image: the same pixels either way.
+    // Round 5 default: the reservoir kernel (render_persist_res) -- refill once RTO_RES_DEFAULT lanes idle, 7 waves per SIMD (72
+    // VGPRs: spill-free; at 64 the allocator spills ray state inside the march loop), thresholds prefetched at set-up and
+    // loaded LDS-direct at refill.  refill = 832 / 732: the round-4 kernel (A/B).  Frames of 2^25 pixels or more keep the
+    // round-4 kernel (the reservoir kernel packs frame and pixel into one word).
+#ifndef RTO_RES_DEFAULT
+#define RTO_RES_DEFAULT 24
+#endif
+    if (wide && RTO_RES_DEFAULT > 0 && refill == 0 && (int64_t)fb.width * fb.height < (int64_t(1) << 25))
+        return launch_batch_impl<SPP, RTO_RES_DEFAULT ? RTO_RES_DEFAULT : 24, 7, true, 1>(tree, opt, fb, kResPrefetch | kResLdsDma, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream);
     if (wide)
-        return launch_batch_impl<SPP, 32, RTO_WPS_DEFAULT, true>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream);
-    return launch_batch_impl<SPP, 32, RTO_WPS_DEFAULT, false>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream);
+        return launch_batch_impl<SPP, 32, RTO_WPS_DEFAULT, true>(tree, opt, fb, 0, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream);
+    return launch_batch_impl<SPP, 32, RTO_WPS_DEFAULT, false>(tree, opt, fb, 0, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream);
 }
 
 hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
                                int refill, bool cull, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
     switch (spp) {
+#ifndef RTO_DEV_SPP6_ONLY  // (development builds: compile the benchmark's instantiation only)
         case 1: return launch_batch_spp<1>(tree, opt, fb, jump, queue, hits, num_cus, refill, cull, occ, ev, stream);
         case 2: return launch_batch_spp<2>(tree, opt, fb, jump, queue, hits, num_cus, refill, cull, occ, ev, stream);
         case 3: return launch_batch_spp<3>(tree, opt, fb, jump, queue, hits, num_cus, refill, cull, occ, ev, stream);
         case 4: return launch_batch_spp<4>(tree, opt, fb, jump, queue, hits, num_cus, refill, cull, occ, ev, stream);
+#endif
         case 6: return launch_batch_spp<6>(tree, opt, fb, jump, queue, hits, num_cus, refill, cull, occ, ev, stream);
+#ifndef RTO_DEV_SPP6_ONLY
         case 8: return launch_batch_spp<8>(tree, opt, fb, jump, queue, hits, num_cus, refill, cull, occ, ev, stream);
         case 16: return launch_batch_spp<16>(tree, opt, fb, jump, queue, hits, num_cus, refill, cull, occ, ev, stream);
         case 32: return launch_batch_spp<32>(tree, opt, fb, jump, queue, hits, num_cus, refill, cull, occ, ev, stream);
+#endif
         default: return hipErrorInvalidValue;
     }
 }

@@ -73,6 +73,11 @@ bool slots_fit_spp(int64_t n_slots, int spp) { return n_slots < (int64_t(1) << r
 // a hit entry names a leaf slot -- or, inside the batched traversal, an entry of the two-level image (a slightly larger index
 // space: TreeDev::wide_entries + the slots above the grid levels): both must fit the entry's slot bits at this SPP
 bool tree_fits_spp(const rto_tree* tree, int spp);
+// How the fast / batched kernels render `tree` at this SPP: 0 = not at all (generic kernel), 1 = with tree->dev as it is,
+// 2 = with *td = tree->dev minus the two-level image (its entries do not fit a hit entry at this SPP, the leaf slots do:
+// the one-level walk, whose hits name slots).  wide_bits > 0: test hook, pretend a hit entry leaves that many bits for an
+// entry of the two-level image.
+int fast_path_for_spp(const rto_tree* tree, int spp, int wide_bits, rto::TreeDev* td);
 
 bool spp_supported(int spp) {  // volrend.cu:266-278
     return spp == 1 || spp == 2 || spp == 3 || spp == 4 || spp == 6 || spp == 8 || spp == 16 || spp == 32;
@@ -132,6 +137,7 @@ struct rto_ctx {
     int last_n_queues = 0;                // of the last batched launch (rto_ctx_queue_stats)
     int64_t last_slots = 0;
     int batch_fallback = 0;               // tuning / test hook, see rto_ctx_set_tuning
+    int test_wide_bits = 0;               // test hook "wide_bits": pretend a hit entry has this many bits for an entry of the two-level image
     bool cull_single = false;             // tuning "cull_single": the single-frame kernel culls too.  Off by default: a LONE frame waits
                                           // for its longest rays (marked tiles), and the two extra launches cost it 14 us (0.375 ->
                                           // 0.389 ms); with several frames in flight the skipped work is throughput (+6 %)
@@ -697,10 +703,26 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
                 return fail(RTO_E_HIP, "hipMalloc(record index) failed");
             dev_bytes += (size_t)n_slots * 4;
         }
+        // Round 5: with a two-level traversal image the records follow ITS entries (TreeDev::rec_by_entry), so that a hit entry
+        // names its record and nothing translates between traversal and shading.  Not with compact records (their index is
+        // per slot), not when the entries would not fit the hit-entry budget of every SPP (2^26 at SPP 32: such a tree must
+        // stay able to fall back to the one-level walk, whose hits name slots), not with RTO_TREE_SLOT_RECORDS (A/B, tests).
+        const int64_t n_entries = t->dev.widew ? (int64_t)t->dev.wide_entries + (int64_t)t->dev.wide_grid_nodes * 64 : 0;
+        const bool by_entry = n_entries > 0 && !(flags & RTO_TREE_COMPACT_RECORDS) && n_entries < (int64_t(1) << 26) && !getenv("RTO_TREE_SLOT_RECORDS");
+        if (by_entry) n_rec = n_entries;
         const size_t rb = (size_t)n_rec * rec * 2;
         if (hipMalloc(&t->d_shrec, rb) == hipSuccess) {
-            hipError_t e = rto::launch_build_shrec((const uint16_t*)t->d_data, n_slots, data_dim, rec, (const uint32_t*)t->d_recidx,
-                                                   (uint16_t*)t->d_shrec, nullptr);
+            hipError_t e;
+            if (by_entry) {
+                rto::TreeDev td = t->dev;  // (the look-up tables of the two-level image are set; the rest of it as far as the kernel reads it)
+                td.nodew = (const uint32_t*)t->d_nodew;
+                td.data_dim = data_dim;
+                td.top_levels = top_levels;
+                e = rto::launch_build_shrec_wide(td, (const uint16_t*)t->d_data, n_entries, rec, (uint16_t*)t->d_shrec, nullptr);
+                t->dev.rec_by_entry = 1;
+            } else
+                e = rto::launch_build_shrec((const uint16_t*)t->d_data, n_slots, data_dim, rec, (const uint32_t*)t->d_recidx,
+                                            (uint16_t*)t->d_shrec, nullptr);
             if (e == hipSuccess) e = hipDeviceSynchronize();
             if (e != hipSuccess) return fail(RTO_E_HIP, std::string("build_shrec failed: ") + hipGetErrorString(e));
             dev_bytes += rb;
@@ -778,10 +800,29 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
 
 // child[] / data[] of a tree that dropped them at upload, back on the device for the generic kernel (same leaf values:
 // tests/test_render_parity.py::test_generic_kernel_on_a_tree_without_reference_arrays)
-bool tree_fits_spp(const rto_tree* tree, int spp) {
+bool tree_fits_spp(const rto_tree* tree, int spp) { return fast_path_for_spp(tree, spp, 0, nullptr) != 0; }
+
+int fast_path_for_spp(const rto_tree* tree, int spp, int wide_bits, rto::TreeDev* td) {
+    if (td) *td = tree->dev;
+    if (!tree->fast_ok) return 0;
     const int64_t n_slots = tree->info.capacity * tree->dev.N3;
     const int64_t wide = tree->dev.widew ? (int64_t)tree->dev.wide_entries + (int64_t)tree->dev.wide_grid_nodes * 64 : 0;
-    return slots_fit_spp(n_slots > wide ? n_slots : wide, spp);
+    const bool wide_fits = wide_bits > 0 ? wide < (int64_t(1) << wide_bits) : slots_fit_spp(wide, spp);
+    if (tree->dev.rec_by_entry) return wide_fits ? 1 : 0;  // (its records are indexed by the entries: no one-level fallback; the
+                                                           //  upload only chooses that layout when the entries fit every SPP)
+    if (!slots_fit_spp(n_slots, spp)) return 0;
+    if (wide_fits) return 1;
+    // the entry count of the two-level image can be ~8x the slot count of the deepest level (odd number of levels
+    // below the grid), so it can exceed the budget where the slots do not -- such a launch walks the one-level image
+    // (nodew + topgrid, the WIDE = false instantiations) instead of dropping to the generic kernel
+    if (td) {
+        td->widew = nullptr;
+        td->wgslot = nullptr;
+        td->worig = nullptr;
+        td->wide_entries = 0;
+        td->wide_grid_nodes = 0;
+    }
+    return 2;
 }
 
 int ensure_reference_arrays(const rto_tree* tree) {
@@ -801,8 +842,12 @@ int ensure_reference_arrays(const rto_tree* tree) {
     }
     hipError_t e = hipMemset((char*)d_data + data_bytes, 0, 16);
     if (e == hipSuccess)
-        e = rto::launch_rebuild_reference((const uint16_t*)t->d_shrec, (const uint32_t*)t->d_nodew, (const uint32_t*)t->d_recidx, n_slots,
-                                          t->dev.data_dim, t->shrec_halves, (uint16_t*)d_data, (int32_t*)d_child, nullptr);
+        e = rto::launch_rebuild_reference(t->dev.rec_by_entry ? nullptr : (const uint16_t*)t->d_shrec, (const uint32_t*)t->d_nodew,
+                                          (const uint32_t*)t->d_recidx, n_slots, t->dev.data_dim, t->shrec_halves, (uint16_t*)d_data,
+                                          (int32_t*)d_child, nullptr);
+    if (e == hipSuccess && t->dev.rec_by_entry)  // entry-ordered records: the coefficients in a second pass, entry by entry
+        e = rto::launch_rebuild_reference_wide(t->dev, (int64_t)t->dev.wide_entries + (int64_t)t->dev.wide_grid_nodes * 64, t->shrec_halves,
+                                               (uint16_t*)d_data, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         (void)hipFree(d_data);
@@ -1309,6 +1354,8 @@ int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value) {
         return build_tile_tables(c);
     } else if (k == "refill") {
         c->refill = value;
+    } else if (k == "wide_bits") {  // test hook (fast_path_for_spp): 0 = the real budget
+        c->test_wide_bits = value;
     } else if (k == "cull") {  // empty-space culling of the batched path (1 = on; same pixels either way)
         c->cull_on = value != 0;
     } else if (k == "cull_single") {  // rto_launch_renderer's fast kernel skips the tiles no culling cell projects into (same pixels)
@@ -1454,7 +1501,8 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
     if (!(cam->fx != 0.f) || !(cam->fy != 0.f)) return set_err(RTO_E_INVALID, "camera focal length is zero");
 
     int kernel = ctx->kernel;
-    const bool fast_here = tree->fast_ok && tree_fits_spp(tree, o->spp);
+    rto::TreeDev tdev;
+    const bool fast_here = fast_path_for_spp(tree, o->spp, ctx->test_wide_bits, &tdev) != 0;
     if (kernel == RTO_KERNEL_AUTO) kernel = fast_here ? RTO_KERNEL_FAST : RTO_KERNEL_GENERIC;
     if (kernel == RTO_KERNEL_FAST && !fast_here)
         return set_err(RTO_E_UNSUPPORTED, "fast kernel needs an N == 2 tree of depth <= 24 whose leaf slots fit 31 - ceil(log2 spp) bits "
@@ -1481,7 +1529,7 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
     cd.fy = cam->fy;
     std::memcpy(cd.transform, cam->transform, sizeof(cd.transform));
     const rto::OptDev od = make_opt_dev(o);
-    rto::FrameOut fo;
+    rto::FrameOut fo = {};
     fo.aux = rto_ctx_aux(ctx);
     fo.image = o->denoise ? rto_ctx_noisy(ctx) : rto_ctx_image(ctx);  // volrend.cu:206
     fo.stats = nullptr;
@@ -1509,7 +1557,7 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
             HIP_TRY(hipMalloc((void**)&ctx->tile_mask, (size_t)ctx->frames * mask_words * sizeof(uint32_t)));
             ctx->mask_words = mask_words;
         }
-        HIP_TRY(rto::launch_mark_tiles_one(tree->dev, cd, ctx->tile_mask, mask_words, stream));
+        HIP_TRY(rto::launch_mark_tiles_one(tdev, cd, ctx->tile_mask, mask_words, stream));
         fo.cull_marks = ctx->tile_mask;
         fo.cull_mask_words = mask_words;
     }
@@ -1526,7 +1574,9 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
     }
 
     if (!keep_marks) ctx->marks_n = 0;  // (the generic kernel and the counting instantiation mark no tiles)
-    hipError_t e = rto::launch_render(kernel, o->spp, tree->dev, cd, od, ctx->rng, ctx->jump, fo, ctx->strip_rows, stream);
+    // (the generic kernel reads tree->dev itself: child[] / data[] may just have been rebuilt by ensure_reference_arrays)
+    hipError_t e = rto::launch_render(kernel, o->spp, kernel == RTO_KERNEL_FAST ? tdev : tree->dev, cd, od, ctx->rng, ctx->jump, fo,
+                                      ctx->strip_rows, stream);
     if (e != hipSuccess) return set_err(RTO_E_HIP, std::string("render launch failed: ") + hipGetErrorString(e));
     if (cull_one) {  // the selected slot's marks, for rto_ctx_tile_marks / the culled denoise stage
         ctx->marks_n = 1;
@@ -1572,7 +1622,7 @@ static int generic_frames(const rto_tree* tree, const rto_camera* cams, const in
         rto::Pcg32 rng = ctx->rng;
         rng.state = j.mult * ctx->rng.state + j.plus;
         const size_t slot = (size_t)(slot0 + f);
-        rto::FrameOut fo;
+        rto::FrameOut fo = {};
         fo.aux = ctx->aux + slot * RTO_AUX_CHANNELS * px;
         fo.image = (o->denoise ? ctx->noisy : ctx->image) + slot * 4 * px;
         fo.stats = nullptr;
@@ -1603,7 +1653,8 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");
     ctx->marks_n = 0;  // whatever happens below, the tile marks of an earlier launch no longer describe this context's frames
-    if (!tree->fast_ok || !tree_fits_spp(tree, o->spp) || ctx->batch_fallback == 1) {
+    rto::TreeDev tdev;
+    if (fast_path_for_spp(tree, o->spp, ctx->test_wide_bits, &tdev) == 0 || ctx->batch_fallback == 1) {
         // No traversal image (N != 2, depth > 24, >= 2^29 leaf slots: the top-grid entry's budget) or more slots than a
         // hit-list entry can name at this SPP (2^28 at spp <= 8, 2^26 at spp 32): the same frames, one launch of the
         // generic kernel each -- same images, without the batching gain.
@@ -1706,10 +1757,11 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     hipEvent_t* ev = nullptr;
     if (ctx->kt_on && ctx->kt_count < kKtRing) ev = &ctx->kt_ev[(size_t)ctx->kt_count++ * 4];
     ctx->occ.force_lds_refusal = ctx->batch_fallback == 2;
-    hipError_t e = rto::launch_render_batch(o->spp, tree->dev, od, fb, ctx->jump, ctx->queue,
+    hipError_t e = rto::launch_render_batch(o->spp, tdev, od, fb, ctx->jump, ctx->queue,
                                             ctx->hits + (size_t)slot0 * o->spp * px,  // = fb.f[0].hits: the kernel indexes frames from here
                                             ctx->num_cus, ctx->refill, cull, &ctx->occ, ev, stream);
     if (ctx->occ.lds_refused) {
+        if (ev) --ctx->kt_count;  //  nothing was launched, nothing recorded the slot's events: give it back
         // the device does not grant a workgroup the LDS the traversal kernel needs for this depth x SPP x frame count
         // ((max_depth + 1 - top_levels + spp + 1) KB for the ancestor stack and thresholds + 56 B per frame); nothing but
         // the frame table was written so far: the same frames through the generic kernel, frame by frame

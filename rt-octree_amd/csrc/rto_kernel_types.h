@@ -63,6 +63,11 @@ struct TreeDev {
     // a record is ONE 128-byte line fetched by 16-byte loads; nullptr when absent (shading then reads data[]).  When it
     // exists the host releases `data` and `child` after the upload (both nullptr until the generic kernel asks for them).
     const uint16_t* shrec;
+    // Round 5: the records are laid out in the order of the TWO-LEVEL IMAGE's entries (record e = the leaf of entry e of widew;
+    // a leaf at the first level of a pair owns 8 entries and so 8 copies): a hit entry of the traversal then names its record
+    // directly -- no wgslot / worig / nodew look-ups between traversal and shading (they cost the shading kernel 0.37 ms per
+    // 100 frames, or the traversal's flush two dependent gathers per round).  0: shrec is indexed by the leaf slot.
+    int rec_by_entry;
     // RTO_TREE_COMPACT_RECORDS: shrec holds records only for the leaf slots a ray can hit (density > 0), in slot order;
     // recidx[slot] = its record, kNoRecord for the others.  nullptr: shrec is indexed by the slot itself.
     const uint32_t* recidx;
@@ -152,7 +157,12 @@ struct FrameBatch {
     uint32_t* chunk_base;
     int qchunk[kMaxQueues + 1];
     const FrameDesc* f;  // [n] in device memory (the context's table, written on the launch stream by write_frames_kernel)
+    // set by the launcher (render_persist_res): kResPrefetch = a tile's set-up touches its pixels' thresholds, so that the refill
+    // rounds find them in the L2; kResHitsWide = the hit entries name entries of the two-level image and the SHADING kernel
+    // translates them to leaf slots (wide_to_slot), not the traversal's flush
+    int res_flags;
 };
+constexpr int kResPrefetch = 1, kResHitsWide = 2, kResLdsDma = 4;  // kResLdsDma: thresholds go memory -> LDS directly (global_load_lds)
 struct FrameChunk {
     FrameDesc f[kFrameChunk];
 };

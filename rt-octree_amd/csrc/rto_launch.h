@@ -18,6 +18,11 @@ hipError_t launch_build_shrec(const uint16_t* data, int64_t n_slots, int data_di
 hipError_t launch_rebuild_reference(const uint16_t* shrec, const uint32_t* nodew, const uint32_t* recidx, int64_t n_slots, int data_dim,
                                     int rec, uint16_t* data, int32_t* child, hipStream_t stream);
 
+// entry-ordered records (TreeDev::rec_by_entry): built from data[] through the tree's two-level image (tree.widew / wgslot /
+// worig / nodew must be set), and data[]'s coefficients back from them (after launch_rebuild_reference with shrec = nullptr)
+hipError_t launch_build_shrec_wide(const TreeDev& tree, const uint16_t* data, int64_t n_entries, int rec, uint16_t* out, hipStream_t stream);
+hipError_t launch_rebuild_reference_wide(const TreeDev& tree, int64_t n_entries, int rec, uint16_t* data, hipStream_t stream);
+
 // top-of-tree shortcut grid: 2^(3G) entries (TreeDev::topgrid)
 hipError_t launch_build_topgrid(const uint32_t* nodew, int G, uint2* grid, hipStream_t stream);
 

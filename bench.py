@@ -61,9 +61,12 @@ WARM_FRAMES_REF = 100  # main_headless.cpp:469-479: 100 warm-up frames each adva
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8, help="timed steps; one step = one batch of --batch frames")
-    ap.add_argument("--warmup", type=int, default=2, help="untimed warm-up steps (batches)")
-    ap.add_argument("--batch", type=int, default=100, help="frames per step = per launch group (1..128)")
+    ap.add_argument("--steps", type=int, default=8, help="timed steps; one step = --groups-per-step launch groups of --batch frames")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed warm-up steps")
+    ap.add_argument("--batch", type=int, default=100, help="frames per launch group (1..128)")
+    ap.add_argument("--groups-per-step", type=int, default=12,
+                    help="launch groups per step: one step = groups-per-step x batch frames (default 1200 = six passes over the "
+                         "reference's 200-pose test trajectory), so that the driver's 20 steps keep the GPU busy for ~2 s")
     ap.add_argument("--size", type=int, default=800, help="square image size (config C2/C5)")
     ap.add_argument("--width", type=int, default=0, help="with --height: non-square frames (config C4: 1920x1080)")
     ap.add_argument("--height", type=int, default=0)
@@ -112,6 +115,9 @@ def parse_args(argv=None):
                     help="no GPU work: join the process group (gloo), print every rank's frame plan as JSON and exit -- "
                          "pins the rank / scene / pose / RNG-jump bookkeeping of a multi-GPU run on a CPU box")
     ap.add_argument("--net-cull", type=int, default=1, help="A/B: 0 = run GuidanceNet on every tile")
+    ap.add_argument("--full-outputs", action="store_true",
+                    help="A/B: the batched launches of the timed region store all 48 B per pixel (8 aux planes + noisy image) instead of "
+                         "the 16 B the fused denoise stage reads (rto_ctx_set_lean_outputs; same denoised images)")
     ap.add_argument("--no-filter-cull", action="store_true",
                     help="A/B: filter every tile, also those that see only culled (background) render tiles")
     ap.add_argument("--fp32-maps", action="store_true",
@@ -249,7 +255,7 @@ def plan_only(args):
     B = max(1, min(128, args.batch))
     n_scenes = 1 if args.tree else max(1, min(8, args.scenes))
     maps = ["pose", "scene"] if n_scenes > 1 else ["pose"]
-    mine = {m: plan_groups(args.steps * B, B, rank, world, n_poses_for(world), n_scenes, m) for m in maps}
+    mine = {m: plan_groups(args.steps * B * max(1, args.groups_per_step), B, rank, world, n_poses_for(world), n_scenes, m) for m in maps}
     plans = [mine]
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -259,7 +265,7 @@ def plan_only(args):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"world": world, "steps": args.steps, "batch": B, "frames_per_rank": args.steps * B, "scenes": n_scenes,
+        print(json.dumps({"world": world, "steps": args.steps, "batch": B, "groups_per_step": max(1, args.groups_per_step), "frames_per_rank": args.steps * B * max(1, args.groups_per_step), "scenes": n_scenes,
                           "plans": {m: [plans[r][m] for r in range(world)] for m in maps},
                           "rng_jump_of_pose": "%d + pose" % WARM_FRAMES_REF}))
 
@@ -403,6 +409,10 @@ def main():
     aux_t = torch.as_tensor(ctx.batch_views()[0], device=dev)  # zero-copy [B,8,H,W]
     # lane = (context, stream, network instance with its own output buffers, aux view)
     lanes = [(ctx, stream, net, aux_t)]
+    # lean outputs (round 5): the timed launch groups store (r, g, b, alpha) per pixel -- what GuidanceNet + filter read -- and
+    # no aux planes; only with the fused network (PyTorch's reads the aux tensor) and with denoise on
+    lean = denoise and not args.torch_net and not args.full_outputs
+    noisy_of = {id(ctx): torch.as_tensor(ctx.batch_views()[1], device=dev)}  # zero-copy [B,H,W,4]
     for _ in range(1, max(1, args.streams)):
         c2 = R.RenderContext(W, H, device=local_rank, frames=B)
         for kv in filter(None, args.tuning.split(",")):
@@ -411,9 +421,11 @@ def main():
         if denoise:
             n2 = compact.half().to(dev) if args.torch_net else denoiser.FusedGuidanceNet(compact, device=local_rank)
         lanes.append((c2, torch.cuda.Stream(dev), n2, torch.as_tensor(c2.batch_views()[0], device=dev)))
+        noisy_of[id(c2)] = torch.as_tensor(c2.batch_views()[1], device=dev)
 
     filter_mode = R.FILTER_EXACT if args.exact_filter else R.FILTER_FAST
-    n_frames = args.steps * B  # timed frames of this rank: one step = one batch
+    FS = B * max(1, args.groups_per_step)  # frames per step
+    n_frames = args.steps * FS  # timed frames of this rank
     # fused GuidanceNet + factorised filter: keep the maps in fp16 between the two kernels (same pixels, half the bytes)
     packed_route = denoise and not args.torch_net and not args.exact_filter and not args.fp32_maps
 
@@ -428,10 +440,15 @@ def main():
         n = len(idx)
         lctx, lstream, lnet, laux = lanes[lane]
         lctx.rng_seed()
+        lctx.set_lean_outputs(lean)
+        net_in = dict(rgba=True) if lean else dict(squares_implied=True)
+        if lean:
+            laux = noisy_of[id(lctx)]  # the network reads the (r, g, b, alpha) image the launch leaves
         if ev:
             ev[0].record(lstream)
         R.launch_renderer_batch(trees[scene], [cams[i] for i in idx], opt, lctx, lstream,
                                 rng_jumps=[WARM_FRAMES_REF + i for i in idx])
+        lctx.set_lean_outputs(False)  # (every other pass of this script reads full outputs)
         if ev:
             ev[1].record(lstream)
         if denoise:
@@ -439,13 +456,13 @@ def main():
             if packed_route and not exact:  # GuidanceNet -> fp16 maps in the handle's scratch -> factorised filter
                 # (network / filter tiles that see only culled = background render tiles are filled, not computed: same bits)
                 marks = None if args.no_filter_cull else lctx.tile_marks()
-                lnet.forward_packed(laux[:n], stream=lstream, squares_implied=True, cull=marks if args.net_cull else None)
+                lnet.forward_packed(laux[:n], stream=lstream, cull=marks if args.net_cull else None, **net_in)
                 if ev:
                     ev[2].record(lstream)
                 lnet.filter_packed(lctx.noisy_ptr, lctx.image_ptr, stream=lstream, shape=(n, H, W), cull=marks)
             elif not args.torch_net:  # fp32 weight / guidance planes (the reference's tensors); exact: the bit-exact filter
                 marks = None if args.no_filter_cull else lctx.tile_marks()
-                wm, gm = lnet(laux[:n], stream=lstream, squares_implied=True, cull=marks if args.net_cull else None)
+                wm, gm = lnet(laux[:n], stream=lstream, cull=marks if args.net_cull else None, **net_in)
                 if ev:
                     ev[2].record(lstream)
                 lnet.filter_planes(wm, gm, lctx.noisy_ptr, lctx.image_ptr, mode=R.FILTER_EXACT if exact else filter_mode,
@@ -463,7 +480,7 @@ def main():
         return plan_groups(n_frames, B, rank, world, len(poses), n_scenes, scene_map)
 
     def timed(scene_map, exact=False):
-        warm, work = plan(args.warmup * B, scene_map), plan(n_frames, scene_map)
+        warm, work = plan(args.warmup * FS, scene_map), plan(n_frames, scene_map)
         events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in work]
         if work:  # allocation pass (untimed, whatever --warmup is): every lane sees the largest group once, so no
             # buffer of the library or of torch's allocator is created inside the timed region
@@ -551,7 +568,10 @@ def main():
         nlast = len(last_group[1])
         for slot in sorted({0, nlast // 2, nlast - 1}):
             lctx.select_frame(slot)
-            spot_frames.append((last_group[0], last_group[1][slot], lctx.download_aux(stream=lanes[last_lane][1])))
+            # (lean launch: no aux planes -- the noisy image holds planes 0..3 as (r, g, b, alpha); planes 4..7 are their squares)
+            snap = (lctx.download_image(noisy=True, stream=lanes[last_lane][1]).transpose(2, 0, 1) if lctx.frames_are_lean(slot, 1)
+                    else lctx.download_aux(stream=lanes[last_lane][1]))
+            spot_frames.append((last_group[0], last_group[1][slot], snap))
         lctx.select_frame(0)
 
     # ---------------- untimed, N > 1: the path's one collective -- the final gather of RGBA8 frames to rank 0 ----------------
@@ -964,13 +984,14 @@ def main():
                 a8, px4 = (C.c_float * 8)(), (C.c_float * 4)()
                 orc.lib().orc_render_pixel(C.byref(zs[sc].c), C.byref(ocam), C.byref(oopt), C.byref(base), int(idx), a8, px4, None)
                 y, x = divmod(int(idx), W)
-                same = np.array_equal(np.array(a8[:], np.float32).view(np.uint32), aux[:, y, x].view(np.uint32))
+                same = np.array_equal(np.array(a8[:aux.shape[0]], np.float32).view(np.uint32), np.ascontiguousarray(aux[:, y, x]).view(np.uint32))
                 checked += 1
                 mismatched += 0 if same else 1
                 hit += 1 if a8[3] > 0 else 0
         parity = {"pixels_checked": checked, "mismatches": mismatched, "pixels_with_hits": hit,
                   "frames": [[sc, i] for sc, i, _ in spot_frames],
-                  "what": "8 aux planes (fp32 bits) of random pixels + corners + centre of frames of the LAST TIMED launch group "
+                  "values_per_pixel": int(spot_frames[0][2].shape[0]),
+                  "what": "8 aux planes (fp32 bits; after a lean launch: the 4 stored values = planes 0..3) of random pixels + corners + centre of frames of the LAST TIMED launch group "
                           "against oracle/'s render_kernel + trace_ray for that pixel (orc_render_pixel); the oracle is the "
                           "checker here, never the thing measured"}
         if mismatched:
@@ -1083,16 +1104,26 @@ def main():
         "dtype": "f32" if not denoise else "f32 (traversal, filter) + f16 x f16 -> f32 (GuidanceNet conv, %s)" % ("MIOpen" if args.torch_net else "fused MFMA kernel"),
         "data": "synthetic",
         "config": {
-            "workload": "configs[%s]: %slego-like synthetic PlenOctree %s (%d nodes, depth %d), %dx%d SPP=%d%s, 1 step = 1 batch of %d frames (one launch group), frames sharded %s"
+            "workload": "configs[%s]: %slego-like synthetic PlenOctree %s (%d nodes, depth %d), %dx%d SPP=%d%s, 1 step = %d launch groups of %d frames, frames sharded %s"
                         % ({"c2": "1", "c4": "3 stand-in", "c5": "4"}.get(wid, "2" if n_scenes > 1 else "1-like"),
                            ("%d scenes, " % n_scenes) if n_scenes > 1 else "",
                            tree.data_format, tree.capacity, tree.max_depth, W, H, args.spp,
-                           " + GuidanceNet(8,32,5,2,4) denoise" if denoise else " raw (no denoise)", B,
+                           " + GuidanceNet(8,32,5,2,4) denoise" if denoise else " raw (no denoise)", max(1, args.groups_per_step), B,
                            "scene s -> rank s mod N" if (maps[0] == "scene" and n_scenes > 1) else "frame g -> rank g mod N"),
             "tree_nodes": int(tree.capacity), "tree_device_mb": tree.device_bytes / 1e6,
-            "frames_per_step": B, "frames_timed": total_frames, "frames_per_launch": frames_per_launch, "streams": len(lanes),
+            "frames_per_step": FS, "groups_per_step": max(1, args.groups_per_step), "frames_per_group": B, "frames_timed": total_frames, "frames_per_launch": frames_per_launch, "streams": len(lanes),
             "scenes": n_scenes, "scene_map": maps[0], "filter": "exact" if args.exact_filter else "factorised", "maps": "fp16 packed" if packed_route else "fp32 planes",
             "parallelism": "frames x%d" % world,
+            # which clause of the north star each figure claims (VERDICT r4 task 4)
+            "value_route": ("render stage bit-exact against oracle/ (fp32 aux planes / RGBA8 of the noisy frame: parity_spot); denoise "
+                            "stage = fused fp16 GuidanceNet + %s" % ("the bit-exact filter" if (args.exact_filter or not packed_route) else
+                            "FACTORISED filter on packed fp16 maps: the TOLERANCE route (north star: 'within 1e-4 PSNR otherwise'; "
+                            "150 dB against the exact filter, psnr.rgba8_bytes_differing_factorised_vs_exact)")) if denoise else
+                           "raw render, bit-exact against oracle/",
+            "value_exact": exact_pass["value"] if exact_pass else None,  # the same frames through the bit-exact filter route
+            "reference_loop_fps": ref_loop["fps"] if ref_loop else None,  # the reference's loop shape: one launch + one host wait per frame
+            "reference_loop_pipelined_wall_fps": (ref_loop.get("pipelined") or {}).get("wall_fps") if ref_loop else None,
+            "lean_outputs": bool(lean),
             "world": world, "backend": (backend if world > 1 else None), "gpus_visible": n_dev,
             "launcher": ("none" if world == 1 else "bench.py itself (child torch.distributed.run)"
                          if os.environ.get("RTO_BENCH_SELF_LAUNCHED") else "external (torchrun)"),

@@ -207,6 +207,18 @@ int rto_ctx_set_kernel(rto_ctx* c, int kernel);
  * workgroups of the persistent traversal kernel per CU as fit, else a cap 1..8: the kernel's true occupancy knob --
  * `refill`'s waves/SIMD only sets the register budget). */
 int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value);
+/* Lean outputs of the batched render -> denoise route (round 5; off by default).  The reference's kernel stores, per pixel,
+ * 8 aux planes and an RGBA32F image (volrend.cu:187-212: 48 bytes) -- of which its own denoise stage reads aux planes 0..3
+ * (planes 4..7 are their squares) and the image's rgb, which duplicates planes 0..2.  With lean outputs on, a
+ * rto_launch_renderer_batch with options.denoise = 1 stores 16 bytes per pixel instead: the noisy image as (r, g, b, ALPHA)
+ * -- alpha = aux plane 3 where the reference writes 1.0 -- and NO aux planes (the context's aux buffer keeps whatever it
+ * held).  Consumers: rto_denoise (picks the route by itself), or rto_guidance_net_forward*(..., flags = RTO_NET_INPUT_RGBA)
+ * on rto_ctx_noisy + rto_filtering* on the same image (the filter never reads the image's alpha, filtering.cu:186-199).
+ * The denoised image is bit-identical to the full-output route's.  Single-frame launches, launches with denoise = 0 and
+ * everything that reads the aux buffer (--write_buffer, rto_ctx_download_aux) need the full outputs: leave it off there.
+ * rto_ctx_frames_are_lean: 1 when slots [first_slot, first_slot + n) were all written by a lean launch last. */
+int rto_ctx_set_lean_outputs(rto_ctx* c, int on);
+int rto_ctx_frames_are_lean(const rto_ctx* c, int first_slot, int n);
 /* Per-kernel HIP-event timing of the batched path: when enabled, every rto_launch_renderer_batch
  * records events before the traversal kernel, between it and the shading kernel, and after (on the
  * launch stream; up to 256 launches between reads).  _read synchronises on the recorded events and
@@ -334,6 +346,10 @@ int rto_guidance_net_forward(const rto_guidance_net* net, void* stream, const fl
  * 0..3, which is how the renderer fills them (volrend.cu:195-202); the kernel then reads planes 0..3 only and
  * squares them itself: the same values from half the bytes.  Results are bit-identical to flags = 0 on such input. */
 #define RTO_NET_AUX_SQUARES_IMPLIED 1
+/* RTO_NET_INPUT_RGBA (round 5) -- `aux` is not an aux buffer but an interleaved image, device [n][H][W][4] fp32 = (r, g, b,
+ * alpha): the values of aux planes 0..3 (volrend.cu:187-194), as a LEAN batched launch leaves them in the context's noisy
+ * buffer (rto_ctx_set_tuning "lean_outputs").  Squares implied.  Bit-identical maps to the aux-buffer input. */
+#define RTO_NET_INPUT_RGBA 2
 int rto_guidance_net_forward_ex(const rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W,
                                 float* weight_map, float* guidance_map, int flags);
 /* The denoise stage (Denoiser::denoise, denoiser.cpp:31-61) as two launches that keep the maps in their native

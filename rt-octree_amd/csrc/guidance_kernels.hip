@@ -74,8 +74,10 @@ struct NetCull {
 #ifndef RTO_NET_SQ0_WG
 #define RTO_NET_SQ0_WG 3
 #endif
-template <int C1, int L, bool SQ, bool PACK>
-__global__ void __launch_bounds__(256, SQ ? 4 : RTO_NET_SQ0_WG) guidance_fused(const float* __restrict__ aux,    // [n][8][H][W]
+// IN (round 5): 0 = all 8 aux planes, 1 = SQ, 2 = SQ from the INTERLEAVED image a lean batched launch leaves ([n][H][W][4] =
+// r, g, b, alpha -- the values of aux planes 0..3, rto_ctx_set_tuning "lean_outputs"): one 16-byte load per staged pixel.
+template <int C1, int L, int IN, bool PACK>
+__global__ void __launch_bounds__(256, IN ? 4 : RTO_NET_SQ0_WG) guidance_fused(const float* __restrict__ aux,    // [n][8][H][W] (IN = 2: [n][H][W][4])
                                                        const _Float16* __restrict__ w1,  // [C1][96]   k = tap*8 + ci; k = 72: bias
                                                        const _Float16* __restrict__ w2,  // [16][9*C1] k = tap*C1 + ci
                                                        const float* __restrict__ b2,     // [16]
@@ -112,7 +114,8 @@ __global__ void __launch_bounds__(256, SQ ? 4 : RTO_NET_SQ0_WG) guidance_fused(c
     const int tx_first = blockIdx.x * kStrip;
     const int y0 = blockIdx.y * kGH;
     const int64_t HW = (int64_t)H * W;
-    aux += (int64_t)blockIdx.z * kCIn * HW;
+    constexpr bool SQ = IN != 0;
+    aux += (int64_t)blockIdx.z * (IN == 2 ? 4 : kCIn) * HW;
     weight_out += (int64_t)blockIdx.z * L * HW;  // (PACK: [H][W][8] fp16 = 4 floats per pixel = L * HW floats per image too)
     guidance_out += (int64_t)blockIdx.z * L * HW;
 
@@ -182,10 +185,18 @@ __global__ void __launch_bounds__(256, SQ ? 4 : RTO_NET_SQ0_WG) guidance_fused(c
             const int gx = x0 - 2 + tx, gy = y0 - 2 + ty;
             const bool in = e < NPIX && gx >= 0 && gx < W && gy >= 0 && gy < H;
             const int gi = in ? gy * W + gx : 0;  // (8 * H * W < 2^31: rto_ctx_create's size check)
+            if constexpr (IN == 2) {
+                const float4 t = reinterpret_cast<const float4*>(aux)[gi];
+                v[it][0] = in ? t.x : 0.f;
+                v[it][1] = in ? t.y : 0.f;
+                v[it][2] = in ? t.z : 0.f;
+                v[it][3] = in ? t.w : 0.f;
+            } else {
 #pragma unroll
-            for (int c = 0; c < NLD; ++c) {
-                const float t = aux[c * (int)HW + gi];
-                v[it][c] = in ? t : 0.f;
+                for (int c = 0; c < NLD; ++c) {
+                    const float t = aux[c * (int)HW + gi];
+                    v[it][c] = in ? t : 0.f;
+                }
             }
         }
     };
@@ -406,9 +417,9 @@ __global__ void __launch_bounds__(256, SQ ? 4 : RTO_NET_SQ0_WG) guidance_fused(c
 
 hipError_t launch_guidance_net(const float* aux, const void* w1, const void* w2, const float* b2, int c1,
                                int levels, int n, int H, int W, float* weight_out, float* guidance_out,
-                               bool squares_implied, const uint32_t* tile_mask, int mask_words, const uint32_t* fill_k,
+                               int in_mode, const uint32_t* tile_mask, int mask_words, const uint32_t* fill_k,
                                const float* fill_planes, hipStream_t stream) {
-    if (c1 != 32 || levels != 4) return hipErrorInvalidValue;  // the reference configuration (blender.txt:21-25)
+    if (c1 != 32 || levels != 4 || in_mode < 0 || in_mode > 2) return hipErrorInvalidValue;  // the reference configuration (blender.txt:21-25)
     const int tiles_x = (W + kGW - 1) / kGW;
     const dim3 grid((tiles_x + kStrip - 1) / kStrip, (H + kGH - 1) / kGH, n), block(256);
     const bool pack = guidance_out == nullptr;  // weight_out is then the packed fp16 buffer [n][H][W][8]
@@ -418,13 +429,13 @@ hipError_t launch_guidance_net(const float* aux, const void* w1, const void* w2,
     cull.tiles_x = (W + 7) / 8;
     cull.fill = cull.mask && pack ? make_uint4(fill_k[0], fill_k[1], fill_k[2], fill_k[3]) : make_uint4(0u, 0u, 0u, 0u);
     for (int i = 0; i < 8; ++i) cull.planes[i] = cull.mask && !pack ? fill_planes[i] : 0.f;
-#define RTO_NET(SQ, PK)                                                                                                   \
-    hipLaunchKernelGGL((guidance_fused<32, 4, SQ, PK>), grid, block, 0, stream, aux, (const _Float16*)w1, (const _Float16*)w2,     \
+#define RTO_NET(IN, PK)                                                                                                   \
+    hipLaunchKernelGGL((guidance_fused<32, 4, IN, PK>), grid, block, 0, stream, aux, (const _Float16*)w1, (const _Float16*)w2,     \
                        b2, weight_out, guidance_out, H, W, cull)
     if (pack) {
-        if (squares_implied) RTO_NET(true, true); else RTO_NET(false, true);
+        if (in_mode == 2) RTO_NET(2, true); else if (in_mode == 1) RTO_NET(1, true); else RTO_NET(0, true);
     } else {
-        if (squares_implied) RTO_NET(true, false); else RTO_NET(false, false);
+        if (in_mode == 2) RTO_NET(2, false); else if (in_mode == 1) RTO_NET(1, false); else RTO_NET(0, false);
     }
 #undef RTO_NET
     return hipGetLastError();

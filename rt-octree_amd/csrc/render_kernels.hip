@@ -2226,7 +2226,11 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
             out[p][2] *= INV_SPP;
             out[p][3] *= INV_SPP;
         }
-        write_pixel(fo, SIZE, (int)idx, opt.background_brightness, out[p]);
+        if (fb.lean) {  // (block-uniform) volrend.cu:174-178 + the four values its consumers read, in one 16-byte store
+            const float remain = opt.background_brightness * (1.f - out[p][3]);
+            reinterpret_cast<float4*>(fo.image)[idx] = make_float4(out[p][0] + remain, out[p][1] + remain, out[p][2] + remain, out[p][3]);
+        } else
+            write_pixel(fo, SIZE, (int)idx, opt.background_brightness, out[p]);
     }
 }
 

@@ -137,6 +137,8 @@ struct rto_ctx {
     int last_n_queues = 0;                // of the last batched launch (rto_ctx_queue_stats)
     int64_t last_slots = 0;
     int batch_fallback = 0;               // tuning / test hook, see rto_ctx_set_tuning
+    bool lean = false;                    // rto_ctx_set_lean_outputs
+    int lean_first = 0, lean_n = 0;       // slots the last launch wrote lean (lean_n = 0: none)
     int test_wide_bits = 0;               // test hook "wide_bits": pretend a hit entry has this many bits for an entry of the two-level image
     bool cull_single = false;             // tuning "cull_single": the single-frame kernel culls too.  Off by default: a LONE frame waits
                                           // for its longest rays (marked tiles), and the two extra launches cost it 14 us (0.375 ->
@@ -1337,6 +1339,16 @@ int rto_wide_image_probe(const int32_t* child, const uint16_t* sigma_bits, int64
     return RTO_OK;
 }
 
+int rto_ctx_set_lean_outputs(rto_ctx* c, int on) {
+    if (!c) return set_err(RTO_E_INVALID, "rto_ctx_set_lean_outputs: null context");
+    c->lean = on != 0;
+    return RTO_OK;
+}
+
+int rto_ctx_frames_are_lean(const rto_ctx* c, int first_slot, int n) {
+    return c && n > 0 && c->lean_n > 0 && first_slot >= c->lean_first && first_slot + n <= c->lean_first + c->lean_n ? 1 : 0;
+}
+
 int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value) {
     if (!c || !key) return set_err(RTO_E_INVALID, "rto_ctx_set_tuning: null argument");
     const std::string k(key);
@@ -1574,6 +1586,7 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
     }
 
     if (!keep_marks) ctx->marks_n = 0;  // (the generic kernel and the counting instantiation mark no tiles)
+    if (ctx->lean_n > 0 && ctx->sel >= ctx->lean_first && ctx->sel < ctx->lean_first + ctx->lean_n) ctx->lean_n = 0;  // (a single frame has full outputs)
     // (the generic kernel reads tree->dev itself: child[] / data[] may just have been rebuilt by ensure_reference_arrays)
     hipError_t e = rto::launch_render(kernel, o->spp, kernel == RTO_KERNEL_FAST ? tdev : tree->dev, cd, od, ctx->rng, ctx->jump, fo,
                                       ctx->strip_rows, stream);
@@ -1598,6 +1611,7 @@ int rto_launch_renderer_batch(const rto_tree* tree, const rto_camera* cams, cons
 static int generic_frames(const rto_tree* tree, const rto_camera* cams, const int64_t* rng_jumps, int n, const rto_options* o,
                           rto_ctx* ctx, void* stream_, int slot0) {
     ctx->marks_n = 0;
+    ctx->lean_n = 0;  // (full outputs: the generic kernel knows no lean mode)
     if (tree->quant)
         return set_err(RTO_E_UNSUPPORTED, "a quantised tree kept quantised cannot take the generic kernel (too many leaf slots for the "
                                           "batched kernels at this spp, or the traversal kernel's LDS was refused)");
@@ -1653,6 +1667,7 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");
     ctx->marks_n = 0;  // whatever happens below, the tile marks of an earlier launch no longer describe this context's frames
+    ctx->lean_n = 0;
     rto::TreeDev tdev;
     if (fast_path_for_spp(tree, o->spp, ctx->test_wide_bits, &tdev) == 0 || ctx->batch_fallback == 1) {
         // No traversal image (N != 2, depth > 24, >= 2^29 leaf slots: the top-grid entry's budget) or more slots than a
@@ -1730,6 +1745,7 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     const size_t px = frame_px(ctx);
     rto::FrameDesc frames[rto::kMaxBatch];
     fb.f = ctx->d_frames;
+    fb.lean = ctx->lean && o->denoise ? 1 : 0;
     for (int f = 0; f < n; ++f) {
         if (cams[f].width != ctx->width || cams[f].height != ctx->height)
             return set_err(RTO_E_INVALID, "camera size does not match the render context");
@@ -1771,6 +1787,10 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     ctx->marks_n = n;
     ctx->marks_slot0 = slot0;
     ctx->marks_bg = o->background_brightness;
+    if (fb.lean) {
+        ctx->lean_first = slot0;
+        ctx->lean_n = n;
+    }
     return RTO_OK;
 }
 

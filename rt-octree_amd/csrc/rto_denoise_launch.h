@@ -45,9 +45,11 @@ hipError_t launch_filter_backward(const float* grad_out, const float* img_in, co
 
 // fused compact GuidanceNet (guidance_kernels.hip): w1 fp16 [c1][96], w2 fp16 [16][9*c1], b2 [16];
 // guidance_out == nullptr: weight_out receives the packed fp16 maps [n][H][W][8] instead
+// in_mode: 0 = aux [n][8][H][W]; 1 = the same, planes 4..7 implied (squares of planes 0..3); 2 = aux is an interleaved image
+// [n][H][W][4] = r, g, b, alpha (planes 0..3 of the aux buffer, as a lean batched launch leaves them), squares implied
 hipError_t launch_guidance_net(const float* aux, const void* w1, const void* w2, const float* b2, int c1,
                                int levels, int n, int H, int W, float* weight_out, float* guidance_out,
-                               bool squares_implied, const uint32_t* tile_mask, int mask_words, const uint32_t* fill_k,
+                               int in_mode, const uint32_t* tile_mask, int mask_words, const uint32_t* fill_k,
                                const float* fill_planes, hipStream_t stream);
 
 }  // namespace rto

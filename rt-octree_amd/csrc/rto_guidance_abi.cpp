@@ -96,6 +96,9 @@ int rto_guidance_net_create(const float* w1, const float* b1, const float* w2, c
     return RTO_OK;
 }
 
+// flags of the forward calls -> launch_guidance_net's in_mode
+static int net_in_mode(int flags) { return (flags & RTO_NET_INPUT_RGBA) ? 2 : (flags & RTO_NET_AUX_SQUARES_IMPLIED) ? 1 : 0; }
+
 int rto_guidance_net_forward(const rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W,
                              float* weight_map, float* guidance_map) {
     return rto_guidance_net_forward_ex(net, stream, aux, n, H, W, weight_map, guidance_map, 0);
@@ -107,7 +110,7 @@ int rto_guidance_net_forward_ex(const rto_guidance_net* net, void* stream, const
         return fail(RTO_E_INVALID, "rto_guidance_net_forward: bad argument");
     DeviceScope scope(net->device);
     const hipError_t e = rto::launch_guidance_net(aux, net->w1, net->w2, net->b2, net->c1, net->levels, n, H, W,
-                                                  weight_map, guidance_map, (flags & RTO_NET_AUX_SQUARES_IMPLIED) != 0, nullptr, 0, nullptr, nullptr,
+                                                  weight_map, guidance_map, net_in_mode(flags), nullptr, 0, nullptr, nullptr,
                                                   (hipStream_t)stream);
     if (e != hipSuccess) return fail(RTO_E_HIP, std::string("GuidanceNet launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
@@ -167,7 +170,7 @@ int rto_guidance_net_forward_packed_culled(rto_guidance_net* net, void* stream, 
         if (const int rc = ensure_fill_tile(net, background, (hipStream_t)stream)) return rc;
     }
     const hipError_t e = rto::launch_guidance_net(aux, net->w1, net->w2, net->b2, net->c1, net->levels, n, H, W,
-                                                  (float*)net->packed, nullptr, (flags & RTO_NET_AUX_SQUARES_IMPLIED) != 0,
+                                                  (float*)net->packed, nullptr, net_in_mode(flags),
                                                   tile_marks, words_per_frame, tile_marks ? net->fill_k : nullptr, nullptr, (hipStream_t)stream);
     if (e != hipSuccess) return fail(RTO_E_HIP, std::string("GuidanceNet launch failed: ") + hipGetErrorString(e));
     net->packed_n = n;
@@ -287,7 +290,7 @@ int rto_guidance_net_forward_culled(rto_guidance_net* net, void* stream, const f
     DeviceScope scope(net->device);
     if (const int rc = ensure_fill_tile(net, background, (hipStream_t)stream)) return rc;
     const hipError_t e = rto::launch_guidance_net(aux, net->w1, net->w2, net->b2, net->c1, net->levels, n, H, W, weight_map, guidance_map,
-                                                  (flags & RTO_NET_AUX_SQUARES_IMPLIED) != 0, tile_marks, words_per_frame, nullptr,
+                                                  net_in_mode(flags), tile_marks, words_per_frame, nullptr,
                                                   net->fill_planes, (hipStream_t)stream);
     if (e != hipSuccess) return fail(RTO_E_HIP, std::string("GuidanceNet launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
@@ -330,8 +333,15 @@ int rto_denoise(rto_guidance_net* net, rto_ctx* ctx, int n, int mode, void* stre
     int words = 0, first = 0, frames = 0;
     float bg = 0.f;
     if (rto_ctx_tile_marks(ctx, &marks, &words, &first, &frames, &bg) != RTO_OK || first != sel || frames < n) marks = nullptr;
+    // frames of a lean batched launch (rto_ctx_set_tuning "lean_outputs"): their aux planes were not written, the noisy image
+    // carries r, g, b, alpha -- the network reads that
+    int net_flags = RTO_NET_AUX_SQUARES_IMPLIED;
+    if (rto_ctx_frames_are_lean(ctx, sel, n)) {
+        aux = noisy;
+        net_flags = RTO_NET_INPUT_RGBA;
+    }
     if (mode == RTO_FILTER_FACTORISED) {
-        if (const int rc = rto_guidance_net_forward_packed_culled(net, stream, aux, n, H, W, RTO_NET_AUX_SQUARES_IMPLIED, marks, words, bg)) return rc;
+        if (const int rc = rto_guidance_net_forward_packed_culled(net, stream, aux, n, H, W, net_flags, marks, words, bg)) return rc;
         return rto_filtering_packed_culled(net, stream, noisy, image, n, H, W, marks, words, bg);
     }
     const size_t plane_floats = (size_t)n * net->levels * H * W;
@@ -346,7 +356,7 @@ int rto_denoise(rto_guidance_net* net, rto_ctx* ctx, int n, int mode, void* stre
         }
     }
     float *wm = net->planes, *gm = net->planes + plane_floats;
-    if (const int rc = rto_guidance_net_forward_culled(net, stream, aux, n, H, W, wm, gm, RTO_NET_AUX_SQUARES_IMPLIED, marks, words, bg)) return rc;
+    if (const int rc = rto_guidance_net_forward_culled(net, stream, aux, n, H, W, wm, gm, net_flags, marks, words, bg)) return rc;
     return rto_filtering_culled(net, stream, wm, gm, H, W, n, noisy, image, RTO_FILTER_EXACT, marks, words, bg);
 }
 

@@ -190,13 +190,18 @@ class FusedGuidanceNet:
         self._h = h
         self._out = {}
 
-    def __call__(self, aux, stream=None, squares_implied=False, cull=None):
+    def __call__(self, aux, stream=None, squares_implied=False, cull=None, rgba=False):
         """squares_implied: aux planes 4..7 are the fp32 squares of planes 0..3 (the renderer's aux buffer): the
         kernel reads half the bytes, results are bit-identical.  cull = RenderContext.tile_marks() of the launch that
-        rendered aux: tiles whose inputs are all background get the background maps without being computed (same bits)"""
+        rendered aux: tiles whose inputs are all background get the background maps without being computed (same bits).
+        rgba: `aux` is the noisy image [n, H, W, 4] = (r, g, b, alpha) of a lean batched launch (RTO_NET_INPUT_RGBA)"""
         from ._lib import check, lib
-        n, c, H, W = aux.shape
-        assert c == 8 and aux.dtype == torch.float32 and aux.is_contiguous()
+        if rgba:
+            n, H, W, c = aux.shape
+            assert c == 4 and aux.dtype == torch.float32 and aux.is_contiguous()
+        else:
+            n, c, H, W = aux.shape
+            assert c == 8 and aux.dtype == torch.float32 and aux.is_contiguous()
         key = (n, H, W)
         if key not in self._out:
             self._out[key] = (torch.empty((n, self.levels, H, W), device=self.device),
@@ -209,7 +214,7 @@ class FusedGuidanceNet:
             if frames < n:
                 raise ValueError("GuidanceNet: %d frames but tile marks of %d" % (n, frames))
         check(lib().rto_guidance_net_forward_culled(self._h, V._stream_ptr(s), aux.data_ptr(), n, H, W, wm.data_ptr(), gm.data_ptr(),
-                                                    1 if squares_implied else 0, marks, int(words), float(bg)))
+                                                    2 if rgba else (1 if squares_implied else 0), marks, int(words), float(bg)))
         return wm, gm
 
     def denoise(self, ctx, n=1, mode=V.FILTER_FAST, stream=None):
@@ -239,21 +244,26 @@ class FusedGuidanceNet:
         from ._lib import check, lib
         check(lib().rto_guidance_net_reserve(self._h, int(n), int(H), int(W)))
 
-    def forward_packed(self, aux, stream=None, squares_implied=False, cull=None):
+    def forward_packed(self, aux, stream=None, squares_implied=False, cull=None, rgba=False):
         """the network, its 8 fp16 output channels kept packed in the handle's scratch (rto_guidance_net_forward_packed).
         cull = RenderContext.tile_marks() of the launch that rendered aux (frames in order): network tiles whose inputs are
-        all background get the network's background output without being computed (same bits)"""
+        all background get the network's background output without being computed (same bits).
+        rgba: `aux` is the noisy image [n, H, W, 4] = (r, g, b, alpha) of a lean batched launch (RTO_NET_INPUT_RGBA)"""
         from ._lib import check, lib
-        n, c, H, W = aux.shape
-        assert c == 8 and aux.dtype == torch.float32 and aux.is_contiguous()
+        if rgba:
+            n, H, W, c = aux.shape
+            assert c == 4 and aux.dtype == torch.float32 and aux.is_contiguous()
+        else:
+            n, c, H, W = aux.shape
+            assert c == 8 and aux.dtype == torch.float32 and aux.is_contiguous()
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
         marks, words, bg = (None, 0, 0.0)
         if cull is not None:
             marks, words, _slot0, frames, bg = cull
             if frames < n:
                 raise ValueError("forward_packed: %d frames but tile marks of %d" % (n, frames))
-        check(lib().rto_guidance_net_forward_packed_culled(self._h, V._stream_ptr(s), aux.data_ptr(), n, H, W, 1 if squares_implied else 0,
-                                                           marks, int(words), float(bg)))
+        check(lib().rto_guidance_net_forward_packed_culled(self._h, V._stream_ptr(s), aux.data_ptr(), n, H, W,
+                                                           2 if rgba else (1 if squares_implied else 0), marks, int(words), float(bg)))
         self._packed_shape = (n, H, W)
 
     def filter_packed(self, img_in, img_out, stream=None, shape=None, cull=None):

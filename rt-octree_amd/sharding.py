@@ -39,8 +39,16 @@ def gather_frames(local_frames, n_frames, rank, world, dist=None, device=None):
         import torch.distributed as dist
     mine = shard_indices(n_frames, rank, world)
     max_local = (n_frames + world - 1) // world
-    any_frame = next(iter(local_frames.values()))
-    H, W, C = any_frame.shape
+    if n_frames < world:
+        # fewer frames than ranks (--max_imgs 5 over 8 GPUs): some ranks own no frame and so know no frame shape -- every rank
+        # learns it from the ones that do (the condition is the same on all ranks, so they all take this extra collective)
+        shp = torch.tensor(list(next(iter(local_frames.values())).shape) if local_frames else [0, 0, 0], dtype=torch.int64)
+        if device is not None:
+            shp = shp.to(device)
+        dist.all_reduce(shp, op=dist.ReduceOp.MAX)
+        H, W, C = (int(v) for v in shp.cpu())
+    else:
+        H, W, C = next(iter(local_frames.values())).shape
     buf = torch.zeros((max_local, H, W, C), dtype=torch.uint8)
     for k, i in enumerate(mine):
         buf[k] = torch.from_numpy(np.ascontiguousarray(local_frames[i]))

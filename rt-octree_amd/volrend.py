@@ -329,6 +329,14 @@ class RenderContext:
         results never change"""
         check(lib().rto_ctx_set_tuning(self._h, key.encode("ascii"), int(value)))
 
+    def set_lean_outputs(self, on=True):
+        """rto_ctx_set_lean_outputs: batched launches with denoise on store the noisy image as (r, g, b, alpha) and no aux
+        planes -- 16 instead of 48 bytes per pixel; consumers: FusedGuidanceNet(..., rgba=True) on noisy_ptr, denoise()"""
+        check(lib().rto_ctx_set_lean_outputs(self._h, int(bool(on))))
+
+    def frames_are_lean(self, first=0, n=1):
+        return bool(lib().rto_ctx_frames_are_lean(self._h, int(first), int(n)))
+
     def kernel_timing(self, on=True):
         """HIP-event timing of the traversal / shading kernels of launch_renderer_batch"""
         check(lib().rto_ctx_kernel_timing(self._h, int(bool(on))))

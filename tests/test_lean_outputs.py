@@ -1,0 +1,115 @@
+"""Lean outputs of the batched render -> denoise route (round 5, VERDICT r4 task 3; rto_ctx_set_lean_outputs).
+
+The reference's kernel stores 48 bytes per pixel (8 aux planes + an RGBA32F image, volrend.cu:187-212) of which its denoise
+stage reads 16: aux planes 0..3 -- planes 4..7 are their squares, the image's rgb is planes 0..2 again.  A lean batched launch
+stores exactly those four values, interleaved, as the noisy image's (r, g, b, alpha) and nothing else.  Checked here:
+the four values are the full route's aux planes 0..3 bit for bit, the aux buffer is left alone, the denoised images of both
+filter routes equal the full route's bit for bit (one-call rto_denoise and the two-call form with RTO_NET_INPUT_RGBA), a
+launch with denoise off or a single-frame launch keeps the full outputs."""
+import numpy as np
+import pytest
+
+import rt_octree_amd as R
+from helpers import assert_bits_equal
+from rt_octree_amd import denoiser, synth
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def scene():
+    t = synth.make_tree(depth_limit=7, basis_dim=9, shell=2.5)
+    dt = R.N3Tree.from_arrays(t.child, t.data, t.scale, t.offset, t.data_format)
+    torch.manual_seed(3)
+    net = denoiser.FusedGuidanceNet(denoiser.GuidanceNetCompact.from_full(denoiser.GuidanceNet(8, 32, 5, 2, 4)).eval())
+    yield dt, net
+    dt.free()
+
+
+def cams_for(W, H, n):
+    fx = synth.blender_focal(W)
+    out = []
+    for p in synth.orbit_poses(n):
+        c = R.Camera(W, H, fx, fx)
+        c.set_c2w(p)
+        out.append(c)
+    return out
+
+
+def views(ctx, n):
+    aux, noisy, image = (torch.as_tensor(v, device="cuda:0")[:n] for v in ctx.batch_views())
+    return aux, noisy, image
+
+
+@pytest.mark.parametrize("W,H,bg", [(400, 304, 1.0), (333, 257, 0.25)])
+def test_lean_launch_stores_planes_0_to_3_and_denoises_to_the_same_images(scene, W, H, bg):
+    dt, net = scene
+    n = 4
+    cams = cams_for(W, H, n)
+    opt = R.RenderOptions(spp=6, denoise=True, background_brightness=bg)
+    jumps = [100 + i for i in range(n)]
+    full = R.RenderContext(W, H, frames=n)
+    full.rng_seed()
+    R.launch_renderer_batch(dt, cams, opt, full, rng_jumps=jumps)
+    assert not full.frames_are_lean(0, n)
+    aux_f, noisy_f, image_f = views(full, n)
+    want = {}
+    for mode in (R.FILTER_FAST, R.FILTER_EXACT):
+        full.select_frame(0)
+        net.denoise(full, n=n, mode=mode)
+        torch.cuda.synchronize()
+        want[mode] = image_f.clone()
+    aux_full = aux_f.clone()
+
+    lean = R.RenderContext(W, H, frames=n)
+    aux_l, noisy_l, image_l = views(lean, n)
+    aux_l.fill_(-3.0)  # (a lean launch must not touch the aux buffer)
+    lean.set_lean_outputs(True)
+    lean.rng_seed()
+    R.launch_renderer_batch(dt, cams, opt, lean, rng_jumps=jumps)
+    torch.cuda.synchronize()
+    assert lean.frames_are_lean(0, n) and lean.frames_are_lean(1, 2) and not lean.frames_are_lean(0, n + 1)
+    assert bool(torch.all(aux_l == -3.0)), "a lean launch wrote aux planes"
+    got = noisy_l.permute(0, 3, 1, 2).contiguous()  # [n][4][H][W] = (r, g, b, alpha) planes
+    assert_bits_equal(got.cpu().numpy(), aux_full[:, :4].cpu().numpy(), "lean (r, g, b, alpha) vs aux planes 0..3")
+    assert_bits_equal(noisy_l[..., :3].cpu().numpy(), noisy_f[..., :3].cpu().numpy(), "lean rgb vs the full noisy image")
+    for mode in (R.FILTER_FAST, R.FILTER_EXACT):  # the one-call form finds the route by itself
+        image_l.fill_(-7.0)
+        lean.select_frame(0)
+        net.denoise(lean, n=n, mode=mode)
+        torch.cuda.synchronize()
+        assert_bits_equal(image_l.cpu().numpy(), want[mode].cpu().numpy(), "rto_denoise on lean frames, mode %d" % mode)
+    # the two-call forms with RTO_NET_INPUT_RGBA, culled and not
+    marks = lean.tile_marks()
+    assert marks is not None
+    lean.select_frame(0)
+    for cull in (None, marks):
+        image_l.fill_(-7.0)
+        net.forward_packed(noisy_l, rgba=True, cull=cull)
+        net.filter_packed(lean.noisy_ptr, lean.image_ptr, shape=(n, H, W), cull=cull)
+        torch.cuda.synchronize()
+        assert_bits_equal(image_l.cpu().numpy(), want[R.FILTER_FAST].cpu().numpy(), "packed route on the lean image")
+        wm, gm = net(noisy_l, rgba=True, cull=cull)
+        net.filter_planes(wm, gm, lean.noisy_ptr, lean.image_ptr, mode=R.FILTER_EXACT, cull=cull)
+        torch.cuda.synchronize()
+        assert_bits_equal(image_l.cpu().numpy(), want[R.FILTER_EXACT].cpu().numpy(), "fp32-plane route on the lean image")
+    # denoise off: the image is the final one (volrend.cu:206) -- full outputs whatever the switch says
+    lean.rng_seed()
+    R.launch_renderer_batch(dt, cams, R.RenderOptions(spp=6, denoise=False, background_brightness=bg), lean, rng_jumps=jumps)
+    torch.cuda.synchronize()
+    assert not lean.frames_are_lean(0, n)
+    assert_bits_equal(aux_l.cpu().numpy(), aux_full.cpu().numpy(), "denoise off: full aux planes")
+    assert bool(torch.all(image_l[..., 3] == 1.0))
+    # a single-frame launch into a slot a lean launch wrote: full outputs for that slot, the rest stays lean
+    lean.rng_seed()
+    R.launch_renderer_batch(dt, cams, opt, lean, rng_jumps=jumps)
+    lean.select_frame(1)
+    lean.rng_seed()
+    lean.rng_advance(jumps[1] << 32)
+    R.launch_renderer(dt, cams[1], opt, lean)
+    torch.cuda.synchronize()
+    assert not lean.frames_are_lean(0, n)
+    assert_bits_equal(aux_l[1].cpu().numpy(), aux_full[1].cpu().numpy(), "single frame after a lean launch: full aux planes")
+    assert bool(torch.all(noisy_l[1, ..., 3] == 1.0))
+    lean.select_frame(0)

@@ -85,6 +85,41 @@ def test_two_ranks_gather_equals_single_process():
     assert timing["frames"] == 7 and abs(timing["render_ms"] - 1.0) < 1e-12 and abs(timing["fps"] - 1000.0 / 6.0) < 1e-9
 
 
+def _empty_rank_worker(rank, world, port, q, n_frames):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "1"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(HERE))
+    from rt_octree_amd import sharding
+    # (synthetic frames: what is under test is the collective, and 8 processes must stay light on an 8-core box)
+    local = {i: np.full((6, 5, 4), 10 * i + 1, np.uint8) for i in sharding.shard_indices(n_frames, rank, world)}
+    frames = sharding.gather_frames(local, n_frames, rank, world, dist=dist)
+    if rank == 0:
+        q.put(np.stack(frames))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_with_ranks_that_own_no_frame():
+    """`--max_imgs 5` over 8 ranks -- ranks 5..7 own no frame (and know no frame shape); the gather must neither
+    raise there nor hang the others"""
+    world, n_frames = 8, 5
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_empty_rank_worker, args=(r, world, port, q, n_frames)) for r in range(world)]
+    for p in procs:
+        p.start()
+    frames = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert frames.shape == (n_frames, 6, 5, 4)
+    for i in range(n_frames):
+        assert np.all(frames[i] == 10 * i + 1)
+
+
 # ------------------------------------------------------------------ bench.py's frame schedule
 def _bench():
     sys.path.insert(0, os.path.dirname(HERE))
@@ -131,7 +166,7 @@ def test_bench_plan_two_ranks_over_gloo(tmp_path):
     import subprocess
     root = os.path.dirname(HERE)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--batch", "32",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--batch", "32", "--groups-per-step", "1",
            "--warmup", "0", "--scenes", "2", "--plan-only"]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)

@@ -55,3 +55,28 @@ def assert_bits_equal(a, b, what=""):
     bad = np.flatnonzero(av.reshape(-1) != bv.reshape(-1))
     assert bad.size == 0, "%s: %d of %d words differ; first at %d: %r vs %r" % (
         what, bad.size, av.size, bad[0], a.reshape(-1)[bad[0]], b.reshape(-1)[bad[0]])
+
+
+def oracle_threads():
+    """threads for whole-frame oracle renders: the cores this process may really use (affinity mask capped by the cgroup's CPU
+    quota -- the GPU boxes show 256 CPUs behind a quota of 16, and 256 throttled OpenMP threads crawl)"""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def oracle_whole_frame(ht, cam, fx, spp, jump, fy=None):
+    """orc.render_frame for one librto camera at RNG jump `jump` -> (aux [8,H,W], rgba [H,W,4])"""
+    ocam = orc.camera(cam.width, cam.height, fx, fx if fy is None else fy, cam.transform.reshape(-1))
+    aux, rgba, _ = orc.render_frame(ht, ocam, orc.default_options(spp=spp), orc.rng(frame=jump), threads=oracle_threads(), want_stats=False)
+    return aux, rgba

@@ -1,7 +1,8 @@
 """BASELINE.json configs[3] at size: 1920x1080, SPP 6, SH25 tree, GuidanceNet + filter, batched -- the shape of
-the TanksAndTemple Truck run (T&T intrinsics fx = fy = 1160, a close orbit).  Full frames cannot go through the
-CPU oracle in test time, so: size-independent properties of every pixel, bit-exact oracle spot pixels, batched ==
-frame loop, the denoised image against the oracle filter on the same maps."""
+the TanksAndTemple Truck run (T&T intrinsics fx = fy = 1160, a close orbit; a synthetic SH25 stand-in: no T&T data exists
+offline).  Two COMPLETE 1080p frames against the oracle bit for bit (round 5: ~0.5 s each on the box's 16 cores),
+size-independent properties of every pixel, oracle spot pixels on the third, batched == frame loop, the denoised image
+against the oracle filter on the same maps."""
 import ctypes as C
 
 import numpy as np
@@ -9,7 +10,7 @@ import pytest
 
 import orc
 import rt_octree_amd as R
-from helpers import assert_bits_equal
+from helpers import assert_bits_equal, oracle_whole_frame
 from rt_octree_amd import denoiser, synth
 
 pytestmark = pytest.mark.gpu
@@ -53,6 +54,12 @@ def test_c4_1080p_sh25_denoised_batch():
             assert orc.lib().orc_render_pixel(C.byref(ht.c), C.byref(ocam), C.byref(oopt), C.byref(base), int(idx), a8, rgba, None) == 0
             y, x = divmod(int(idx), W)
             assert_bits_equal(aux[:, y, x], np.array(a8[:], np.float32), "frame %d pixel %d" % (f, idx))
+    # ---- two complete frames against the oracle: all 8 aux planes of all 2 073 600 pixels, and the RGBA8 bytes
+    for f in (0, 2):
+        aux_o, rgba_o = oracle_whole_frame(ht, cams[f], 1160.0, spp, jumps[f])
+        ctx.select_frame(f)
+        assert_bits_equal(ctx.download_aux(), aux_o, "whole 1080p frame %d: aux planes" % f)
+        assert np.array_equal(ctx.download_rgba8(noisy=True), orc.rgba8(rgba_o)), "whole 1080p frame %d: RGBA8" % f
     # ---- batched == the reference's frame loop (one launch per frame, rng.advance in between)
     one = R.RenderContext(W, H)
     one.rng_seed()

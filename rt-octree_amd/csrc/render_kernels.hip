@@ -40,6 +40,15 @@ namespace rto {
 
 // ------------------------------------------------------------------ shared pieces
 
+// A pointer loaded from device memory (the frame table's aux / image / hits) is generic to the compiler, which then issues
+// flat_load / flat_store for it.  It is device memory: typed as a global-address-space pointer the accesses become
+// global_load / global_store.
+#define RTO_GLOBAL __attribute__((address_space(1)))
+template <class T>
+RTO_DEV RTO_GLOBAL T* as_global(T* p) {
+    return (RTO_GLOBAL T*)p;
+}
+
 // cuda/common.cuh:16-27
 RTO_DEV float norm3(const float* d) { return sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]); }
 RTO_DEV void normalize3(float* d) {
@@ -1138,7 +1147,7 @@ __global__ void __launch_bounds__(256) sample_kernel(const FrameBatch fb, const 
     // a pixel of a culled tile: an empty hit list, no draws (its RNG stream is its own: nobody observes the skipped ones)
     if (fb.tile_mask && !tile_marked(fb, (int)blockIdx.y, tile)) {  // (shade_kernel reads the marks, not a list)
 #ifdef RTO_SHADE_NO_MARKS
-        fd.hits[hit_index<SPP>(idx, 0u, SIZE)] = 0u;
+        as_global(fd.hits)[hit_index<SPP>(idx, 0u, SIZE)] = 0u;
 #endif
         return;
     }
@@ -1160,10 +1169,11 @@ __global__ void __launch_bounds__(256) sample_kernel(const FrameBatch fb, const 
         }
         dst[n] = tv;
     }
-#pragma unroll
     // (-log(1 - 0) = -0.0: the thresholds are only ever compared, so +0.0 serves; its clear top bit is what the
     //  shading kernel ends a hit list on)
-    for (int i = 0; i < SPP; ++i) fd.hits[hit_index<SPP>(idx, (uint32_t)i, SIZE)] = __float_as_uint(dst[i]) & ~kHitValid;
+    RTO_GLOBAL uint32_t* const fhits = as_global(fd.hits);
+#pragma unroll
+    for (int i = 0; i < SPP; ++i) fhits[hit_index<SPP>(idx, (uint32_t)i, SIZE)] = __float_as_uint(dst[i]) & ~kHitValid;
 }
 
 // Staged hit lists (round 4, VERDICT r3 task 5; -DRTO_HITS_DIRECT restores the store per hit): a ray's hit entries wait in LDS -- in the rows of its threshold column that
@@ -1193,6 +1203,22 @@ RTO_DEV void flush_hits(RayState& rs, const TreeDev& tree, uint32_t* __restrict_
     for (int i = 1; i < SPP; ++i)
         if ((uint32_t)i < rs.nh) tp[(uint32_t)(i - 1) * hstride] = e[i];
     rs.nh = 0;
+}
+
+// thresholds I .. N-1 of a pixel (tp: its entry 1 in the hand-off buffer) into rows I .. N-1 of the wave's columns, LDS-direct
+template <int I, int N>
+RTO_DEV void dma_thresholds(const __attribute__((address_space(1))) uint32_t* tp, uint32_t hstride,
+                            __attribute__((address_space(3))) uint32_t* rows) {
+    if constexpr (I < N) {
+        // (a pixel's entries 1.. are consecutive: the immediate offset addresses them.  The hardware adds that offset to the
+        //  LDS address as well as to the memory address -- tools/probes/lds_dma_probe.hip, profiles/r5_c_lds_dma_probe.txt --
+        //  so the row base is moved back by as much)
+        if (kHitsLayout != 0)
+            __builtin_amdgcn_global_load_lds(tp, rows + I * 256 - (I - 1), 4, 4 * (I - 1), 0);
+        else
+            __builtin_amdgcn_global_load_lds(tp + (uint32_t)(I - 1) * hstride, rows + I * 256, 4, 0, 0);
+        dma_thresholds<I + 1, N>(tp, hstride, rows);
+    }
 }
 
 // REFILL = idle lanes that trigger a retire + refill round
@@ -1350,22 +1376,32 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     if (rank < take && x < W && y < H) {
                         RTO_DBG_AT(6)
                         const float* fd = s_cams + frame * kCamFloats;
+                        // (round 5: what the set-up derives from launch constants -- 0.5 W, bbox +- 1e-6 in double, the NDC factors --
+                        //  is derived HERE: left alone the compiler hoists those values out of the kernel's loops into ~12 VGPRs and
+                        //  spills them; the empty asm statements make the inputs opaque.  This was the kernel's whole private segment.)
+                        int Wl = W, Hl = H;
+                        OptDev o2 = opt;
+                        TreeDev t2 = tree;
+                        asm volatile("" : "+s"(Wl), "+s"(Hl));
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) asm volatile("" : "+s"(o2.render_bbox[i]));
+                        asm volatile("" : "+s"(t2.ndc_width), "+s"(t2.ndc_height), "+s"(t2.ndc_focal));
                         CamDev cam;
-                        cam.width = W;
-                        cam.height = H;
+                        cam.width = Wl;
+                        cam.height = Hl;
                         cam.fx = fd[0];
                         cam.fy = fd[1];
 #pragma unroll
                         for (int i = 0; i < 12; ++i) cam.transform[i] = fd[2 + i];
                         float vdir[3];
-                        ray_setup(x, y, cam, tree, rs.dir, vdir, rs.cen);
+                        ray_setup(x, y, cam, t2, rs.dir, vdir, rs.cen);
                         float tmin;
                         {   // where this pixel's next hit entry goes (hoff) and the one after it (hnext): hit_index
                             const uint32_t fbase = (uint32_t)frame * (uint32_t)SPP * SIZE, pixel = (uint32_t)(y * W + x);
                             rs.hoff = fbase + hit_index<SPP>(pixel, 0u, SIZE);
                             rs.hnext = fbase + hit_index<SPP>(pixel, SPP > 1 ? 1u : 0u, SIZE);
                         }
-                        if (ray_enter(tree, opt, rs.dir, rs.cen, 1e9f, rs.invdir, rs.delta_scale, tmin, rs.tmax)) {
+                        if (ray_enter(t2, o2, rs.dir, rs.cen, 1e9f, rs.invdir, rs.delta_scale, tmin, rs.tmax)) {
                             // sorted thresholds of this pixel (sample_kernel left them in the hand-off
                             // buffer, where the ray's hit list will overwrite them)
                             rs.cur = __uint_as_float(hits[rs.hoff]);
@@ -1600,23 +1636,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
 // Record (dwords): dir[3] (scaled + renormalised, rt_core.cuh:206-208), invdir[3], delta_scale, tmin, tmax, pixel
 // index (y * W + x); with the NDC warp (LLFF) also cen[3] -- without it the origin is the same for every ray of a
 // frame and travels in SGPRs.
-// thresholds I .. N-1 of a pixel (tp: its entry 1 in the hand-off buffer) into rows I .. N-1 of the wave's columns, LDS-direct
-template <int I, int N>
-RTO_DEV void dma_thresholds(const __attribute__((address_space(1))) uint32_t* tp, uint32_t hstride,
-                            __attribute__((address_space(3))) uint32_t* rows) {
-    if constexpr (I < N) {
-        // (a pixel's entries 1.. are consecutive: the immediate offset addresses them.  The hardware adds that offset to the
-        //  LDS address as well as to the memory address -- tools/probes/lds_dma_probe.hip, profiles/r5_c_lds_dma_probe.txt --
-        //  so the row base is moved back by as much)
-        if (kHitsLayout != 0)
-            __builtin_amdgcn_global_load_lds(tp, rows + I * 256 - (I - 1), 4, 4 * (I - 1), 0);
-        else
-            __builtin_amdgcn_global_load_lds(tp + (uint32_t)(I - 1) * hstride, rows + I * 256, 4, 0, 0);
-        dma_thresholds<I + 1, N>(tp, hstride, rows);
-    }
-}
-
-#define RTO_RES_LDS_DMA_WAIT 1
+#define RTO_RES_LDS_DMA_WAIT 1  // (rto_march_leaf.inc: state the dependence of the column reads on the LDS-direct loads)
 template <int SPP, int KREF, int WPS, bool DIRECT>
 __global__ void __launch_bounds__(256, WPS) render_persist_res(const TreeDev tree, const OptDev opt, const FrameBatch fb,
                                                            unsigned long long* __restrict__ queue,
@@ -1683,10 +1703,6 @@ __global__ void __launch_bounds__(256, WPS) render_persist_res(const TreeDev tre
     // a ray's parked hit entries leave for the hand-off buffer: entry 0 into the dense plane, entries 1.. as one run (they name
     // entries of the two-level image: the shading kernel translates, FrameBatch::res_flags & kResHitsWide)
     auto flush = [&]() {
-        if (fb.res_flags & 8) {  // TIMING EXPERIMENT ONLY (wrong pixels): no hit list leaves the kernel
-            rs.nh = 0;
-            return;
-        }
         const uint32_t pid = __float_as_uint(s_dst[kPidRow * 256]);  // (the launcher keeps W * H < 2^25)
         const uint32_t fbase = (pid >> 25) * (uint32_t)SPP * SIZE, pixel = pid & 0x1ffffffu;
         hits[fbase + hit_index<SPP>(pixel, 0u, SIZE)] = __float_as_uint(s_dst[0]);
@@ -1835,10 +1851,9 @@ __global__ void __launch_bounds__(256, WPS) render_persist_res(const TreeDev tre
                     }
                     // sorted thresholds of this pixel (sample_kernel left them in the hand-off buffer, where the ray's hit
                     // list will overwrite them)
-                    rs.cur = (fb.res_flags & 16) ? 1.0f : __uint_as_float(hits[hoff]);  // (16: TIMING EXPERIMENT ONLY, no threshold loads)
+                    rs.cur = __uint_as_float(hits[hoff]);
                     const uint32_t* tp = hits + hnext;
-                    if (fb.res_flags & 16) {
-                    } else if (lds_dma) {
+                    if (lds_dma) {
                         // thresholds 1.. straight from memory into this lane's column (global_load_lds_dword: lane L of the wave
                         // writes dword L of the row M0 points at -- exactly its column), no VGPR round trip and NO WAIT here:
                         // the loads are in flight while the wave marches on; vmcnt is in order, so the first node word that
@@ -2043,6 +2058,7 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
     const int64_t wave_px0 = ((int64_t)pblock * 4 + wv) * (64 * P);
     if (wave_px0 >= SIZE) return;  // wave-uniform
     const FrameDesc& fd = fb.f[frame];  // block-uniform index: scalar loads
+    const RTO_GLOBAL uint32_t* const fhits = as_global((const uint32_t*)fd.hits);
 
     // ---- each lane: the hit lists of its P pixels (pixel p*64 + lane of the wave: coalesced)
     uint32_t h[P][SPP];
@@ -2080,18 +2096,18 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
                 // (fetching the run only for a pixel whose first entry is valid saves 20 bytes per empty pixel and costs a
                 //  dependent round trip per wave: 2.03 instead of 1.95 ms per 100 frames)
                 uint32_t raw[SPP];
-                raw[0] = fd.hits[idx];
+                raw[0] = fhits[idx];
 #pragma unroll
                 for (int i = 1; i < SPP; ++i) raw[i] = 0u;
                 if (raw[0] & kHitValid) {
-                    const uint32_t* hp = fd.hits + SIZE + idx * (SPP - 1);
+                    const RTO_GLOBAL uint32_t* hp = fhits + SIZE + idx * (SPP - 1);
 #pragma unroll
                     for (int i = 1; i < SPP; ++i) raw[i] = hp[i - 1];
                 }
 #else
                 uint32_t raw[SPP];
-                raw[0] = fd.hits[idx];
-                const uint32_t* hp = fd.hits + SIZE + idx * (SPP - 1);
+                raw[0] = fhits[idx];
+                const RTO_GLOBAL uint32_t* hp = fhits + SIZE + idx * (SPP - 1);
 #pragma unroll
                 for (int i = 1; i < SPP; ++i) raw[i] = hp[i - 1];
 #endif
@@ -2102,7 +2118,7 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
                     n[p] += open ? 1u : 0u;
                 }
             } else if (kHitsLayout == 1) {  // the whole list is one contiguous run: fetch it, then find its end
-                const uint32_t* hp = fd.hits + idx * SPP;
+                const RTO_GLOBAL uint32_t* hp = fhits + idx * SPP;
                 uint32_t raw[SPP];
 #pragma unroll
                 for (int i = 0; i < SPP; ++i) raw[i] = hp[i];
@@ -2113,7 +2129,7 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
                     n[p] += open ? 1u : 0u;
                 }
             } else {
-                const uint32_t* hp = fd.hits + idx;
+                const RTO_GLOBAL uint32_t* hp = fhits + idx;
 #pragma unroll
                 for (int i = 0; i < SPP; ++i) {
                     h[p][i] = 0u;
@@ -2211,10 +2227,9 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
         __builtin_amdgcn_wave_barrier();
     }
 
-    FrameOut fo = {};
-    fo.aux = fd.aux;
-    fo.image = fd.image;
-    fo.stats = nullptr;
+    RTO_GLOBAL float* const g_aux = as_global(fd.aux);
+    typedef float f4_t __attribute__((ext_vector_type(4)));  // (HIP's float4 has no assignment across address spaces)
+    RTO_GLOBAL f4_t* const g_image = (RTO_GLOBAL f4_t*)as_global(fd.image);
     constexpr float INV_SPP = 1.0f / SPP;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -2226,11 +2241,24 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
             out[p][2] *= INV_SPP;
             out[p][3] *= INV_SPP;
         }
-        if (fb.lean) {  // (block-uniform) volrend.cu:174-178 + the four values its consumers read, in one 16-byte store
-            const float remain = opt.background_brightness * (1.f - out[p][3]);
-            reinterpret_cast<float4*>(fo.image)[idx] = make_float4(out[p][0] + remain, out[p][1] + remain, out[p][2] + remain, out[p][3]);
-        } else
-            write_pixel(fo, SIZE, (int)idx, opt.background_brightness, out[p]);
+        // volrend.cu:174-212 (write_pixel, through global-address-space pointers): background composite, then the 8 aux planes
+        // and the RGBA32F image with alpha = 1 -- or, lean (block-uniform), the four values their consumers read in one store
+        const float remain = opt.background_brightness * (1.f - out[p][3]);
+        const float r = out[p][0] + remain, g = out[p][1] + remain, b = out[p][2] + remain, al = out[p][3];
+        if (fb.lean) {
+            g_image[idx] = f4_t{r, g, b, al};
+        } else {
+            RTO_GLOBAL float* a = g_aux + idx;
+            a[0] = r;
+            a[SIZE] = g;
+            a[2 * SIZE] = b;
+            a[3 * SIZE] = al;
+            a[4 * SIZE] = r * r;
+            a[5 * SIZE] = g * g;
+            a[6 * SIZE] = b * b;
+            a[7 * SIZE] = al * al;
+            g_image[idx] = f4_t{r, g, b, 1.0f};
+        }
     }
 }
 
@@ -2497,11 +2525,13 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
     refill %= 1000;
     const bool wide = tree.widew != nullptr;
     if constexpr (SPP == 6) {  // tuning instantiations only for the benchmark configuration (and its usual two-level image)
-#define RTO_F(R, O) return launch_batch_impl<SPP, R, O, true>(tree, opt, fb, 0, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream)
+#define RTO_F(R, O) return launch_batch_impl<SPP, R, O, true>(tree, opt, fb, res_flags, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream)
         if (wide) switch (refill) {  // A/B set kept for tools/ab_tuning.py: 100 * waves/SIMD + refill threshold
             case 808: RTO_F(8, 8);
             case 816: RTO_F(16, 8);
+            case 824: RTO_F(24, 8);
             case 832: RTO_F(32, 8);
+            case 840: RTO_F(40, 8);
             case 724: RTO_F(24, 7);
             case 732: RTO_F(32, 7);
             case 740: RTO_F(40, 7);
@@ -2514,7 +2544,8 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
 #undef RTO_F
 #define RTO_R(K, O) return launch_batch_impl<SPP, K, O, true, 1>(tree, opt, fb, res_flags, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream)
 #define RTO_D(K, O) return launch_batch_impl<SPP, K, O, true, 2>(tree, opt, fb, res_flags, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream)
-        if (wide) switch (refill) {  // the reservoir kernel (round 5): 900 + idle-lane threshold at 8 waves per SIMD, 500 + at 7; 400 + / 300 + = direct hit stores
+        // (the reservoir kernel packs frame and pixel of a ray into one word: frames below 2^25 pixels)
+        if (wide && (int64_t)fb.width * fb.height < (int64_t(1) << 25)) switch (refill) {  // the reservoir kernel (round 5): 900 + idle-lane threshold at 8 waves per SIMD, 500 + at 7; 400 + / 300 + = direct hit stores
             case 908: RTO_R(8, 8);
             case 912: RTO_R(12, 8);
             case 916: RTO_R(16, 8);
@@ -2542,15 +2573,11 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
     // which change the register budget, not the number of resident waves).
     // The two-level traversal image when the tree has one (always, unless it would not fit its index space or the device's
     // memory: rto_abi.cpp build_wide_image), else the one-level image: the same pixels either way.
-    // Round 5 default: the reservoir kernel (render_persist_res) -- refill once RTO_RES_DEFAULT lanes idle, 7 waves per SIMD (72
-    // VGPRs: spill-free; at 64 the allocator spills ray state inside the march loop), thresholds prefetched at set-up and
-    // loaded LDS-direct at refill.  refill = 832 / 732: the round-4 kernel (A/B).  Frames of 2^25 pixels or more keep the
-    // round-4 kernel (the reservoir kernel packs frame and pixel into one word).
-#ifndef RTO_RES_DEFAULT
-#define RTO_RES_DEFAULT 24
-#endif
-    if (wide && RTO_RES_DEFAULT > 0 && refill == 0 && (int64_t)fb.width * fb.height < (int64_t(1) << 25))
-        return launch_batch_impl<SPP, RTO_RES_DEFAULT ? RTO_RES_DEFAULT : 24, 7, true, 1>(tree, opt, fb, kResPrefetch | kResLdsDma, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream);
+    // Round 5: the reservoir kernel (render_persist_res; tuning refill = 500 + K / 900 + K, flags x 100000) was built to light the
+    // lanes the round-4 kernel leaves dark -- and is NOT the default: same-box A/B, 100 frames of C2: 4.27-4.32 ms at its best
+    // setting (K = 24, 7 waves per SIMD, prefetch + LDS-direct thresholds) against 4.11-4.20 for this kernel, which round 5 left
+    // spill-free at 59 VGPRs, without the hit-entry translation in its flush (TreeDev::rec_by_entry) and without the flat loads
+    // a laundered LDS pointer had put into its hit branch (profiles/r5_*_ab*.txt; DESIGN.md section 4 "Round 5").
     if (wide)
         return launch_batch_impl<SPP, 32, RTO_WPS_DEFAULT, true>(tree, opt, fb, 0, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream);
     return launch_batch_impl<SPP, 32, RTO_WPS_DEFAULT, false>(tree, opt, fb, 0, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream);

@@ -127,7 +127,7 @@ TorchDenoiser::~TorchDenoiser() {
 bool TorchDenoiser::fused() const { return impl_->fused != nullptr; }
 rto_guidance_net* TorchDenoiser::fused_handle() const { return impl_->fused; }
 
-void TorchDenoiser::forward(float* aux, int n, int H, int W, const float** weight, const float** guidance, int* levels) {
+void TorchDenoiser::forward(float* aux, int n, int H, int W, const float** weight, const float** guidance, int* levels, bool input_rgba) {
     torch::NoGradGuard no_grad;
     const auto options = torch::TensorOptions().device(torch::kCUDA, impl_->device).dtype(torch::kFloat32);
     if (impl_->fused) {  // same maps from one HIP kernel on the default stream (the CLI's stream)
@@ -138,13 +138,14 @@ void TorchDenoiser::forward(float* aux, int n, int H, int W, const float** weigh
         }
         // aux is the renderer's buffer: planes 4..7 are the squares of planes 0..3
         if (rto_guidance_net_forward_ex(impl_->fused, nullptr, aux, n, H, W, impl_->weight.data_ptr<float>(),
-                                        impl_->guidance.data_ptr<float>(), RTO_NET_AUX_SQUARES_IMPLIED) != RTO_OK)
+                                        impl_->guidance.data_ptr<float>(), input_rgba ? RTO_NET_INPUT_RGBA : RTO_NET_AUX_SQUARES_IMPLIED) != RTO_OK)
             throw std::runtime_error(std::string("fused GuidanceNet failed: ") + rto_last_error());
         *weight = impl_->weight.data_ptr<float>();
         *guidance = impl_->guidance.data_ptr<float>();
         *levels = L;
         return;
     }
+    if (input_rgba) throw std::runtime_error("the TorchScript module reads the 8-plane aux buffer: lean outputs need the fused network");
     torch::Tensor aux_t = torch::from_blob(aux, {n, 8, H, W}, options);  // denoiser.cpp:40-43 (n = 1 there)
     auto maps = impl_->module.forward({aux_t}).toTuple()->elements();
     impl_->weight = maps[0].toTensor().contiguous();    // [n,L,H,W]

@@ -26,7 +26,9 @@ public:
 
     // aux: device pointer to [n,8,H,W] fp32 (zero-copy from_blob).  On return *weight / *guidance point
     // at contiguous device tensors [n,L,H,W] that stay alive until the next call.
-    void forward(float* aux, int n, int H, int W, const float** weight, const float** guidance, int* levels);
+    // input_rgba (fused network only): `aux` is the noisy image [n][H][W][4] = (r, g, b, alpha) a lean batched launch leaves
+    // (rto_ctx_set_lean_outputs, RTO_NET_INPUT_RGBA) instead of the 8-plane aux buffer
+    void forward(float* aux, int n, int H, int W, const float** weight, const float** guidance, int* levels, bool input_rgba = false);
 
 private:
     struct Impl;

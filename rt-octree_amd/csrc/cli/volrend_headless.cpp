@@ -430,11 +430,13 @@ int main(int argc, char** argv) {
             marks = nullptr;
         if (timed) rto_timer_start(ctx, RTO_T_TORCH);
         const bool packed = denoiser->fused() && filter_mode == RTO_FILTER_FACTORISED;
+        // frames of a lean batched launch (below): no aux planes, the noisy image holds (r, g, b, alpha) -- the network reads that
+        const bool lean = rto_ctx_frames_are_lean(ctx, 0, n) != 0;
         if (packed)
-            rc = rto_guidance_net_forward_packed_culled(denoiser->fused_handle(), stream, rto_ctx_aux(ctx), n, height, width,
-                                                        RTO_NET_AUX_SQUARES_IMPLIED, marks, mark_words, mark_bg);
+            rc = rto_guidance_net_forward_packed_culled(denoiser->fused_handle(), stream, lean ? rto_ctx_noisy(ctx) : rto_ctx_aux(ctx), n, height,
+                                                        width, lean ? RTO_NET_INPUT_RGBA : RTO_NET_AUX_SQUARES_IMPLIED, marks, mark_words, mark_bg);
         else
-            denoiser->forward(rto_ctx_aux(ctx), n, height, width, &w, &g, &L);
+            denoiser->forward(lean ? rto_ctx_noisy(ctx) : rto_ctx_aux(ctx), n, height, width, &w, &g, &L, lean);
         if (timed) rto_timer_stop(ctx, RTO_T_TORCH);
         if (rc != RTO_OK) return rc;
         if (timed) rto_timer_start(ctx, RTO_T_FILTER);
@@ -471,6 +473,9 @@ int main(int argc, char** argv) {
     std::vector<float> aux;
     const bool write_buffer = args.has("write_buffer");
     if (write_buffer) aux.resize((size_t)width * height * RTO_AUX_CHANNELS);
+    // Batched launches whose aux planes nobody reads store the 16 bytes per pixel the fused denoise stage consumes instead of the
+    // reference's 48 (rto_ctx_set_lean_outputs; same PNGs).  --write_buffer dumps the aux planes, the TorchScript module reads them.
+    if (batch > 1 && options.denoise && denoiser && denoiser->fused() && !write_buffer) CHECK_RTO(rto_ctx_set_lean_outputs(ctx, 1));
 
     if (batch > 1) {
         // throughput form of the loop below: groups of `batch` poses per launch.  ctx.rng stays at its

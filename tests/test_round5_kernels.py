@@ -1,0 +1,131 @@
+"""Round 5: the variants of the batched path that the default launch does not take must render the default's pixels.
+
+  * the record layouts: coefficient records in the order of the two-level image's entries (TreeDev::rec_by_entry, the default
+    for dense SH9 / SH16 trees) against slot-ordered records (RTO_TREE_SLOT_RECORDS=1 at upload), through every kernel --
+    batched, single-frame, the counting instantiation (one-level walk + two-level lookup of the hit's entry) and the generic
+    kernel after the reference arrays were rebuilt FROM the entry-ordered records;
+  * the reservoir traversal kernel (render_persist_res, tuning refill = 500 + K / 900 + K, flags x 100000: 1 = thresholds
+    touched at set-up, 4 = LDS-direct threshold loads; 300 + K / 400 + K = one store per hit) -- not the default, but a kernel
+    of the library: bit-identical frames for every setting, also on a deep tree (LDS ancestor stack), an NDC tree and SPP 1;
+  * a launch whose SPP leaves a hit entry too few bits for an entry of the two-level image, but enough for a leaf
+    slot, walks the ONE-level image instead of dropping to the generic kernel (test hook: tuning "wide_bits")."""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+import rt_octree_amd as R
+from helpers import assert_bits_equal, cameras, make_pair, oracle_frame
+from rt_octree_amd import synth
+
+pytestmark = pytest.mark.gpu
+POSES = synth.orbit_poses(8)
+
+
+def batch_frames(dt, cams, spp, jumps, tuning=(), lean=False):
+    W, H = cams[0].width, cams[0].height
+    ctx = R.RenderContext(W, H, frames=len(cams))
+    for k, v in tuning:
+        ctx.set_tuning(k, v)
+    ctx.rng_seed()
+    R.launch_renderer_batch(dt, cams, R.RenderOptions(spp=spp, denoise=False), ctx, rng_jumps=jumps)
+    out = []
+    for f in range(len(cams)):
+        ctx.select_frame(f)
+        out.append(ctx.download_aux())
+    ctx.free()
+    return np.stack(out)
+
+
+def test_entry_ordered_and_slot_ordered_records_render_the_same_frames():
+    tree = synth.make_tree(depth_limit=7, basis_dim=16, seed=5, shell=2.0)
+    ht = orc.HostTree(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+    dt_e = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+    os.environ["RTO_TREE_SLOT_RECORDS"] = "1"
+    try:
+        dt_s = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+    finally:
+        del os.environ["RTO_TREE_SLOT_RECORDS"]
+    assert dt_e.wide_nodes > 0 and dt_s.wide_nodes == dt_e.wide_nodes
+    assert dt_e.device_bytes > dt_s.device_bytes  # (a first-level leaf of a pair owns 8 entries: more records than slots)
+    W, H, spp = 160, 120, 6
+    cams = [cameras(W, H, p)[1] for p in POSES[:4]]
+    jumps = [100 + i for i in range(4)]
+    a_e, a_s = batch_frames(dt_e, cams, spp, jumps), batch_frames(dt_s, cams, spp, jumps)
+    assert_bits_equal(a_e, a_s, "batched frames, entry- vs slot-ordered records")
+    want = oracle_frame(ht, cameras(W, H, POSES[2])[0], spp, frame=102)
+    assert_bits_equal(a_e[2], want[0], "entry-ordered records vs the oracle")
+    for dt in (dt_e, dt_s):
+        ctx = R.RenderContext(W, H)
+        for kernel, stats in ((R.KERNEL_FAST, False), (R.KERNEL_FAST, True), (R.KERNEL_GENERIC, False)):
+            ctx.rng_seed()
+            ctx.rng_advance(102 << 32)
+            ctx.set_kernel(kernel)
+            ctx.enable_stats(stats)
+            R.launch_renderer(dt, cams[2], R.RenderOptions(spp=spp, denoise=False), ctx)
+            assert_bits_equal(ctx.download_aux(), want[0], "kernel %d stats %d" % (kernel, stats))
+        ctx.enable_stats(False)
+        ctx.free()
+    dt_e.free()
+    dt_s.free()
+
+
+RES_SETTINGS = [508, 516, 524, 532, 908, 916, 100516, 400516, 500524, 500508, 316, 500308, 416]
+
+
+@pytest.mark.parametrize("case", ["sh9_d8", "deep_d12", "spp1", "ndc"])
+def test_reservoir_kernel_settings_render_the_default_frames(case):
+    if case == "deep_d12":  # more than two pairs of levels below the grid: the LDS ancestor stack, not the register one
+        from test_render_parity import _chain_tree
+        tree = _chain_tree(13, seed=13)
+    else:
+        tree = synth.make_tree(depth_limit=8 if case == "sh9_d8" else 6, basis_dim=9 if case != "spp1" else 16, seed=11, shell=2.0)
+    dt = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+    if case == "ndc":
+        dt.set_ndc(200.0, 150.0, 180.0)
+    assert dt.wide_nodes > 0
+    W, H, spp = (200, 152, 1) if case == "spp1" else (200, 152, 6)
+    if case == "deep_d12":  # (the chain tree's dense leaves sit near the centre: look at it from close by)
+        cams = [cameras(W, H, synth.look_at_c2w(pos, target=(0.1, -0.1, 0.05)))[1]
+                for pos in [(2.2, 1.7, 1.9), (-1.9, 2.4, 0.8), (0.4, 0.3, 2.9), (1.0, -2.0, 1.5), (-2.0, -1.0, 2.0)]]
+    else:
+        cams = [cameras(W, H, p)[1] for p in POSES[:5]]
+    jumps = [7 + 3 * i for i in range(5)]
+    base = batch_frames(dt, cams, spp, jumps)
+    assert np.any(base[:, 3] > 0)
+    settings = RES_SETTINGS if spp == 6 else []  # (the A/B instantiations exist for the benchmark's SPP only)
+    for code in settings:
+        got = batch_frames(dt, cams, spp, jumps, tuning=(("refill", code),))
+        assert_bits_equal(got, base, "%s: refill = %d" % (case, code))
+    if spp != 6:  # other SPPs: the round-4 kernel is the only batched traversal kernel -- the codes fall through to it
+        assert_bits_equal(batch_frames(dt, cams, spp, jumps, tuning=(("refill", 516),)), base, "spp 1, refill code ignored")
+    dt.free()
+
+
+def test_two_level_image_over_budget_walks_the_one_level_image():
+    """slot-ordered records (compact records / RGBA trees have them): with a hit entry 'too small' for the two-level image's
+    entries the launch takes the WIDE = false instantiations -- same frames, no generic fallback (the generic kernel would
+    need the reference arrays back: device_bytes stays put)"""
+    tree = synth.make_tree(depth_limit=7, basis_dim=9, seed=3, shell=2.0)
+    dt = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format, compact_records=True)
+    assert dt.wide_nodes > 0
+    W, H, spp = 160, 120, 6
+    cams = [cameras(W, H, p)[1] for p in POSES[:3]]
+    jumps = [5, 6, 7]
+    base = batch_frames(dt, cams, spp, jumps)
+    got = batch_frames(dt, cams, spp, jumps, tuning=(("wide_bits", 6),))  # 2^6 entries: nothing fits
+    assert_bits_equal(got, base, "one-level walk forced by the budget hook")
+    one = R.RenderContext(W, H)
+    one.set_tuning("wide_bits", 6)
+    one.rng_seed()
+    one.rng_advance(6 << 32)
+    R.launch_renderer(dt, cams[1], R.RenderOptions(spp=spp, denoise=False), one)
+    assert_bits_equal(one.download_aux(), base[1], "single-frame kernel on the one-level image")
+    # a tree whose records follow the entries cannot fall back (its records are indexed by them): generic kernel, same frames
+    dt_e = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+    got_e = batch_frames(dt_e, cams, spp, jumps, tuning=(("wide_bits", 6),))
+    assert_bits_equal(got_e, base, "entry-ordered records over budget: the generic kernel, same frames")
+    one.free()
+    dt.free()
+    dt_e.free()

@@ -907,6 +907,8 @@ struct RayState {
     uint32_t nh;           // staged hit lists: hit entries of this ray parked in LDS, not yet written out
     uint32_t node;  // node about to be visited; kGridNext = the top grid is visited next (two-level image: 0 = the grid)
     uint32_t woff;  // two-level image: lowest of the coordinate bits that index the node about to be visited
+    uint32_t wb;    // two-level image: coordinate bits per axis that index it -- G at the grid, 2 at a wide node (round 5: kept with
+                    // the ray instead of re-derived from `node` by a compare + select in every iteration)
     float cxy __attribute__((ext_vector_type(2)));  // cen[0], cen[1] as a register pair for the packed march arithmetic
     // _dda_unit's max(t1, t1 + invdir) per axis is t1 + (invdir > 0 ? invdir : 0): the sign of invdir is the ray's, not the
     // step's (exit_add below)
@@ -1426,6 +1428,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                                 rs.piz = (uint32_t)(rs.pos[2] * 16777216.f);
                                 rs.node = WIDE ? 0u : (G > 0 ? kGridNext : 0u);
                                 rs.woff = 24u - (uint32_t)G;
+                                rs.wb = (uint32_t)G;
                             }
                         } else {
                             rs.tmax = -1.f;  // missed the box (ray_enter wrote a tmax that the stale t might undercut)
@@ -1459,7 +1462,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     // (node number, 2, 22 - G - 2 p) at the wide node of the levels (G + 2p, G + 2p + 1).  v_bfe_u32 and
                     // v_lshl_or_b32 take the per-lane widths: no grid / node case split, no second address, no branch pair
                     // around two loads (the one-level walk below spends 19 VALU + 7 SALU where this spends 10 VALU).
-                    const uint32_t b = rs.node ? 2u : (uint32_t)G;
+                    const uint32_t b = rs.wb;
                     slot = (rs.node << b) | __builtin_amdgcn_ubfe(rs.pix, rs.woff, b);
                     slot = (slot << b) | __builtin_amdgcn_ubfe(rs.piy, rs.woff, b);
                     slot = (slot << b) | __builtin_amdgcn_ubfe(rs.piz, rs.woff, b);
@@ -1477,7 +1480,14 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                         }
                     }
 #else
-                    w = nodew[slot];  // (through the L1: non-temporal loads cost 15-50 %)
+                    // (through the L1: non-temporal loads cost 15-50 %.  The byte offset as a 32-bit value -- the image has < 2^29
+                    //  entries -- lets the load take its base from SGPRs and one VGPR of offset: no 64-bit address pair, no register
+                    //  pinned to zero for its high half)
+#ifdef RTO_NODE_ADDR64  // (A/B: the 64-bit address pair of rounds 1-4)
+                    w = nodew[slot];
+#else
+                    w = *(gptr_t)((const __attribute__((address_space(1))) char*)nodew + (uint32_t)(slot << 2));
+#endif
 #endif
                     if ((int32_t)w >= -(1 << 30)) {  // internal: two levels down (from the grid: into the level-G node)
                         RTO_DBG_AT(1)
@@ -1489,6 +1499,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                         } else
                             stack[(((24u - (uint32_t)G) - rs.woff) >> 1) * 256u] = w;  // row p + 1 of the pair it spans (grid: row 0)
                         rs.woff -= 2u;
+                        rs.wb = 2u;
                     }
                 }
                 if constexpr (!WIDE) {
@@ -1878,6 +1889,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist_res(const TreeDev tre
                     rs.piz = (uint32_t)(rs.pos[2] * 16777216.f);
                     rs.node = 0u;
                     rs.woff = 24u - (uint32_t)G;
+                    rs.wb = (uint32_t)G;
                 }
             }
             rec_pos += take;
@@ -1893,7 +1905,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist_res(const TreeDev tre
             if (active) {  // ---- one node visit for every active lane (see render_persist)
                 RTO_DBG_AT(0)
                 uint32_t slot, w;
-                const uint32_t b = rs.node ? 2u : (uint32_t)G;
+                const uint32_t b = rs.wb;
                 slot = (rs.node << b) | __builtin_amdgcn_ubfe(rs.pix, rs.woff, b);
                 slot = (slot << b) | __builtin_amdgcn_ubfe(rs.piy, rs.woff, b);
                 slot = (slot << b) | __builtin_amdgcn_ubfe(rs.piz, rs.woff, b);
@@ -1909,6 +1921,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist_res(const TreeDev tre
                     } else
                         stack[(((24u - (uint32_t)G) - rs.woff) >> 1) * 256u] = w;
                     rs.woff -= 2u;
+                    rs.wb = 2u;
                 }
                 if ((int32_t)w < -(1 << 30)) {  // leaf: the march step (rt_core.cuh:241-270)
 #include "rto_march_leaf.inc"

@@ -88,7 +88,7 @@ def test_the_traversal_kernels_private_segments_are_what_is_recorded_here():
     for spp in (1, 2, 3, 4, 6, 8, 16, 32):
         k = res["_ZN3rto14render_persistILi%dELi32ELi8ELb1EEEvNS_7TreeDevENS_6OptDevENS_10FrameBatchEPyPjj" % spp]
         assert k["occupancy"] == 8 and k["vgprs"] <= 64, (spp, k)
-        assert k["scratch"] <= (64 if spp == 32 else 0), "render_persist<%d, wide>: %d bytes of scratch per lane" % (spp, k["scratch"])
+        assert k["scratch"] <= (72 if spp == 32 else 0), "render_persist<%d, wide>: %d bytes of scratch per lane" % (spp, k["scratch"])
         k1 = res["_ZN3rto14render_persistILi%dELi32ELi8ELb0EEEvNS_7TreeDevENS_6OptDevENS_10FrameBatchEPyPjj" % spp]
         assert k1["occupancy"] == 8 and k1["scratch"] <= (48 if spp == 32 else 8), (spp, k1)
     r = res["_ZN3rto18render_persist_resILi6ELi24ELi7ELb0EEEvNS_7TreeDevENS_6OptDevENS_10FrameBatchEPyPjj"]

@@ -2205,8 +2205,13 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
         const uint32_t cnt_w = min(total - w0, (uint32_t)kShadeCap);
         for (uint32_t j = lane; j < cnt_w; j += 64) {
             const uint32_t he = s_h[wv][j];
-            const int64_t idx = wave_px0 + s_q[wv][j];
-            const int x = (int)(idx % W), y = (int)(idx / W);
+            // the entry's pixel = pixel s_q of the wave's run, which starts at (wx0, wy0): carries instead of a 64-bit division
+            // per entry (round 5: `idx % W`, `idx / W` on an int64 were ~150 of the ~690 instructions an entry cost)
+            int x = wx0 + (int)s_q[wv][j], y = wy0;
+            while (x >= W) {
+                x -= W;
+                ++y;
+            }
             float dir[3], vdir[3], cen[3];
             ray_setup(x, y, cam, tree, dir, vdir, cen);  // only vdir is needed (rt_core.cuh:278)
             float basis_fn[RTO_BASIS_MAX_DEV];

@@ -120,6 +120,11 @@ RTO_DEV bool ray_enter(const TreeDev& tree, const OptDev& opt, float* dir, const
     return !(tmax < 0 || tmin > tmax);
 }
 
+// min(max(x, 0), 1 - 1e-6) (n3tree_query.hpp:20-24 clamp) as one v_med3_f32: the same value for every
+// finite x (the sign of a zero result may differ, which no later operation can observe: the
+// fixed-point conversion, fract * invdir and the sums that follow give the same numbers)
+RTO_DEV float clamp_unit(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f - 1e-6f); }
+
 // _dda_unit rt_core.cuh:38-51
 RTO_DEV float dda_unit(const float* p, const float* invdir) {
     float tm = 1e4;
@@ -688,12 +693,14 @@ __global__ void __launch_bounds__(256, SPP <= 8 ? RTO_FAST_WPS : 4) render_fast(
         if (WIDE && G == 0) stack[0] = 0u;
         uint32_t stk0 = 0u, stk1 = 0u;
         const bool regstack = WIDE && (tree.max_depth - G + 1) / 2 <= 2;  // (uniform) pairs of levels below the grid
+        const float exit_add[3] = {invdir[0] > 0.f ? invdir[0] : 0.f, invdir[1] > 0.f ? invdir[1] : 0.f, invdir[2] > 0.f ? invdir[2] : 0.f};
 
         while (t < tmax) {
-            float pos[3] = {cen[0] + t * dir[0], cen[1] + t * dir[1], cen[2] + t * dir[2]};
-            pos[0] = f_max(f_min(pos[0], 1.f - 1e-6f), 0.f);
-            pos[1] = f_max(f_min(pos[1], 1.f - 1e-6f), 0.f);
-            pos[2] = f_max(f_min(pos[2], 1.f - 1e-6f), 0.f);
+            // (round 5: the arithmetic forms of the batched kernel's march step -- one v_med3 per clamp, v_fract, the exit
+            //  time as t1 + (invdir > 0 ? invdir : 0), no 1e4 start of the minimum: see rto_march_leaf.inc for why each is the
+            //  same number -- a lone frame waits for the DEPENDENT chain of its longest ray, a third of which is this arithmetic:
+            //  0.307 -> 0.295 ms per lone 800x800 SPP-6 frame, profiles/r5_w_ab_fast.txt)
+            const float pos[3] = {clamp_unit(cen[0] + t * dir[0]), clamp_unit(cen[1] + t * dir[1]), clamp_unit(cen[2] + t * dir[2])};
             const uint32_t ix = (uint32_t)(pos[0] * 16777216.f);
             const uint32_t iy = (uint32_t)(pos[1] * 16777216.f);
             const uint32_t iz = (uint32_t)(pos[2] * 16777216.f);
@@ -721,7 +728,7 @@ __global__ void __launch_bounds__(256, SPP <= 8 ? RTO_FAST_WPS : 4) render_fast(
                     const uint32_t b = node ? 2u : (uint32_t)G, msk = (1u << b) - 1u;
                     const uint32_t off = node ? (uint32_t)(22 - G - 2 * pr) : 24u - (uint32_t)G;
                     slot = (((node << b | ((ix >> off) & msk)) << b | ((iy >> off) & msk)) << b) | ((iz >> off) & msk);
-                    w = tree.widew[slot];
+                    w = *(const uint32_t*)((const char*)tree.widew + (uint32_t)(slot << 2));  // (< 2^29 entries: a 32-bit byte offset)
                     if (nodew_is_leaf(w)) break;
                     node = w;  // the wide node two levels down
                     ++pr;
@@ -786,13 +793,10 @@ __global__ void __launch_bounds__(256, SPP <= 8 ? RTO_FAST_WPS : 4) render_fast(
             // bit for bit (a pure exponent shift, or the same single rounding into the denormals)
             const float cube_sz = __uint_as_float((uint32_t)(128 + lvl) << 23);
             const float inv_cube = __uint_as_float((uint32_t)(126 - lvl) << 23);
-            float loc[3];
+            float ex[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const float s = pos[i] * cube_sz;
-                loc[i] = s - floorf(s);
-            }
-            const float t_subcube = dda_unit(loc, invdir) * inv_cube;
+            for (int i = 0; i < 3; ++i) ex[i] = -__builtin_amdgcn_fractf(pos[i] * cube_sz) * invdir[i] + exit_add[i];
+            const float t_subcube = __builtin_fminf(__builtin_fminf(ex[0], ex[1]), ex[2]) * inv_cube;
             const float delta_t = t_subcube + opt.step_size;
             const float sigma = half_bits_to_float((uint16_t)(w & 0xffffu));
             if (sigma > opt.sigma_thresh) {
@@ -887,11 +891,6 @@ __global__ void __launch_bounds__(256, SPP <= 8 ? RTO_FAST_WPS : 4) render_fast(
 //     queue per XCD over an image wedge each, tile-major across the frames (FrameBatch::qstart);
 //   * the end-of-queue drain happens once per batch instead of once per frame.
 // Per-ray arithmetic is exactly render_fast's; results are bit-identical.
-
-// min(max(x, 0), 1 - 1e-6) (n3tree_query.hpp:20-24 clamp) as one v_med3_f32: the same value for every
-// finite x (the sign of a zero result may differ, which no later operation can observe: the
-// fixed-point conversion, fract * invdir and the sums that follow give the same numbers)
-RTO_DEV float clamp_unit(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f - 1e-6f); }
 
 // the per-ray state that survives between march steps (thresholds live in LDS, hits go straight
 // to the hand-off buffer)

@@ -1227,7 +1227,10 @@ RTO_DEV void dma_thresholds(const __attribute__((address_space(1))) uint32_t* tp
 // at a leaf, takes its march step and picks the restart node of the next one -- instead of a nested
 // "descend until leaf" loop whose trip count is the maximum over the wave (measured: 1.4 loads per
 // lane-step on average, but ~4 per wave-step for the slowest lane).
-template <int SPP, int REFILL, int WPS, bool WIDE>
+// STACK: where the ancestor stack lives -- 1: two registers (WIDE and at most two pairs of levels below the grid: decided by the
+// launcher, so the loop body holds no wave-uniform "which stack?" dispatch: that was 11 scalar instructions per iteration of ~135
+// issue slots), 0: the LDS rows
+template <int SPP, int REFILL, int WPS, bool WIDE, int STACK>
 __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, const OptDev opt, const FrameBatch fb,
                                                        unsigned long long* __restrict__ queue,
                                                        uint32_t* __restrict__ hits, const uint32_t chunk) {
@@ -1304,7 +1307,8 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     // ancestor "stack" is two registers: the restart node then comes from a select, not from an LDS read on the path of
     // every iteration (-2 % in one box, profiles/r4_r_ab_regstack.txt).  Deeper trees keep the LDS rows.  (wave-uniform)
     uint32_t stk0 = 0u, stk1 = 0u;
-    const bool regstack = WIDE && (tree.max_depth - G + 1) / 2 <= 2;
+    static_assert(WIDE || STACK == 0, "the register stack is for the two-level image");
+    constexpr bool regstack = STACK == 1;
 #ifdef RTO_HITS_DIRECT
     constexpr bool kHitsDirect = true;
 #else
@@ -2433,11 +2437,12 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
     const bool res_regstack = (tree.max_depth - tree.top_levels + 1) / 2 <= 2;
     const size_t lds = RES ? (size_t)(SPP + 2 + 10 + (res_regstack ? 0 : tree.max_depth + 1 - tree.top_levels) + (tree.ndc_width > 0 ? 3 : 0)) * 256 * sizeof(uint32_t)
                            : (size_t)(tree.max_depth + 1 - tree.top_levels + SPP + 1) * 256 * sizeof(uint32_t) + sizeof(float) * kCamFloats * (size_t)fb_in.n;
-    auto kern = [] {
+    auto kern = [regs = res_regstack] {
+        (void)regs;
         if constexpr (RES)
             return &render_persist_res<SPP, REFILL, WPS, RES == 2>;
         else
-            return &render_persist<SPP, REFILL, WPS, WIDE>;
+            return WIDE && regs ? &render_persist<SPP, REFILL, WPS, WIDE, WIDE ? 1 : 0> : &render_persist<SPP, REFILL, WPS, WIDE, 0>;
     }();
     FrameBatch fb = fb_in;
     // (the reservoir kernel never translates its hit entries: they name their records directly, TreeDev::rec_by_entry, or the

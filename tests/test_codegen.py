@@ -52,7 +52,7 @@ def test_the_two_gathers_of_a_node_visit_are_issued_back_to_back(tmp_path):
     """the ONE-level walk (trees without the two-level image): top-grid entry and slot word are issued back to back"""
     text = device_asm("render_kernels.hip")
     for spp in (1, 6):  # the benchmark's instantiations (C5, C2 / C4)
-        m = re.search(r"^_ZN3rto14render_persistILi%dELi32ELi8ELb0EEE[^\n]*\n(.*?)s_endpgm" % spp, text, re.S | re.M)
+        m = re.search(r"^_ZN3rto14render_persistILi%dELi32ELi8ELb0ELi0EEE[^\n]*\n(.*?)s_endpgm" % spp, text, re.S | re.M)
         assert m, "render_persist<%d,32,8,false> not found in the assembly" % spp
         body = [ln.split(";")[0].strip() for ln in m.group(1).splitlines()]
         body = [ln for ln in body if ln and not ln.startswith(".") or ln.startswith(".LBB")]
@@ -70,9 +70,13 @@ def test_the_two_level_walk_has_one_gather_per_node_visit(tmp_path):
     entry, no second address computation anywhere in the kernel"""
     text = device_asm("render_kernels.hip")
     for spp in (1, 6):
-        m = re.search(r"^_ZN3rto14render_persistILi%dELi32ELi8ELb1EEE[^\n]*\n(.*?)s_endpgm" % spp, text, re.S | re.M)
-        assert m, "render_persist<%d,32,8,true> not found in the assembly" % spp
-        assert "global_load_dwordx2" not in m.group(1)
+        for stack in (0, 1):  # ancestor stack in LDS rows / in two registers
+            m = re.search(r"^_ZN3rto14render_persistILi%dELi32ELi8ELb1ELi%dEEE[^\n]*\n(.*?)s_endpgm" % (spp, stack), text, re.S | re.M)
+            assert m, "render_persist<%d,32,8,true,%d> not found in the assembly" % (spp, stack)
+            assert "global_load_dwordx2" not in m.group(1)
+
+
+LDS_STACK_SCRATCH, LDS_STACK_SCRATCH_32 = 36, 72  # bytes per lane today (28-36 for SPP <= 16)
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
@@ -86,10 +90,14 @@ def test_the_traversal_kernels_private_segments_are_what_is_recorded_here():
     that a change of them is a decision, not an accident."""
     res = kernel_resources("render_kernels.hip")
     for spp in (1, 2, 3, 4, 6, 8, 16, 32):
-        k = res["_ZN3rto14render_persistILi%dELi32ELi8ELb1EEEvNS_7TreeDevENS_6OptDevENS_10FrameBatchEPyPjj" % spp]
+        k = res["_ZN3rto14render_persistILi%dELi32ELi8ELb1ELi1EEEvNS_7TreeDevENS_6OptDevENS_10FrameBatchEPyPjj" % spp]
         assert k["occupancy"] == 8 and k["vgprs"] <= 64, (spp, k)
         assert k["scratch"] <= (72 if spp == 32 else 0), "render_persist<%d, wide>: %d bytes of scratch per lane" % (spp, k["scratch"])
-        k1 = res["_ZN3rto14render_persistILi%dELi32ELi8ELb0EEEvNS_7TreeDevENS_6OptDevENS_10FrameBatchEPyPjj" % spp]
+        # (the same kernel with its ancestor stack in LDS rows -- trees deeper than four levels below the top grid: spills
+        #  in the ray set-up, none inside the march loop)
+        kl = res["_ZN3rto14render_persistILi%dELi32ELi8ELb1ELi0EEEvNS_7TreeDevENS_6OptDevENS_10FrameBatchEPyPjj" % spp]
+        assert kl["occupancy"] == 8 and kl["scratch"] <= (LDS_STACK_SCRATCH_32 if spp == 32 else LDS_STACK_SCRATCH), (spp, kl)
+        k1 = res["_ZN3rto14render_persistILi%dELi32ELi8ELb0ELi0EEEvNS_7TreeDevENS_6OptDevENS_10FrameBatchEPyPjj" % spp]
         assert k1["occupancy"] == 8 and k1["scratch"] <= (48 if spp == 32 else 8), (spp, k1)
     r = res["_ZN3rto18render_persist_resILi6ELi24ELi7ELb0EEEvNS_7TreeDevENS_6OptDevENS_10FrameBatchEPyPjj"]
     assert r["occupancy"] == 7 and r["vgprs"] <= 72 and r["scratch"] == 0, r

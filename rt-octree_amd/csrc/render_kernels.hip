@@ -198,6 +198,32 @@ RTO_DEV void ray_basis(const TreeDev& tree, const OptDev& opt, const float* vdir
         if (i < opt.basis_minmax[0] || i > opt.basis_minmax[1]) basis_fn[i] = 0.f;
 }
 
+// ray_basis for a tree KNOWN to hold B SH basis functions per channel (the shading kernel's record layouts): the same values in
+// basis_fn[0 .. B-1] -- the only ones shade_leaf_packed<3 B + 1> / shade_leaf_quant<B> read -- without the run-time switch over
+// the basis size, the 25-entry clear and the 25 mask tests (a third of the ~220 instructions the basis cost per hit entry)
+template <int B>
+RTO_DEV void ray_basis_sh(const OptDev& opt, const float* vdir_in, float* basis_fn) {
+    float vdir[3] = {vdir_in[0], vdir_in[1], vdir_in[2]};
+    if (opt.rot_on) {  // (as in ray_basis)
+        const float* k = opt.rot_k;
+        const float cross[3] = {k[1] * vdir[2] - k[2] * vdir[1], k[2] * vdir[0] - k[0] * vdir[2],
+                                k[0] * vdir[1] - k[1] * vdir[0]};
+        const float dot = k[0] * vdir[0] + k[1] * vdir[1] + k[2] * vdir[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            vdir[i] = (float)((double)(vdir[i] * opt.rot_cos + cross[i] * opt.rot_sin) + (double)(k[i] * dot) * opt.rot_omc);
+    }
+    float full[RTO_BASIS_MAX_DEV];
+    sh_basis(B, vdir, full);  // (B is a constant: the switch folds)
+#pragma unroll
+    for (int i = 0; i < B; ++i) basis_fn[i] = full[i];
+    if (opt.basis_minmax[0] > 0 || opt.basis_minmax[1] < B - 1) {  // (uniform; the default options mask nothing)
+#pragma unroll
+        for (int i = 0; i < B; ++i)
+            if (i < opt.basis_minmax[0] || i > opt.basis_minmax[1]) basis_fn[i] = 0.f;
+    }
+}
+
 // rt_core.cuh:286-325 for one hit leaf: out[0..2] += cnt * sigmoid(<basis, coeffs>), out[3] += cnt.
 // The summation order (DC, then the 16..24 group, 9..15, 4..8, 1..3, each left to right) is part of
 // the result.
@@ -1308,7 +1334,11 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     // every iteration (-2 % in one box, profiles/r4_r_ab_regstack.txt).  Deeper trees keep the LDS rows.  (wave-uniform)
     uint32_t stk0 = 0u, stk1 = 0u;
     static_assert(WIDE || STACK == 0, "the register stack is for the two-level image");
-    constexpr bool regstack = STACK == 1;
+    constexpr bool regstack = STACK == 1, kStackInRegs = regstack;
+    uint32_t g_vgpr = (uint32_t)tree.top_levels;  // (rto_march_leaf.inc: the restart's `wb` select)
+    asm volatile("" : "+v"(g_vgpr));
+    uint32_t woff_pair0 = 22u - (uint32_t)tree.top_levels;  // bit offset of the first pair below the grid (one scalar operand)
+    asm volatile("" : "+s"(woff_pair0));
 #ifdef RTO_HITS_DIRECT
     constexpr bool kHitsDirect = true;
 #else
@@ -1495,10 +1525,12 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     if ((int32_t)w >= -(1 << 30)) {  // internal: two levels down (from the grid: into the level-G node)
                         RTO_DBG_AT(1)
                         rs.node = w;
-                        if (regstack) {  // (wave-uniform) two pairs at most: the ancestor "stack" is two registers
+                        if (regstack) {
+                            // two pairs at most: the ancestor "stack" is ONE register, the node of the first pair.  (The second
+                            // pair's node needs none: a restart inside the second pair happens at a leaf of that very node --
+                            // the ray stays in rs.node.)
                             const bool first = rs.woff == 24u - (uint32_t)G;
                             stk0 = first ? w : stk0;
-                            stk1 = first ? stk1 : w;
                         } else
                             stack[(((24u - (uint32_t)G) - rs.woff) >> 1) * 256u] = w;  // row p + 1 of the pair it spans (grid: row 0)
                         rs.woff -= 2u;
@@ -1668,6 +1700,8 @@ __global__ void __launch_bounds__(256, WPS) render_persist_res(const TreeDev tre
     const int G = tree.top_levels;
     uint32_t stk0 = 0u, stk1 = 0u;
     const bool regstack = (tree.max_depth - G + 1) / 2 <= 2;  // (wave-uniform) see render_persist
+    constexpr bool kStackInRegs = false;                         // (not a compile-time fact here: rto_march_leaf.inc branches)
+    constexpr uint32_t g_vgpr = 0u, woff_pair0 = 0u;             // (named by the discarded branch of rto_march_leaf.inc)
     const int stack_rows = regstack ? 0 : tree.max_depth + 1 - G;
     float* const s_dst = reinterpret_cast<float*>(s_mem) + tid;
     uint32_t* const stack = s_mem + kStackRow * 256 + tid;
@@ -2218,7 +2252,12 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
             float dir[3], vdir[3], cen[3];
             ray_setup(x, y, cam, tree, dir, vdir, cen);  // only vdir is needed (rt_core.cuh:278)
             float basis_fn[RTO_BASIS_MAX_DEV];
-            ray_basis(tree, opt, vdir, basis_fn);
+            if constexpr (MODE > 0)  // (the launcher picks MODE from the tree: SH, data_dim = MODE)
+                ray_basis_sh<(MODE - 1) / 3>(opt, vdir, basis_fn);
+            else if constexpr (MODE < 0)  // quantised SH tree, -MODE basis functions
+                ray_basis_sh<-MODE>(opt, vdir, basis_fn);
+            else
+                ray_basis(tree, opt, vdir, basis_fn);
             float o[4];
             uint32_t leaf = hit_slot<SPP>(he);
             if (fb.res_flags & kResHitsWide) leaf = wide_to_slot(tree, leaf);  // (block-uniform) the traversal left entries of the two-level image

@@ -382,6 +382,7 @@ __global__ void __launch_bounds__(256, 2) filter_backward(const float4* __restri
 #define RTO_FAST_WGS 4
 #endif
 constexpr int kFastW = 32, kFastH = RTO_FAST_H, kFastRows = RTO_FAST_H / 8;  // outputs per workgroup; rows per thread
+constexpr int kFastRowStride = 48, kFastHalf = 24;  // LDS row of a staged tile: [even columns | pad | odd columns | pad] (filter_fast)
 
 // a level of filter_fast for a tile whose guidance range would underflow the factorised exponentials:
 // per-pixel maximum as in the exact form, taps from global memory (rare, slow, correct)
@@ -438,10 +439,17 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
                                                      int H, int W, const FilterCull cull) {
     constexpr int SW = kFastW + 2 * L, SH = kFastH + 2 * L, NE = SW * SH;
     constexpr int PER = (NE + 255) / 256;  // staged elements per thread
+    // LDS rows of P_l and of the window-row sums are SPLIT BY COLUMN PARITY: column c of a row sits at (c & 1) * kFastHalf +
+    // (c >> 1) of a kFastRowStride-slot row.  Pass A of the box filter gives a thread TWO adjacent output columns (it reads
+    // 2 S + 2 values for them instead of 2 (2 S + 1)): its lanes then walk one parity half with stride 1 -- conflict-free
+    // 16-byte reads (a half offset of 24 slots = 128 B mod 256 B keeps the alternating lanes of pass B and of the stores on
+    // different banks too).
+    constexpr int SWP = kFastRowStride, HALF = kFastHalf;
+    static_assert(SW / 2 <= HALF && HALF + SW / 2 <= SWP, "a parity half holds the even / odd columns of a staged row");
     extern __shared__ float4 s_dyn[];
-    float4* s_p = s_dyn;         // [SH][SW] P_l of the current level
-    float4* s_hs = s_dyn + NE;   // [kFastH + 2 L][kFastW] window-row sums of the current level (two-pass box filter)
-    float4* s_rgb = s_hs + (kFastH + 2 * L) * kFastW;  // fp32-plane form only: [SH][SW] noisy tile (the packed form keeps its pixels in registers)
+    float4* s_p = s_dyn;               // [SH][SWP] P_l of the current level
+    float4* s_hs = s_dyn + SH * SWP;   // [kFastH + 2 L][SWP] window-row sums of the current level (two-pass box filter)
+    float4* s_rgb = s_hs + (kFastH + 2 * L) * SWP;  // fp32-plane form only: [NE] noisy tile (the packed form keeps its pixels in registers)
     __shared__ float s_red[2][4];
 
     const int tid = threadIdx.x;
@@ -458,7 +466,6 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
     const _Float16* packed = reinterpret_cast<const _Float16*>(weight);
     const int lx = tid & (kFastW - 1), ry = tid / kFastW;  // column, row group
     const int py0 = blockIdx.y * kFastH + ry * kFastRows;
-    const int base = (ry * kFastRows + L) * SW + lx + L;     // staged index of this thread's first output
 
     // tiles of the strip that see only background: filled from the measured tile, not computed (bit ts; workgroup-uniform)
     uint32_t skip = 0;
@@ -488,11 +495,32 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
         float gv[PACKED ? 1 : L][PACKED ? 1 : PER];
         float wl[PACKED ? 1 : L][PACKED ? 1 : kFastRows];
     };
-    auto gindex = [&](int x0, int i) {  // staged element i of this thread -> global index (or -1 outside the image)
+    // staged element i of this thread, in STORAGE order (a row's even columns, then its odd ones: 8 consecutive lanes store to
+    // 8 consecutive LDS slots): row ty, column tx of the staged tile, slot in s_p -- packed into ONE register per element
+    // (slot | tx << 11 | ty << 17; bit 31: beyond the tile) and unpacked where it is used: the compiler otherwise keeps every
+    // derived index of every element live across the strip loop, and the packed form spills
+    uint32_t epk[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
         const int e = tid + i * 256;
-        const int ty = e / SW, tx = e - ty * SW;
+        const int ty = e / SW, r = e - ty * SW, half = r >= SW / 2 ? 1 : 0, k = r - half * (SW / 2);
+        epk[i] = (uint32_t)(ty * SWP + half * HALF + k) | (uint32_t)(2 * k + half) << 11 | (uint32_t)ty << 17 | (e < NE ? 0u : 0x80000000u);
+    }
+    static_assert(SH * SWP <= 2048 && SW <= 64 && SH <= 32, "bit budget of the packed element index");
+    auto elem = [&](int i, int& ty, int& tx, bool& in_tile) {
+        uint32_t v = epk[i];
+        asm volatile("" : "+v"(v));  // (opaque: nothing derived from it is loop-invariant to the compiler)
+        ty = (int)((v >> 17) & 31u);
+        tx = (int)((v >> 11) & 63u);
+        in_tile = (int32_t)v >= 0;
+        return (int)(v & 2047u);
+    };
+    auto gindex = [&](int x0, int i) {  // staged element i of this thread -> global index (or -1 outside the image)
+        int ty, tx;
+        bool in_tile;
+        elem(i, ty, tx, in_tile);
         const int gx = x0 + tx, gy = y0 + ty;
-        return (e < NE && gx >= 0 && gx < W && gy >= 0 && gy < H) ? gy * W + gx : -1;  // (a frame has < 2^31 pixels)
+        return (in_tile && gx >= 0 && gx < W && gy >= 0 && gy < H) ? gy * W + gx : -1;  // (a frame has < 2^31 pixels)
     };
     auto fetch = [&](int tile, Fetched& f) {
         const int x0 = tile * kFastW - L, px = tile * kFastW + lx;
@@ -610,11 +638,14 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
                     const int e = tid + i * 256;
                     if (e < NE) {
                         const float E = inimg[i] ? __builtin_amdgcn_exp2f((gv[i] - c) * 1.44269504088896340736f) : 0.f;
+                        int ty, tx;
+                        bool in_tile;
+                        const int sp = elem(i, ty, tx, in_tile);
                         if constexpr (PACKED) {
-                            s_p[e] = make_float4(E * cr[i], E * cg[i], E * cb[i], E);
+                            s_p[sp] = make_float4(E * cr[i], E * cg[i], E * cb[i], E);
                         } else {
                             const float4 t = s_rgb[e];  // (written by this very thread)
-                            s_p[e] = make_float4(E * t.x, E * t.y, E * t.z, E);
+                            s_p[sp] = make_float4(E * t.x, E * t.y, E * t.z, E);
                         }
                     }
                 }
@@ -629,20 +660,35 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
                 // pass B: a thread adds the 2S + 1 row sums of each of its outputs (rows ascending: box_rows' order again).
                 // Same additions in the same order -- bit-identical to the one-pass form -- from 52 reads per output.
                 constexpr int S = l + 1, HR = kFastH + 2 * S;
+                // (pass A, two adjacent output columns 2 xp, 2 xp + 1 per thread: the 2 S + 2 values of their windows are read
+                //  once, the 2 S - 1... values both windows hold are added once -- t1 + .. + t2S, ascending -- and each sum gets its
+                //  own end: the tolerance route's sums in another order than the one-pass form's, differences of an ulp)
 #pragma unroll
-                for (int it = 0; it < (HR * kFastW + 255) / 256; ++it) {
+                for (int it = 0; it < (HR * (kFastW / 2) + 255) / 256; ++it) {
                     const int idx = tid + it * 256;
-                    if (idx < HR * kFastW) {
-                        const int ya = idx / kFastW, xa = idx - ya * kFastW;
-                        const float4* row = s_p + (L - S + ya) * SW + L + xa;
+                    if (idx < HR * (kFastW / 2)) {
+                        const int ya = idx / (kFastW / 2), xp = idx - ya * (kFastW / 2);
+                        const float4* row = s_p + (L - S + ya) * SWP + xp;
                         float2v rg = {0.f, 0.f}, bs = {0.f, 0.f};
+                        float4 t0, tl;
 #pragma unroll
-                        for (int dx = -S; dx <= S; ++dx) {
-                            const float4 t = row[dx];
-                            rg += float2v{t.x, t.y};
-                            bs += float2v{t.z, t.w};
+                        for (int k = 0; k <= 2 * S + 1; ++k) {
+                            constexpr int c0 = L - S;  // staged column of the first window value of output column 0
+                            const float4 t = row[((c0 + k) & 1) * HALF + ((c0 + k) >> 1)];
+                            if (k == 0)
+                                t0 = t;
+                            else if (k == 2 * S + 1)
+                                tl = t;
+                            else {
+                                rg += float2v{t.x, t.y};
+                                bs += float2v{t.z, t.w};
+                            }
+                            // (at most four 16-byte values in flight: the scheduler otherwise hoists all 2 S + 2 reads -- 40 VGPRs
+                            //  at S = 4 next to the prefetched tile -- and the packed form spills)
+                            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                         }
-                        s_hs[idx] = make_float4(rg.x, rg.y, bs.x, bs.y);
+                        s_hs[ya * SWP + xp] = make_float4(t0.x + rg.x, t0.y + rg.y, t0.z + bs.x, t0.w + bs.y);
+                        s_hs[ya * SWP + HALF + xp] = make_float4(rg.x + tl.x, rg.y + tl.y, bs.x + tl.z, bs.y + tl.w);
                     }
                 }
                 __syncthreads();  // the row sums are complete (and s_p may be rewritten by the next level)
@@ -651,7 +697,7 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
                 for (int o = 0; o < kFastRows; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int j = 0; j < 2 * S + kFastRows; ++j) {
-                    const float4 t = s_hs[(ry * kFastRows + j) * kFastW + lx];
+                    const float4 t = s_hs[(ry * kFastRows + j) * SWP + (lx & 1) * HALF + (lx >> 1)];
 #pragma unroll
                     for (int o = 0; o < kFastRows; ++o) {
                         if (j - o >= 0 && j - o <= 2 * S) {
@@ -696,7 +742,7 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
 hipError_t launch_filter_fast_packed(const void* packed_maps, int H, int W, int n, const float* img_in, float* img_out,
                                      const uint32_t* tile_mask, int mask_words, const float* fill_tile, hipStream_t stream) {
     const dim3 grid(((W + kFastW - 1) / kFastW + kFastStrip - 1) / kFastStrip, (H + kFastH - 1) / kFastH, n), block(256);
-    const size_t lds = (size_t)((kFastW + 8) * (kFastH + 8) + (kFastH + 8) * kFastW) * sizeof(float4);  // P_l tile + window-row sums
+    const size_t lds = (size_t)(2 * (kFastH + 8) * kFastRowStride) * sizeof(float4);  // P_l tile + window-row sums, parity-split rows
     FilterCull cull;
     cull.mask = tile_mask;
     cull.mask_words = mask_words;
@@ -721,7 +767,7 @@ hipError_t launch_filter_fast_culled(const float* weight, const float* guidance,
     float4* out4 = reinterpret_cast<float4*>(img_out);
 #define RTO_FFAST(LL)                                                                                              \
     case LL: {                                                                                                     \
-        const size_t lds = (size_t)(2 * (kFastW + 2 * LL) * (kFastH + 2 * LL) + (kFastH + 2 * LL) * kFastW) * sizeof(float4); \
+        const size_t lds = (size_t)(2 * (kFastH + 2 * LL) * kFastRowStride + (kFastW + 2 * LL) * (kFastH + 2 * LL)) * sizeof(float4); \
         hipLaunchKernelGGL((filter_fast<LL, false>), grid, block, lds, stream, weight, guidance, in4, out4, H, W, cull); \
     } break;
     switch (L) {

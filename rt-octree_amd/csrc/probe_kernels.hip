@@ -296,24 +296,32 @@ __global__ void __launch_bounds__(256) valu_probe_kernel(int iters, float k0, fl
     s_probe[threadIdx.x] = threadIdx.x;
     const uint32_t lds_addr = (uint32_t)(threadIdx.x * 4u);  // (LDS kinds: conflict-free dword per lane)
     __syncthreads();
+    // kinds 68..: an earlier kind's block with part of the wave switched off -- does a VALU instruction cost less when whole
+    // 16- or 32-lane groups of its wave are inactive?  (EXEC is set around the timed loop, whose own control flow is scalar.)
+    constexpr int BK = KIND == 68 || KIND == 69 ? 0 : KIND >= 70 && KIND <= 72 ? 2 : KIND >= 73 && KIND <= 75 ? 14 : KIND;
+    constexpr unsigned long long kExec = KIND == 68 || KIND == 70 || KIND == 73 ? 0xFFFFFFFFull
+                                         : KIND == 69 || KIND == 71 || KIND == 74 ? 0xFFFFull
+                                         : KIND == 72 ? 0x5555555555555555ull
+                                         : KIND == 75 ? 0x0000FFFF0000FFFFull : ~0ull;
+    if constexpr (kExec != ~0ull) asm volatile("s_mov_b64 exec, %0" ::"s"(kExec));
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
     for (int it = 0; it < iters; ++it) {
-        if constexpr (KIND == 0) asm volatile(RTO_R16(OP_FMA) RTO_R16(OP_FMA) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 1) asm volatile(RTO_R16(OP_ADDU) RTO_R16(OP_ADDU) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 2) asm volatile(RTO_R16(OP_LSHLOR) RTO_R16(OP_LSHLOR) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 3) asm volatile(RTO_R16(OP_MUL) RTO_R16(OP_MUL) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 4) asm volatile(RTO_R16(OP_FRACT) RTO_R16(OP_FRACT) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 5) asm volatile(RTO_R16(OP_CVT) RTO_R16(OP_CVT) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 6) asm volatile(RTO_R16(OP_FFBH) RTO_R16(OP_FFBH) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 7) asm volatile(RTO_R16(OP_MED3) RTO_R16(OP_MED3) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 8) asm volatile(RTO_R16(OP_BFE) RTO_R16(OP_BFE) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 9) asm volatile(RTO_R16(OP_MAX) RTO_R16(OP_MAX) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 10) asm volatile(RTO_R16(OP_CMPSEL) : RTO_REGS16 : "v"(k1), "v"(k0) : "vcc");
-        if constexpr (KIND == 11) asm volatile(RTO_R8(OP_PKFMA) RTO_R8(OP_PKFMA) RTO_R8(OP_PKFMA) RTO_R8(OP_PKFMA) : RTO_REGS8 : "v"(dk1), "v"(dk0));
-        if constexpr (KIND == 12) asm volatile(RTO_R8(OP_PKMUL) RTO_R8(OP_PKMUL) RTO_R8(OP_PKMUL) RTO_R8(OP_PKMUL) : RTO_REGS8 : "v"(dk1), "v"(dk0));
-        if constexpr (KIND == 13) asm volatile(RTO_R8(OP_FMA64) RTO_R8(OP_FMA64) RTO_R8(OP_FMA64) RTO_R8(OP_FMA64) : RTO_REGS8 : "v"(dk1), "v"(dk0));
-        if constexpr (KIND == 14)  // the traversal loop's mix: float mul / fract / max / min / med3 / cvt, integer xor / or / ffbh / bfe / shift-or / add
+        if constexpr (BK == 0) asm volatile(RTO_R16(OP_FMA) RTO_R16(OP_FMA) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 1) asm volatile(RTO_R16(OP_ADDU) RTO_R16(OP_ADDU) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 2) asm volatile(RTO_R16(OP_LSHLOR) RTO_R16(OP_LSHLOR) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 3) asm volatile(RTO_R16(OP_MUL) RTO_R16(OP_MUL) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 4) asm volatile(RTO_R16(OP_FRACT) RTO_R16(OP_FRACT) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 5) asm volatile(RTO_R16(OP_CVT) RTO_R16(OP_CVT) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 6) asm volatile(RTO_R16(OP_FFBH) RTO_R16(OP_FFBH) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 7) asm volatile(RTO_R16(OP_MED3) RTO_R16(OP_MED3) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 8) asm volatile(RTO_R16(OP_BFE) RTO_R16(OP_BFE) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 9) asm volatile(RTO_R16(OP_MAX) RTO_R16(OP_MAX) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 10) asm volatile(RTO_R16(OP_CMPSEL) : RTO_REGS16 : "v"(k1), "v"(k0) : "vcc");
+        if constexpr (BK == 11) asm volatile(RTO_R8(OP_PKFMA) RTO_R8(OP_PKFMA) RTO_R8(OP_PKFMA) RTO_R8(OP_PKFMA) : RTO_REGS8 : "v"(dk1), "v"(dk0));
+        if constexpr (BK == 12) asm volatile(RTO_R8(OP_PKMUL) RTO_R8(OP_PKMUL) RTO_R8(OP_PKMUL) RTO_R8(OP_PKMUL) : RTO_REGS8 : "v"(dk1), "v"(dk0));
+        if constexpr (BK == 13) asm volatile(RTO_R8(OP_FMA64) RTO_R8(OP_FMA64) RTO_R8(OP_FMA64) RTO_R8(OP_FMA64) : RTO_REGS8 : "v"(dk1), "v"(dk0));
+        if constexpr (BK == 14)  // the traversal loop's mix: float mul / fract / max / min / med3 / cvt, integer xor / or / ffbh / bfe / shift-or / add
             asm volatile(
                 "v_mul_f32 %0, %0, %16\nv_fract_f32 %1, %1\nv_max_f32 %2, %2, %16\nv_min_f32 %3, %3, %17\n"
                 "v_cvt_u32_f32 %4, %4\nv_xor_b32 %5, %5, %16\nv_or_b32 %6, %6, %17\nv_ffbh_u32 %7, %7\n"
@@ -324,65 +332,66 @@ __global__ void __launch_bounds__(256) valu_probe_kernel(int iters, float k0, fl
                 "v_med3_f32 %8, %8, %16, %17\nv_bfe_u32 %9, %9, 3, 1\nv_lshl_or_b32 %10, %10, 1, %16\nv_add_u32 %11, %11, %16\n"
                 "v_mul_f32 %12, %12, %17\nv_sub_u32 %13, %13, %16\nv_lshlrev_b32 %14, 1, %14\nv_add_f32 %15, %15, %16\n"
                 : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 15) asm volatile(RTO_R16(OP_FMA_SALU) RTO_R16(OP_FMA_SALU) : RTO_REGS16 : "v"(k1), "v"(k0) : "s20", "scc");
-        if constexpr (KIND == 16) asm volatile(RTO_R16(OP_MOV) RTO_R16(OP_MOV) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 17) asm volatile(RTO_R16(OP_RCP) RTO_R16(OP_RCP) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 18) asm volatile(RTO_R16(OP_DEP) RTO_R16(OP_DEP) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 19) asm volatile(RTO_R16(OP_XOR) RTO_R16(OP_XOR) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 20) asm volatile(RTO_R16(OP_AND) RTO_R16(OP_AND) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 21) asm volatile(RTO_R16(OP_OR) RTO_R16(OP_OR) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 22) asm volatile(RTO_R16(OP_LSHLREV) RTO_R16(OP_LSHLREV) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 23) asm volatile(RTO_R16(OP_LSHRREV) RTO_R16(OP_LSHRREV) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 24) asm volatile(RTO_R16(OP_SUBU) RTO_R16(OP_SUBU) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 25) asm volatile(RTO_R16(OP_MIN) RTO_R16(OP_MIN) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 26) asm volatile(RTO_R16(OP_MAXU) RTO_R16(OP_MAXU) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 27) asm volatile(RTO_R16(OP_MINU) RTO_R16(OP_MINU) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 28) asm volatile(RTO_R16(OP_ADDF) RTO_R16(OP_ADDF) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 29) asm volatile(RTO_R16(OP_SUBF) RTO_R16(OP_SUBF) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 30) asm volatile(RTO_R16(OP_FMAC) RTO_R16(OP_FMAC) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 31) asm volatile(RTO_R16(OP_CNDMASK) RTO_R16(OP_CNDMASK) : RTO_REGS16 : "v"(k1), "v"(k0) : "vcc");
-        if constexpr (KIND == 32) asm volatile(RTO_R16(OP_CMP) RTO_R16(OP_CMP) : RTO_REGS16 : "v"(k1), "v"(k0) : "vcc");
-        if constexpr (KIND == 33) asm volatile(RTO_R16(OP_CMPS) RTO_R16(OP_CMPS) : RTO_REGS16 : "v"(k1), "v"(k0) : "s20","s21");
-        if constexpr (KIND == 34) asm volatile(RTO_R16(OP_CMPU) RTO_R16(OP_CMPU) : RTO_REGS16 : "v"(k1), "v"(k0) : "vcc");
-        if constexpr (KIND == 35) asm volatile(RTO_R16(OP_MADU24) RTO_R16(OP_MADU24) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 36) asm volatile(RTO_R16(OP_MULU24) RTO_R16(OP_MULU24) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 37) asm volatile(RTO_R16(OP_MULLO) RTO_R16(OP_MULLO) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 38) asm volatile(RTO_R16(OP_ADD3) RTO_R16(OP_ADD3) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 39) asm volatile(RTO_R16(OP_LSHLADD) RTO_R16(OP_LSHLADD) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 40) asm volatile(RTO_R16(OP_ANDOR) RTO_R16(OP_ANDOR) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 41) asm volatile(RTO_R16(OP_OR3) RTO_R16(OP_OR3) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 42) asm volatile(RTO_R16(OP_XAD) RTO_R16(OP_XAD) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 43) asm volatile(RTO_R16(OP_ALIGNBIT) RTO_R16(OP_ALIGNBIT) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 44) asm volatile(RTO_R16(OP_PERM) RTO_R16(OP_PERM) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 45) asm volatile(RTO_R16(OP_CVTFU) RTO_R16(OP_CVTFU) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 46) asm volatile(RTO_R16(OP_CVTF16) RTO_R16(OP_CVTF16) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 47) asm volatile(RTO_R16(OP_FLOOR) RTO_R16(OP_FLOOR) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 48) asm volatile(RTO_R16(OP_TRUNC) RTO_R16(OP_TRUNC) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 49) asm volatile(RTO_R16(OP_EXP) RTO_R16(OP_EXP) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 50) asm volatile(RTO_R16(OP_LDEXP) RTO_R16(OP_LDEXP) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 51) asm volatile(RTO_R16(OP_MAX3) RTO_R16(OP_MAX3) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 52) asm volatile(RTO_R16(OP_MIN3) RTO_R16(OP_MIN3) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 53) asm volatile(RTO_R16(OP_MADF) RTO_R16(OP_MADF) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 54) asm volatile(RTO_R16(OP_FMA_LIT) RTO_R16(OP_FMA_LIT) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 55) asm volatile(RTO_R16(OP_MUL_SGPR) RTO_R16(OP_MUL_SGPR) : RTO_REGS16 : "v"(k1), "v"(k0) : "s20");
-        if constexpr (KIND == 56) asm volatile(RTO_R16(OP_READLANE) RTO_R16(OP_READLANE) : RTO_REGS16 : "v"(k1), "v"(k0) : "s20");
-        if constexpr (KIND == 57) asm volatile(RTO_R16(OP_READFIRST) RTO_R16(OP_READFIRST) : RTO_REGS16 : "v"(k1), "v"(k0) : "s20");
-        if constexpr (KIND == 58) asm volatile(RTO_R16(OP_DPP) RTO_R16(OP_DPP) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 59) asm volatile(RTO_R16(OP_SDWA) RTO_R16(OP_SDWA) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 60) asm volatile(RTO_R16(OP_MBCNT) RTO_R16(OP_MBCNT) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 61) asm volatile(RTO_R16(OP_BFI) RTO_R16(OP_BFI) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 62) asm volatile(RTO_R16(OP_SALU) RTO_R16(OP_SALU) : RTO_REGS16 : "v"(k1), "v"(k0) : "s20","scc");
-        if constexpr (KIND == 63) asm volatile(RTO_R16(OP_SALU64) RTO_R16(OP_SALU64) : RTO_REGS16 : "v"(k1), "v"(k0) : "s20","s21","scc");
-        if constexpr (KIND == 64) asm volatile(RTO_R16(OP_SNOP) RTO_R16(OP_SNOP) : RTO_REGS16 : "v"(k1), "v"(k0));
-        if constexpr (KIND == 65) asm volatile(RTO_R16(OP_FMA_SALU64) RTO_R16(OP_FMA_SALU64) : RTO_REGS16 : "v"(k1), "v"(k0) : "s20","s21","scc");
-        if constexpr (KIND == 66) {
+        if constexpr (BK == 15) asm volatile(RTO_R16(OP_FMA_SALU) RTO_R16(OP_FMA_SALU) : RTO_REGS16 : "v"(k1), "v"(k0) : "s20", "scc");
+        if constexpr (BK == 16) asm volatile(RTO_R16(OP_MOV) RTO_R16(OP_MOV) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 17) asm volatile(RTO_R16(OP_RCP) RTO_R16(OP_RCP) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 18) asm volatile(RTO_R16(OP_DEP) RTO_R16(OP_DEP) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 19) asm volatile(RTO_R16(OP_XOR) RTO_R16(OP_XOR) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 20) asm volatile(RTO_R16(OP_AND) RTO_R16(OP_AND) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 21) asm volatile(RTO_R16(OP_OR) RTO_R16(OP_OR) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 22) asm volatile(RTO_R16(OP_LSHLREV) RTO_R16(OP_LSHLREV) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 23) asm volatile(RTO_R16(OP_LSHRREV) RTO_R16(OP_LSHRREV) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 24) asm volatile(RTO_R16(OP_SUBU) RTO_R16(OP_SUBU) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 25) asm volatile(RTO_R16(OP_MIN) RTO_R16(OP_MIN) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 26) asm volatile(RTO_R16(OP_MAXU) RTO_R16(OP_MAXU) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 27) asm volatile(RTO_R16(OP_MINU) RTO_R16(OP_MINU) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 28) asm volatile(RTO_R16(OP_ADDF) RTO_R16(OP_ADDF) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 29) asm volatile(RTO_R16(OP_SUBF) RTO_R16(OP_SUBF) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 30) asm volatile(RTO_R16(OP_FMAC) RTO_R16(OP_FMAC) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 31) asm volatile(RTO_R16(OP_CNDMASK) RTO_R16(OP_CNDMASK) : RTO_REGS16 : "v"(k1), "v"(k0) : "vcc");
+        if constexpr (BK == 32) asm volatile(RTO_R16(OP_CMP) RTO_R16(OP_CMP) : RTO_REGS16 : "v"(k1), "v"(k0) : "vcc");
+        if constexpr (BK == 33) asm volatile(RTO_R16(OP_CMPS) RTO_R16(OP_CMPS) : RTO_REGS16 : "v"(k1), "v"(k0) : "s20","s21");
+        if constexpr (BK == 34) asm volatile(RTO_R16(OP_CMPU) RTO_R16(OP_CMPU) : RTO_REGS16 : "v"(k1), "v"(k0) : "vcc");
+        if constexpr (BK == 35) asm volatile(RTO_R16(OP_MADU24) RTO_R16(OP_MADU24) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 36) asm volatile(RTO_R16(OP_MULU24) RTO_R16(OP_MULU24) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 37) asm volatile(RTO_R16(OP_MULLO) RTO_R16(OP_MULLO) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 38) asm volatile(RTO_R16(OP_ADD3) RTO_R16(OP_ADD3) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 39) asm volatile(RTO_R16(OP_LSHLADD) RTO_R16(OP_LSHLADD) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 40) asm volatile(RTO_R16(OP_ANDOR) RTO_R16(OP_ANDOR) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 41) asm volatile(RTO_R16(OP_OR3) RTO_R16(OP_OR3) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 42) asm volatile(RTO_R16(OP_XAD) RTO_R16(OP_XAD) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 43) asm volatile(RTO_R16(OP_ALIGNBIT) RTO_R16(OP_ALIGNBIT) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 44) asm volatile(RTO_R16(OP_PERM) RTO_R16(OP_PERM) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 45) asm volatile(RTO_R16(OP_CVTFU) RTO_R16(OP_CVTFU) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 46) asm volatile(RTO_R16(OP_CVTF16) RTO_R16(OP_CVTF16) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 47) asm volatile(RTO_R16(OP_FLOOR) RTO_R16(OP_FLOOR) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 48) asm volatile(RTO_R16(OP_TRUNC) RTO_R16(OP_TRUNC) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 49) asm volatile(RTO_R16(OP_EXP) RTO_R16(OP_EXP) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 50) asm volatile(RTO_R16(OP_LDEXP) RTO_R16(OP_LDEXP) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 51) asm volatile(RTO_R16(OP_MAX3) RTO_R16(OP_MAX3) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 52) asm volatile(RTO_R16(OP_MIN3) RTO_R16(OP_MIN3) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 53) asm volatile(RTO_R16(OP_MADF) RTO_R16(OP_MADF) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 54) asm volatile(RTO_R16(OP_FMA_LIT) RTO_R16(OP_FMA_LIT) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 55) asm volatile(RTO_R16(OP_MUL_SGPR) RTO_R16(OP_MUL_SGPR) : RTO_REGS16 : "v"(k1), "v"(k0) : "s20");
+        if constexpr (BK == 56) asm volatile(RTO_R16(OP_READLANE) RTO_R16(OP_READLANE) : RTO_REGS16 : "v"(k1), "v"(k0) : "s20");
+        if constexpr (BK == 57) asm volatile(RTO_R16(OP_READFIRST) RTO_R16(OP_READFIRST) : RTO_REGS16 : "v"(k1), "v"(k0) : "s20");
+        if constexpr (BK == 58) asm volatile(RTO_R16(OP_DPP) RTO_R16(OP_DPP) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 59) asm volatile(RTO_R16(OP_SDWA) RTO_R16(OP_SDWA) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 60) asm volatile(RTO_R16(OP_MBCNT) RTO_R16(OP_MBCNT) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 61) asm volatile(RTO_R16(OP_BFI) RTO_R16(OP_BFI) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 62) asm volatile(RTO_R16(OP_SALU) RTO_R16(OP_SALU) : RTO_REGS16 : "v"(k1), "v"(k0) : "s20","scc");
+        if constexpr (BK == 63) asm volatile(RTO_R16(OP_SALU64) RTO_R16(OP_SALU64) : RTO_REGS16 : "v"(k1), "v"(k0) : "s20","s21","scc");
+        if constexpr (BK == 64) asm volatile(RTO_R16(OP_SNOP) RTO_R16(OP_SNOP) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 65) asm volatile(RTO_R16(OP_FMA_SALU64) RTO_R16(OP_FMA_SALU64) : RTO_REGS16 : "v"(k1), "v"(k0) : "s20","s21","scc");
+        if constexpr (BK == 66) {
             asm volatile(RTO_R16(OP_LDSR) RTO_R16(OP_LDSR) "s_waitcnt lgkmcnt(0)\n" : RTO_REGS16 : "v"(k1), "v"(k0), "v"(lds_addr) : "memory");
         }
-        if constexpr (KIND == 67) {
+        if constexpr (BK == 67) {
             asm volatile(RTO_R16(OP_LDSW) RTO_R16(OP_LDSW) "s_waitcnt lgkmcnt(0)\n" : RTO_REGS16 : "v"(k1), "v"(k0), "v"(lds_addr) : "memory");
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if constexpr (kExec != ~0ull) asm volatile("s_mov_b64 exec, -1");
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += a[i];
@@ -470,6 +479,14 @@ const ValuKind kValuKinds[] = {
     {"v_fma_f32 alternating with s_and_b64", 32, valu_probe_kernel<65>},
     {"ds_read_b32 x32 + s_waitcnt (no VALU)", 0, valu_probe_kernel<66>},
     {"ds_write_b32 x32 + s_waitcnt (no VALU)", 0, valu_probe_kernel<67>},
+    {"v_fma_f32, lanes 0-31 only", 32, valu_probe_kernel<68>},
+    {"v_fma_f32, lanes 0-15 only", 32, valu_probe_kernel<69>},
+    {"v_lshl_or_b32, lanes 0-31 only", 32, valu_probe_kernel<70>},
+    {"v_lshl_or_b32, lanes 0-15 only", 32, valu_probe_kernel<71>},
+    {"v_lshl_or_b32, even lanes only", 32, valu_probe_kernel<72>},
+    {"traversal mix, lanes 0-31 only", 32, valu_probe_kernel<73>},
+    {"traversal mix, lanes 0-15 only", 32, valu_probe_kernel<74>},
+    {"traversal mix, lanes 0-15 and 32-47 only", 32, valu_probe_kernel<75>},
 };
 constexpr int kNumValuKinds = (int)(sizeof(kValuKinds) / sizeof(kValuKinds[0]));
 

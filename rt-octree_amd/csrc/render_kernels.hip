@@ -124,6 +124,12 @@ RTO_DEV bool ray_enter(const TreeDev& tree, const OptDev& opt, float* dir, const
 // finite x (the sign of a zero result may differ, which no later operation can observe: the
 // fixed-point conversion, fract * invdir and the sums that follow give the same numbers)
 RTO_DEV float clamp_unit(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f - 1e-6f); }
+// The batched kernels keep a ray's position SCALED by 2^24 (kPos24): cen and dir are multiplied by 2^24 once, at the ray's
+// set-up, and cen24 + t * dir24 is then 2^24 times cen + t * dir bit for bit (a power of two commutes with every rounding),
+// so the fixed-point coordinates are a bare float -> integer conversion of the clamped sum -- no multiply per march step --
+// and the leaf-local point frac(pos * 2^(level + 1)) is frac(pos24 * 2^(level - 23)).
+constexpr float kPos24 = 16777216.f;
+RTO_DEV float clamp_unit24(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, (1.f - 1e-6f) * kPos24); }
 
 // _dda_unit rt_core.cuh:38-51
 RTO_DEV float dda_unit(const float* p, const float* invdir) {
@@ -766,7 +772,7 @@ __global__ void __launch_bounds__(256, SPP <= 8 ? RTO_FAST_WPS : 4) render_fast(
                     }
                 }
                 (void)have_w;
-                lvl = (int)((w >> 16) & 31u);  // a leaf word of the wide image carries its level
+                lvl = (int)((w >> kWideLevelShift) & 31u);  // a leaf word of the wide image carries its level
             } else {
             if (lvl < G) {
                 // restart above the shortcut levels: ONE 8-byte lookup replaces the walk over node levels
@@ -922,7 +928,7 @@ __global__ void __launch_bounds__(256, SPP <= 8 ? RTO_FAST_WPS : 4) render_fast(
 // to the hand-off buffer)
 struct RayState {
     float cen[3], dir[3], invdir[3];
-    float pos[3];  // clamp(cen + t * dir, 0, 1 - 1e-6): the point the next march step starts from
+    float pos[3];  // 2^24 * clamp(cen + t * dir, 0, 1 - 1e-6): the point the next march step starts from (scaled: kPos24)
     float delta_scale, t, tmax, src, cur;      // cur = next threshold to cross (dst[spp])
     uint32_t spp;
     uint32_t pix, piy, piz;
@@ -1265,7 +1271,10 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     extern __shared__ uint32_t s_mem[];
     const int tid = threadIdx.x;
     uint32_t* stack = s_mem + tid;  // [level - G][256]
-    const int stack_levels = tree.max_depth + 1 - tree.top_levels;  // levels top_levels.. only
+    // levels top_levels.. only.  STACK == 1 (ancestor stack in a register): two rows all the same -- they hold a ray's two
+    // hand-off offsets (rs.hoff, rs.hnext: written at the set-up, read at the flush, dead weight in the march loop whose
+    // 64-register budget the restart's constants need)
+    const int stack_levels = STACK == 1 ? 2 : tree.max_depth + 1 - tree.top_levels;
     float* s_dst = reinterpret_cast<float*>(s_mem + (size_t)stack_levels * 256) + tid;
     // the cameras of the batch: {fx, fy, transform[12]} per frame = the head of a FrameDesc (56 of its 96 bytes: at 100 frames
     // per launch the table then leaves room for 8 workgroups per CU)
@@ -1337,13 +1346,17 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     constexpr bool regstack = STACK == 1, kStackInRegs = regstack;
     uint32_t g_vgpr = (uint32_t)tree.top_levels;  // (rto_march_leaf.inc: the restart's `wb` select)
     asm volatile("" : "+v"(g_vgpr));
-    uint32_t woff_pair0 = 22u - (uint32_t)tree.top_levels;  // bit offset of the first pair below the grid (one scalar operand)
-    asm volatile("" : "+s"(woff_pair0));
+    // (the restart's selects, rto_march_leaf.inc: bit offsets of the grid and of the first pair below it, in VGPRs; the
+    //  coordinate difference from which a ray is back at the grid, in an SGPR)
+    uint32_t woff_grid_v = 24u - (uint32_t)tree.top_levels, woff_pair0_v = 22u - (uint32_t)tree.top_levels;
+    uint32_t tgrid = 1u << (24 - tree.top_levels);
+    asm volatile("" : "+v"(woff_grid_v), "+v"(woff_pair0_v), "+s"(tgrid));
 #ifdef RTO_HITS_DIRECT
     constexpr bool kHitsDirect = true;
 #else
     constexpr bool kHitsDirect = false;
 #endif
+    constexpr bool kOffsInLds = STACK == 1 && !kHitsDirect;
     RayState rs;
     // a lane marches a ray while rs.t < rs.tmax: that comparison IS the lane's state (an ended ray has t >= tmax or
     // tmax = -1), so the wave-level count of marching lanes is the ballot of one v_cmp instead of a loop-carried flag
@@ -1396,7 +1409,13 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                 const uint32_t first = res_next;
                 res_next += take;
 #ifndef RTO_HITS_DIRECT
-                if (idle && rs.nh) flush_hits<SPP, WIDE>(rs, tree, hits, s_dst, hstride, !tree.rec_by_entry);  // the ended ray's hit list leaves in one go
+                if (idle && rs.nh) {  // the ended ray's hit list leaves in one go
+                    if constexpr (kOffsInLds) {
+                        rs.hoff = stack[0];
+                        rs.hnext = stack[256];
+                    }
+                    flush_hits<SPP, WIDE>(rs, tree, hits, s_dst, hstride, !tree.rec_by_entry);
+                }
 #endif
                 if (idle) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32),
@@ -1441,12 +1460,23 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                             // buffer, where the ray's hit list will overwrite them)
                             rs.cur = __uint_as_float(hits[rs.hoff]);
                             const uint32_t* tp = hits + rs.hnext;
+                            if constexpr (kOffsInLds) {  // (parked until the ray's flush)
+                                stack[0] = rs.hoff;
+                                stack[256] = rs.hnext;
+                            }
 #pragma unroll
                             for (int i = 1; i < SPP; ++i) s_dst[i * 256] = __uint_as_float(tp[(uint32_t)(i - 1) * hstride]);
                             s_dst[SPP * 256] = 3.402823466e+38f;
                             rs.spp = 0;
                             rs.src = 0;
                             rs.t = tmin;
+                            float k24 = kPos24;  // (an SGPR operand: as a literal the compiler parks it in a VGPR pair across the kernel)
+                            asm volatile("" : "+s"(k24));
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {  // (from here on the ray's origin and direction are the scaled ones: kPos24)
+                                rs.cen[i] *= k24;
+                                rs.dir[i] *= k24;
+                            }
                             rs.cxy.x = rs.cen[0];
                             rs.cxy.y = rs.cen[1];
 #pragma unroll
@@ -1455,10 +1485,10 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                             rs.prev_lvl = 0;
                             {  // locate the first position: fixed-point coordinates + first node
 #pragma unroll
-                                for (int i = 0; i < 3; ++i) rs.pos[i] = clamp_unit(rs.cen[i] + rs.t * rs.dir[i]);
-                                rs.pix = (uint32_t)(rs.pos[0] * 16777216.f);
-                                rs.piy = (uint32_t)(rs.pos[1] * 16777216.f);
-                                rs.piz = (uint32_t)(rs.pos[2] * 16777216.f);
+                                for (int i = 0; i < 3; ++i) rs.pos[i] = clamp_unit24(rs.cen[i] + rs.t * rs.dir[i]);
+                                rs.pix = (uint32_t)rs.pos[0];
+                                rs.piy = (uint32_t)rs.pos[1];
+                                rs.piz = (uint32_t)rs.pos[2];
                                 rs.node = WIDE ? 0u : (G > 0 ? kGridNext : 0u);
                                 rs.woff = 24u - (uint32_t)G;
                                 rs.wb = (uint32_t)G;
@@ -1506,10 +1536,10 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                         const uint32_t sg = (hsh & 0x600u) ? 0u : 0x4D00u;
                         if (rs.node == 0u) {
                             const uint32_t glv = 2u + (hsh >> 30);
-                            w = (glv == 5u && (hsh & 0x100u)) ? ((hsh >> 8) & 0xffffu) | 1u : (kLeafTag | glv << 16 | sg);
+                            w = (glv == 5u && (hsh & 0x100u)) ? ((hsh >> 8) & 0xffffu) | 1u : (kLeafTag | glv << kWideLevelShift | sg);
                         } else {  // two pairs below the grid (levels G .. G + 3), leaves at either level of a pair
                             const uint32_t lv = 22u - rs.woff + ((hsh >> 27) & 1u);
-                            w = (rs.woff == 22u - (uint32_t)G && (hsh >> 29) < 5u) ? ((hsh >> 8) & 0xffffu) | 1u : (kLeafTag | lv << 16 | sg);
+                            w = (rs.woff == 22u - (uint32_t)G && (hsh >> 29) < 5u) ? ((hsh >> 8) & 0xffffu) | 1u : (kLeafTag | lv << kWideLevelShift | sg);
                         }
                     }
 #else
@@ -1655,7 +1685,13 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
         } while (n_active > exit_at);
     }
 #ifndef RTO_HITS_DIRECT
-    if (rs.nh) flush_hits<SPP, WIDE>(rs, tree, hits, s_dst, hstride, !tree.rec_by_entry);  // rays that ended after the last refill round
+    if (rs.nh) {  // rays that ended after the last refill round
+        if constexpr (kOffsInLds) {
+            rs.hoff = stack[0];
+            rs.hnext = stack[256];
+        }
+        flush_hits<SPP, WIDE>(rs, tree, hits, s_dst, hstride, !tree.rec_by_entry);
+    }
 #endif
 #ifdef RTO_DBG_COUNTERS
 #pragma unroll
@@ -1701,7 +1737,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist_res(const TreeDev tre
     uint32_t stk0 = 0u, stk1 = 0u;
     const bool regstack = (tree.max_depth - G + 1) / 2 <= 2;  // (wave-uniform) see render_persist
     constexpr bool kStackInRegs = false;                         // (not a compile-time fact here: rto_march_leaf.inc branches)
-    constexpr uint32_t g_vgpr = 0u, woff_pair0 = 0u;             // (named by the discarded branch of rto_march_leaf.inc)
+    constexpr uint32_t g_vgpr = 0u, woff_grid_v = 0u, woff_pair0_v = 0u, tgrid = 0u;  // (named by the discarded branch of rto_march_leaf.inc)
     const int stack_rows = regstack ? 0 : tree.max_depth + 1 - G;
     float* const s_dst = reinterpret_cast<float*>(s_mem) + tid;
     uint32_t* const stack = s_mem + kStackRow * 256 + tid;
@@ -1915,15 +1951,22 @@ __global__ void __launch_bounds__(256, WPS) render_persist_res(const TreeDev tre
                     }
                     rs.spp = 0;
                     rs.src = 0;
+                    float k24 = kPos24;  // (an SGPR operand, see render_persist)
+                    asm volatile("" : "+s"(k24));
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {  // (the march loop works on the scaled origin and direction: kPos24)
+                        rs.cen[i] *= k24;
+                        rs.dir[i] *= k24;
+                    }
                     rs.cxy.x = rs.cen[0];
                     rs.cxy.y = rs.cen[1];
 #pragma unroll
                     for (int i = 0; i < 3; ++i) rs.exit_add[i] = rs.invdir[i] > 0.f ? rs.invdir[i] : 0.f;
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) rs.pos[i] = clamp_unit(rs.cen[i] + rs.t * rs.dir[i]);
-                    rs.pix = (uint32_t)(rs.pos[0] * 16777216.f);
-                    rs.piy = (uint32_t)(rs.pos[1] * 16777216.f);
-                    rs.piz = (uint32_t)(rs.pos[2] * 16777216.f);
+                    for (int i = 0; i < 3; ++i) rs.pos[i] = clamp_unit24(rs.cen[i] + rs.t * rs.dir[i]);
+                    rs.pix = (uint32_t)rs.pos[0];
+                    rs.piy = (uint32_t)rs.pos[1];
+                    rs.piz = (uint32_t)rs.pos[2];
                     rs.node = 0u;
                     rs.woff = 24u - (uint32_t)G;
                     rs.wb = (uint32_t)G;
@@ -2475,7 +2518,7 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
     //  stack lives in registers, 10 dwords per lane of ray records, 13 with the NDC warp)
     const bool res_regstack = (tree.max_depth - tree.top_levels + 1) / 2 <= 2;
     const size_t lds = RES ? (size_t)(SPP + 2 + 10 + (res_regstack ? 0 : tree.max_depth + 1 - tree.top_levels) + (tree.ndc_width > 0 ? 3 : 0)) * 256 * sizeof(uint32_t)
-                           : (size_t)(tree.max_depth + 1 - tree.top_levels + SPP + 1) * 256 * sizeof(uint32_t) + sizeof(float) * kCamFloats * (size_t)fb_in.n;
+                           : (size_t)((WIDE && res_regstack ? 2 : tree.max_depth + 1 - tree.top_levels) + SPP + 1) * 256 * sizeof(uint32_t) + sizeof(float) * kCamFloats * (size_t)fb_in.n;
     auto kern = [regs = res_regstack] {
         (void)regs;
         if constexpr (RES)

@@ -373,7 +373,7 @@ void relay_tree(const std::vector<int64_t>& order, const int32_t* child, const u
 // The persistent kernel visits one node per loop iteration; 0.65 of its 1.65 visits per march step are descents through
 // internal nodes.  A wide node merges an octree node at level L = G + 2p (G = top-grid levels) with its eight children:
 // 64 words, indexed by TWO bits per axis of the sample point, each holding what the two-level walk below that node ends in --
-//   a leaf at level L (replicated into its 8 entries) or L + 1:  kLeafTag | level << 16 | sigma fp16   (the level rides in the
+//   a leaf at level L (replicated into its 8 entries) or L + 1:  kLeafTag | level << 23 (kWideLevelShift) | sigma fp16   (the level rides in the
 //                                                                 word because the entry no longer says which it was)
 //   an internal node at level L + 2:                              the absolute index of ITS wide node
 // so a walk costs one load per TWO levels.  Entry layout inside a wide node: (x2 << 4) | (y2 << 2) | z2 with x2 = the two
@@ -421,7 +421,7 @@ bool build_wide_image(const int32_t* child, int64_t capacity, int max_depth, int
     out.grid_nodes = (uint32_t)grid_nodes;
     out.widew.assign((size_t)(grid_nodes + n_wide) * 64, rto::kLeafTag);  // (padding reads as an empty leaf of level 0; never indexed)
     out.worig.assign((size_t)n_wide, 0u);
-    auto leafw = [&](int level, int64_t slot) { return rto::kLeafTag | ((uint32_t)level << 16) | (uint32_t)sigma_bits(slot); };
+    auto leafw = [&](int level, int64_t slot) { return rto::kLeafTag | ((uint32_t)level << rto::kWideLevelShift) | (uint32_t)sigma_bits(slot); };
     auto entry = [](int a, int b) {  // child digits (x most significant) at level L and L + 1 -> position in the wide node
         const int x2 = ((a >> 2) & 1) << 1 | ((b >> 2) & 1), y2 = ((a >> 1) & 1) << 1 | ((b >> 1) & 1), z2 = (a & 1) << 1 | (b & 1);
         return x2 << 4 | y2 << 2 | z2;
@@ -1332,7 +1332,7 @@ int rto_wide_image_probe(const int32_t* child, const uint16_t* sigma_bits, int64
             const int64_t N = wi.worig[wn];
             slot = nodew_leaf(N * 8 + a) ? N * 8 + a : (N + child[N * 8 + a]) * 8 + b;
         }
-        out_level[i] = (int32_t)((w >> 16) & 31u);
+        out_level[i] = (int32_t)((w >> rto::kWideLevelShift) & 31u);
         out_slot[i] = slot;
         out_sigma[i] = (uint16_t)(w & 0xffffu);
     }

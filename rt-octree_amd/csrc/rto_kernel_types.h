@@ -13,6 +13,10 @@ namespace rto {
 //   internal slot: the reference's child[] value (relative node offset, |v| < 2^30)
 //   leaf slot:     0x80000000 | fp16 bits of the slot's sigma  -> top two bits are 0b10
 constexpr uint32_t kLeafTag = 0x80000000u;
+// A leaf word of the TWO-LEVEL image also carries its leaf's level (< 32), at the bits a float's exponent field starts at:
+// the march step's 2^(level + c) factors are then one integer add / subtract on (word & kWideLevelMask) -- no field extract
+constexpr int kWideLevelShift = 23;
+constexpr uint32_t kWideLevelMask = 31u << kWideLevelShift;
 constexpr int kQueueChunk = 256;  // tile slots per workgroup of the queue compaction
 constexpr int kOccLevel = 7;  // finest cube of the culling cells: 2^-7 of the volume (6 pixels across at 800 x 800)
 constexpr uint32_t kNoRecord = 0xffffffffu;  // TreeDev::recidx entry of a slot without a coefficient record
@@ -50,7 +54,7 @@ struct TreeDev {
     int top_levels;
     // Two-level traversal image (rto_abi.cpp build_wide_image; nullptr: absent).  ONE array: entries [0, 8^G) are the top-grid
     // cells, padded to wide_grid_nodes nodes of 64; wide node k is node wide_grid_nodes + k.  Entry of a node: index
-    // (x2 << 4 | y2 << 2 | z2), two bits per axis; of the grid: (x << 2G | y << G | z).  A word: leaf = kLeafTag | level << 16 |
+    // (x2 << 4 | y2 << 2 | z2), two bits per axis; of the grid: (x << 2G | y << G | z).  A word: leaf = kLeafTag | level << kWideLevelShift |
     // sigma fp16, internal = the NODE NUMBER of the wide node below (two levels down; from the grid: the level-G node's).  An
     // entry's index is also the hit index of its leaf: wgslot[grid cell] / worig[wide node] translate it to the leaf's slot.
     const uint32_t* widew;

@@ -663,7 +663,11 @@ RTO_DEV uint32_t wide_entry_of(const TreeDev& tree, uint32_t ix, uint32_t iy, ui
 #ifndef RTO_FAST_WPS
 #define RTO_FAST_WPS 5
 #endif
-template <int SPP, bool STATS, bool WIDE>
+// STACK == 1 (two-level image, at most two pairs of levels below the grid; the launcher decides): the restart of render_persist's
+// register-stack form -- the node a step starts from is chosen by where the ray is and which coordinate bits changed
+// (rto_march_leaf.inc), positions are kept scaled by 2^24 (kPos24), the step's power-of-two factors come from the level bits of
+// the leaf word -- seven dependent instructions fewer on the chain a lone frame's longest rays wait for
+template <int SPP, bool STATS, bool WIDE, int STACK = 0>
 __global__ void __launch_bounds__(256, SPP <= 8 ? RTO_FAST_WPS : 4) render_fast(const TreeDev tree, const CamDev cam, const OptDev opt,
                                                     const Pcg32 rng_base, const PcgJumpEntry* __restrict__ jump,
                                                     const TileMap tm, const FrameOut fo) {
@@ -726,23 +730,71 @@ __global__ void __launch_bounds__(256, SPP <= 8 ? RTO_FAST_WPS : 4) render_fast(
         uint32_t stk0 = 0u, stk1 = 0u;
         const bool regstack = WIDE && (tree.max_depth - G + 1) / 2 <= 2;  // (uniform) pairs of levels below the grid
         const float exit_add[3] = {invdir[0] > 0.f ? invdir[0] : 0.f, invdir[1] > 0.f ? invdir[1] : 0.f, invdir[2] > 0.f ? invdir[2] : 0.f};
+        static_assert(STACK == 0 || (WIDE && !STATS), "the register-stack restart is for the two-level image");
+        // STACK == 1: the node / bit offset / bits per axis the NEXT step starts from (render_persist's rs.node, rs.woff, rs.wb)
+        uint32_t cnode = 0u, coff = 24u - (uint32_t)G, cb = (uint32_t)G;
+        const uint32_t tgrid = 1u << (24 - G);
+        if constexpr (STACK == 1) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {  // (kPos24)
+                cen[i] *= kPos24;
+                dir[i] *= kPos24;
+            }
+        }
 
         while (t < tmax) {
             // (round 5: the arithmetic forms of the batched kernel's march step -- one v_med3 per clamp, v_fract, the exit
             //  time as t1 + (invdir > 0 ? invdir : 0), no 1e4 start of the minimum: see rto_march_leaf.inc for why each is the
             //  same number -- a lone frame waits for the DEPENDENT chain of its longest ray, a third of which is this arithmetic:
             //  0.307 -> 0.295 ms per lone 800x800 SPP-6 frame, profiles/r5_w_ab_fast.txt)
-            const float pos[3] = {clamp_unit(cen[0] + t * dir[0]), clamp_unit(cen[1] + t * dir[1]), clamp_unit(cen[2] + t * dir[2])};
-            const uint32_t ix = (uint32_t)(pos[0] * 16777216.f);
-            const uint32_t iy = (uint32_t)(pos[1] * 16777216.f);
-            const uint32_t iz = (uint32_t)(pos[2] * 16777216.f);
+            float pos[3];
+            uint32_t ix, iy, iz;
+            if constexpr (STACK == 1) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) pos[i] = clamp_unit24(cen[i] + t * dir[i]);
+                ix = (uint32_t)pos[0];
+                iy = (uint32_t)pos[1];
+                iz = (uint32_t)pos[2];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) pos[i] = clamp_unit(cen[i] + t * dir[i]);
+                ix = (uint32_t)(pos[0] * 16777216.f);
+                iy = (uint32_t)(pos[1] * 16777216.f);
+                iz = (uint32_t)(pos[2] * 16777216.f);
+            }
             // levels whose child digit is unchanged since the previous step
             const uint32_t diff = (ix ^ pix) | (iy ^ piy) | (iz ^ piz);
-            int lvl = __clz((int)diff) - 8;
-            lvl = lvl < prev_lvl ? lvl : prev_lvl;
+            int lvl = 0;
+            if constexpr (STACK != 1) {
+                lvl = __clz((int)diff) - 8;
+                lvl = lvl < prev_lvl ? lvl : prev_lvl;
+            }
             uint32_t node, w, slot;
             bool have_w = false;
-            if constexpr (WIDE) {
+            if constexpr (STACK == 1) {
+                // (see rto_march_leaf.inc: the same node while the bits above its index bits are unchanged; back to the grid when a
+                //  bit at or above 24 - G differs; else, from the second pair, the first pair's node)
+                const bool stay = (diff >> (coff + cb)) == 0u, to_grid = diff >= tgrid;
+                node = to_grid ? 0u : (stay ? cnode : stk0);
+                uint32_t off = to_grid ? 24u - (uint32_t)G : (stay ? coff : 22u - (uint32_t)G);
+                uint32_t b = to_grid ? (uint32_t)G : cb;
+                for (;;) {
+                    slot = (node << b) | __builtin_amdgcn_ubfe(ix, off, b);
+                    slot = (slot << b) | __builtin_amdgcn_ubfe(iy, off, b);
+                    slot = (slot << b) | __builtin_amdgcn_ubfe(iz, off, b);
+                    w = *(const uint32_t*)((const char*)tree.widew + (uint32_t)(slot << 2));  // (< 2^29 entries: a 32-bit byte offset)
+                    if (nodew_is_leaf(w)) break;
+                    stk0 = off == 24u - (uint32_t)G ? w : stk0;  // (the first pair's node: the one ancestor a later step may need)
+                    node = w;  // the wide node two levels down
+                    off -= 2u;
+                    b = 2u;
+                }
+                cnode = node;
+                coff = off;
+                cb = b;
+                (void)have_w;
+                (void)stk1;
+            } else if constexpr (WIDE) {
                 // the two-level image (rto_abi.cpp build_wide_image; round 4): one load per TWO levels below the grid -- a lone
                 // frame waits for the dependent-load chains of its longest rays, and this shortens every one of them
                 // (node, off): (0, 24 - G) = the top grid, whose cells are indexed by G bits per axis; else the wide node of the
@@ -823,8 +875,15 @@ __global__ void __launch_bounds__(256, SPP <= 8 ? RTO_FAST_WPS : 4) render_fast(
 
             // cube_sz = 2^(lvl+1) and its reciprocal straight from exponent bits; x / 2^k == x * 2^-k
             // bit for bit (a pure exponent shift, or the same single rounding into the denormals)
-            const float cube_sz = __uint_as_float((uint32_t)(128 + lvl) << 23);
-            const float inv_cube = __uint_as_float((uint32_t)(126 - lvl) << 23);
+            float cube_sz, inv_cube;
+            if constexpr (STACK == 1) {  // (positions scaled by 2^24: 2^(level + 1 - 24); the level at the word's exponent bits)
+                const uint32_t lvl_bits = w & kWideLevelMask;
+                cube_sz = __uint_as_float(lvl_bits + ((uint32_t)(128 - 24) << 23));
+                inv_cube = __uint_as_float(((uint32_t)126 << 23) - lvl_bits);
+            } else {
+                cube_sz = __uint_as_float((uint32_t)(128 + lvl) << 23);
+                inv_cube = __uint_as_float((uint32_t)(126 - lvl) << 23);
+            }
             float ex[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) ex[i] = -__builtin_amdgcn_fractf(pos[i] * cube_sz) * invdir[i] + exit_add[i];
@@ -2459,7 +2518,10 @@ static hipError_t launch_spp(int kernel, const TreeDev& tree, const CamDev& cam,
         if (fo.stats)  // (the counting instantiation walks the one-level image: its units are defined on that walk)
             hipLaunchKernelGGL((render_fast<SPP, true, false>), grid, block, lds, stream, tree, cam, opt, rng, jump, tm, fo);
         else if (tree.widew)
-            hipLaunchKernelGGL((render_fast<SPP, false, true>), grid, block, lds, stream, tree, cam, opt, rng, jump, tm, fo);
+            if ((tree.max_depth - tree.top_levels + 1) / 2 <= 2)  // two pairs of levels below the grid at most
+                hipLaunchKernelGGL((render_fast<SPP, false, true, 1>), grid, block, lds, stream, tree, cam, opt, rng, jump, tm, fo);
+            else
+                hipLaunchKernelGGL((render_fast<SPP, false, true>), grid, block, lds, stream, tree, cam, opt, rng, jump, tm, fo);
         else
             hipLaunchKernelGGL((render_fast<SPP, false, false>), grid, block, lds, stream, tree, cam, opt, rng, jump, tm, fo);
     } else {

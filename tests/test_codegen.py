@@ -109,8 +109,9 @@ def test_the_traversal_kernels_private_segments_are_what_is_recorded_here():
         assert k1["occupancy"] == 8 and k1["scratch"] <= (40 if spp == 32 else 0), (spp, k1)
     r = res["_ZN3rto18render_persist_resILi6ELi24ELi7ELb0EEEvNS_7TreeDevENS_6OptDevENS_10FrameBatchEPyPjj"]
     assert r["occupancy"] == 7 and r["vgprs"] <= 72 and r["scratch"] == 0, r
-    fast = [v for n, v in res.items() if n.startswith("_ZN3rto11render_fastILi6ELb0ELb1EEE")]
-    assert len(fast) == 1 and fast[0]["occupancy"] == 5 and fast[0]["scratch"] == 0, fast
+    # the single-frame kernel on the two-level image: ancestor stack in LDS rows (0) / the register-stack restart (1)
+    fast = [v for n, v in res.items() if n.startswith("_ZN3rto11render_fastILi6ELb0ELb1ELi")]
+    assert len(fast) == 2 and all(f["occupancy"] == 5 and f["scratch"] == 0 for f in fast), fast
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")

@@ -129,3 +129,34 @@ def test_two_level_image_over_budget_walks_the_one_level_image():
     one.free()
     dt.free()
     dt_e.free()
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3, 4, 5, 6, 7, 8, -7, -8, -10, -11])
+def test_every_tree_depth_through_both_stack_forms(depth):
+    """late round 5: the restart of a march step by coordinate-difference thresholds (register-stack form: at most two pairs
+    of levels below the top grid) and the LDS-stack form beside it.  The grid spans min(depth - 1, 6) levels (none below
+    depth 3), so these depths cover: no grid at all, a grid with one half-filled pair below it, one pair, two pairs (the
+    benchmark's shape), three (LDS rows) -- batched and single-frame kernels against the oracle, bit for bit.  (Negative:
+    a deep narrow chain tree of that many levels, test_render_parity._chain_tree -- a full tree of depth 10 takes minutes to make.)"""
+    if depth < 0:
+        from test_render_parity import _chain_tree
+        tree = _chain_tree(-depth, seed=-depth, basis=9)
+    else:
+        tree = synth.make_tree(depth_limit=depth, basis_dim=9, seed=40 + depth, shell=2.0)
+    ht = orc.HostTree(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+    dt = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+    W, H, spp = 96, 72, 4
+    cams = [cameras(W, H, p)[1] for p in POSES[:3]]
+    jumps = [100 + i for i in range(3)]
+    got = batch_frames(dt, cams, spp, jumps)
+    for f in (0, 2):
+        want = oracle_frame(ht, cameras(W, H, POSES[f])[0], spp, frame=100 + f)
+        assert_bits_equal(got[f], want[0], "batched kernel, depth %d, frame %d" % (depth, f))
+    ctx = R.RenderContext(W, H)
+    ctx.set_kernel(R.KERNEL_FAST)
+    ctx.rng_seed()
+    ctx.rng_advance(102 << 32)
+    R.launch_renderer(dt, cams[2], R.RenderOptions(spp=spp, denoise=False), ctx)
+    assert_bits_equal(ctx.download_aux(), got[2], "single-frame kernel, depth %d" % depth)
+    ctx.free()
+    dt.free()

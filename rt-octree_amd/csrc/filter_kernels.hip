@@ -454,7 +454,11 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
 
     const int tid = threadIdx.x;
     const int tiles_x = (W + kFastW - 1) / kFastW;
-    const int tx_first = blockIdx.x * kFastStrip;
+    // the strip's length follows from the launch: ceil(tiles_x / gridDim.x) <= kFastStrip.  A batch of frames is launched with
+    // full strips (the prefetch pays); a LONE frame with as short ones as it takes to put a few workgroups on every CU -- 250
+    // workgroups of 5 tiles each left three quarters of the chip idle while each walked its strip (fast_strip_for)
+    const int strip = (tiles_x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int tx_first = blockIdx.x * strip;
     const int y0 = blockIdx.y * kFastH - L;
     const int64_t HW = (int64_t)H * W;
     weight += (int64_t)blockIdx.z * L * HW;  // (PACKED: 8 halves = 4 floats per pixel = L * HW floats per image as well)
@@ -472,8 +476,8 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
     if (cull.mask) {
 #pragma unroll
         for (int ts = 0; ts < kFastStrip; ++ts)
-            if (tx_first + ts < tiles_x && sees_only_background<SW, SH>(cull, (tx_first + ts) * kFastW - L, y0, H, W)) skip |= 1u << ts;
-        for (int ts = 0; ts < kFastStrip && tx_first + ts < tiles_x; ++ts)
+            if (ts < strip && tx_first + ts < tiles_x && sees_only_background<SW, SH>(cull, (tx_first + ts) * kFastW - L, y0, H, W)) skip |= 1u << ts;
+        for (int ts = 0; ts < strip && tx_first + ts < tiles_x; ++ts)
             if ((skip >> ts) & 1u) {
 #pragma unroll
                 for (int r = 0; r < kFastRows; ++r)
@@ -481,8 +485,8 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
             }
     }
     auto next_live = [&](int ts) {  // first tile >= ts of the strip that has to be computed (kFastStrip: none)
-        while (ts < kFastStrip && tx_first + ts < tiles_x && ((skip >> ts) & 1u)) ++ts;
-        return (ts < kFastStrip && tx_first + ts < tiles_x) ? ts : kFastStrip;
+        while (ts < strip && tx_first + ts < tiles_x && ((skip >> ts) & 1u)) ++ts;
+        return (ts < strip && tx_first + ts < tiles_x) ? ts : kFastStrip;
     };
 
     // what a tile's computation needs from memory, as it arrives: the staged noisy pixels, the guidance values of the staged
@@ -739,9 +743,18 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
     }
 }
 
+// tiles per workgroup of filter_fast: kFastStrip when that still gives every CU its 8 workgroups, else shorter strips
+static int fast_strip_for(int tiles_x, int tiles_y, int n) {
+    int s = kFastStrip;
+    while (s > 1 && (int64_t)((tiles_x + s - 1) / s) * tiles_y * n < 2048) --s;
+    return s;
+}
+
 hipError_t launch_filter_fast_packed(const void* packed_maps, int H, int W, int n, const float* img_in, float* img_out,
                                      const uint32_t* tile_mask, int mask_words, const float* fill_tile, hipStream_t stream) {
-    const dim3 grid(((W + kFastW - 1) / kFastW + kFastStrip - 1) / kFastStrip, (H + kFastH - 1) / kFastH, n), block(256);
+    const int tiles_x = (W + kFastW - 1) / kFastW, tiles_y = (H + kFastH - 1) / kFastH, strip = fast_strip_for(tiles_x, tiles_y, n);
+    // (grid.x such that ceil(tiles_x / grid.x) == the strip the kernel derives: ceil(tiles_x / strip) workgroups per tile row)
+    const dim3 grid((tiles_x + strip - 1) / strip, tiles_y, n), block(256);
     const size_t lds = (size_t)(2 * (kFastH + 8) * kFastRowStride) * sizeof(float4);  // P_l tile + window-row sums, parity-split rows
     FilterCull cull;
     cull.mask = tile_mask;
@@ -762,7 +775,9 @@ hipError_t launch_filter_fast_culled(const float* weight, const float* guidance,
                                      float* img_out, const uint32_t* tile_mask, int mask_words, const float* fill_tile,
                                      hipStream_t stream) {
     const FilterCull cull{tile_mask, mask_words, (W + 7) / 8, reinterpret_cast<const float4*>(fill_tile)};
-    const dim3 grid(((W + kFastW - 1) / kFastW + kFastStrip - 1) / kFastStrip, (H + kFastH - 1) / kFastH, n), block(256);
+    const int tiles_x = (W + kFastW - 1) / kFastW, tiles_y = (H + kFastH - 1) / kFastH, strip = fast_strip_for(tiles_x, tiles_y, n);
+    // (grid.x such that ceil(tiles_x / grid.x) == the strip the kernel derives: ceil(tiles_x / strip) workgroups per tile row)
+    const dim3 grid((tiles_x + strip - 1) / strip, tiles_y, n), block(256);
     const float4* in4 = reinterpret_cast<const float4*>(img_in);
     float4* out4 = reinterpret_cast<float4*>(img_out);
 #define RTO_FFAST(LL)                                                                                              \

@@ -160,3 +160,40 @@ def test_every_tree_depth_through_both_stack_forms(depth):
     assert_bits_equal(ctx.download_aux(), got[2], "single-frame kernel, depth %d" % depth)
     ctx.free()
     dt.free()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_two_pairs_below_the_grid_random_views(seed):
+    """the register-stack restart's one non-trivial move -- leaving the SECOND pair of levels for the first pair's node without
+    going back to the grid -- needs trees with two pairs below the grid (depth 9-10), which the fuzz scenes (depth <= 7) do not
+    have: deep narrow trees, random cameras outside, inside and grazing the box, batched and single-frame kernels against the oracle"""
+    from test_render_parity import _chain_tree
+    rs = np.random.RandomState(7000 + seed)
+    depth = int(rs.choice([9, 10]))
+    tree = _chain_tree(depth, seed=int(rs.randint(0, 64)), basis=int(rs.choice([4, 9])))
+    ht = orc.HostTree(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+    dt = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+    assert dt.max_depth == depth
+    W, H = int(rs.randint(24, 90)), int(rs.randint(24, 70))
+    spp = int(rs.choice([1, 4, 6, 8]))
+    ocams, cams = [], []
+    for _ in range(3):
+        r = rs.uniform(0.2, 4.0)
+        pos = rs.randn(3)
+        pos = pos / np.linalg.norm(pos) * r
+        oc, c = cameras(W, H, synth.look_at_c2w(pos, rs.uniform(-0.4, 0.4, 3)))
+        ocams.append(oc)
+        cams.append(c)
+    jumps = [5 + i for i in range(3)]
+    got = batch_frames(dt, cams, spp, jumps)
+    for f in range(3):
+        want = oracle_frame(ht, ocams[f], spp, frame=jumps[f])
+        assert_bits_equal(got[f], want[0], "batched kernel, depth %d, seed %d, frame %d" % (depth, seed, f))
+    ctx = R.RenderContext(W, H)
+    ctx.set_kernel(R.KERNEL_FAST)
+    ctx.rng_seed()
+    ctx.rng_advance(jumps[1] << 32)
+    R.launch_renderer(dt, cams[1], R.RenderOptions(spp=spp, denoise=False), ctx)
+    assert_bits_equal(ctx.download_aux(), got[1], "single-frame kernel, depth %d, seed %d" % (depth, seed))
+    ctx.free()
+    dt.free()

@@ -243,6 +243,9 @@ constexpr int kBlk = 32;
 #define OP_FMAC(i) "v_fmac_f32 %" #i ", %16, %17\n"
 #define OP_CNDMASK(i) "v_cndmask_b32 %" #i ", %" #i ", %16, vcc\n"
 #define OP_CMP(i) "v_cmp_lt_f32 vcc, %" #i ", %16\n"
+#define OP_CND_S(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %16, s[20:21]\n"
+#define OP_CND_FMA(i) "v_cndmask_b32 %" #i ", %" #i ", %16, vcc\nv_fma_f32 %" #i ", %" #i ", %16, %17\n"
+#define OP_CMP_3CND(i) "v_cmp_lt_f32 vcc, %" #i ", %16\nv_cndmask_b32 %" #i ", %" #i ", %17, vcc\nv_cndmask_b32 %" #i ", %" #i ", %16, vcc\nv_cndmask_b32 %" #i ", %" #i ", %17, vcc\n"
 #define OP_CMPS(i) "v_cmp_lt_f32 s[20:21], %" #i ", %16\n"
 #define OP_CMPU(i) "v_cmp_lt_u32 vcc, %" #i ", %16\n"
 #define OP_MADU24(i) "v_mad_u32_u24 %" #i ", %" #i ", %16, %17\n"
@@ -383,6 +386,9 @@ __global__ void __launch_bounds__(256) valu_probe_kernel(int iters, float k0, fl
         if constexpr (BK == 63) asm volatile(RTO_R16(OP_SALU64) RTO_R16(OP_SALU64) : RTO_REGS16 : "v"(k1), "v"(k0) : "s20","s21","scc");
         if constexpr (BK == 64) asm volatile(RTO_R16(OP_SNOP) RTO_R16(OP_SNOP) : RTO_REGS16 : "v"(k1), "v"(k0));
         if constexpr (BK == 65) asm volatile(RTO_R16(OP_FMA_SALU64) RTO_R16(OP_FMA_SALU64) : RTO_REGS16 : "v"(k1), "v"(k0) : "s20","s21","scc");
+        if constexpr (BK == 76) asm volatile(RTO_R16(OP_CND_S) RTO_R16(OP_CND_S) : RTO_REGS16 : "v"(k1), "v"(k0) : "s20", "s21");
+        if constexpr (BK == 77) asm volatile(RTO_R16(OP_CND_FMA) : RTO_REGS16 : "v"(k1), "v"(k0) : "vcc");
+        if constexpr (BK == 78) asm volatile(RTO_R8(OP_CMP_3CND) : RTO_REGS16 : "v"(k1), "v"(k0) : "vcc");
         if constexpr (BK == 66) {
             asm volatile(RTO_R16(OP_LDSR) RTO_R16(OP_LDSR) "s_waitcnt lgkmcnt(0)\n" : RTO_REGS16 : "v"(k1), "v"(k0), "v"(lds_addr) : "memory");
         }
@@ -487,6 +493,9 @@ const ValuKind kValuKinds[] = {
     {"traversal mix, lanes 0-31 only", 32, valu_probe_kernel<73>},
     {"traversal mix, lanes 0-15 only", 32, valu_probe_kernel<74>},
     {"traversal mix, lanes 0-15 and 32-47 only", 32, valu_probe_kernel<75>},
+    {"v_cndmask_b32_e64, condition in an SGPR pair", 32, valu_probe_kernel<76>},
+    {"v_cndmask_b32 (vcc) alternating with v_fma_f32", 32, valu_probe_kernel<77>},
+    {"v_cmp_lt_f32 -> vcc + three v_cndmask_b32", 32, valu_probe_kernel<78>},
 };
 constexpr int kNumValuKinds = (int)(sizeof(kValuKinds) / sizeof(kValuKinds[0]));
 

@@ -216,7 +216,10 @@ int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value);
  * on rto_ctx_noisy + rto_filtering* on the same image (the filter never reads the image's alpha, filtering.cu:186-199).
  * The denoised image is bit-identical to the full-output route's.  Single-frame launches, launches with denoise = 0 and
  * everything that reads the aux buffer (--write_buffer, rto_ctx_download_aux) need the full outputs: leave it off there.
- * rto_ctx_frames_are_lean: 1 when slots [first_slot, first_slot + n) were all written by a lean launch last. */
+ * The state is kept PER FRAME SLOT: a launch changes it only for the slots it writes (a single-frame launch into slot k of a
+ * lean batch leaves the other slots lean).  rto_ctx_frames_are_lean: 1 when slots [first_slot, first_slot + n) were all
+ * written by a lean launch last, 0 when none was, -1 for a mixed range -- which rto_denoise refuses (RTO_E_INVALID): denoise
+ * each run of slots by itself. */
 int rto_ctx_set_lean_outputs(rto_ctx* c, int on);
 int rto_ctx_frames_are_lean(const rto_ctx* c, int first_slot, int n);
 /* Per-kernel HIP-event timing of the batched path: when enabled, every rto_launch_renderer_batch
@@ -348,7 +351,7 @@ int rto_guidance_net_forward(const rto_guidance_net* net, void* stream, const fl
 #define RTO_NET_AUX_SQUARES_IMPLIED 1
 /* RTO_NET_INPUT_RGBA (round 5) -- `aux` is not an aux buffer but an interleaved image, device [n][H][W][4] fp32 = (r, g, b,
  * alpha): the values of aux planes 0..3 (volrend.cu:187-194), as a LEAN batched launch leaves them in the context's noisy
- * buffer (rto_ctx_set_tuning "lean_outputs").  Squares implied.  Bit-identical maps to the aux-buffer input. */
+ * buffer (rto_ctx_set_lean_outputs).  Squares implied.  Bit-identical maps to the aux-buffer input. */
 #define RTO_NET_INPUT_RGBA 2
 int rto_guidance_net_forward_ex(const rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W,
                                 float* weight_map, float* guidance_map, int flags);
@@ -431,6 +434,13 @@ int rto_probe_thresholds(uint32_t first_k, uint32_t count, float* host_out);
  * filter's fp32 exp (fn 2) -- the functions DESIGN.md "Math" defines in place of `__logf` / `__expf`
  * (rt_core.cuh:74,95,314; filtering.cu:191).  Lets a test sweep the whole float range against the oracle. */
 int rto_probe_math(int fn, uint32_t first_bits, uint32_t stride, uint32_t count, float* host_out);
+/* Test hook (round 6): the shading kernels evaluate `cnt / (1.f + expf(-t))` (rt_core.cuh:314-318) through a short form --
+ * the library's expf for |t| <= 87 in fused multiply-adds, the division as reciprocal + one exact-residual correction --
+ * that must return the float of the plain statement for every argument.  mode 0: the short sigmoid against the plain one
+ * for the floats t with bit patterns first_bits + i, i < count (<= 2^32), times every sample count cnt_lo .. cnt_hi
+ * (1 .. 32); mode 1: the short division cnt / d alone, for d = those floats (callers pass [1, 2^126)).  Both sides run on
+ * the device.  out3[0] = pairs that differ, out3[1] = the first of them (bits << 8 | cnt; ~0 if none), out3[2] = pairs compared. */
+int rto_probe_sigmoid(int mode, uint32_t first_bits, uint64_t count, int cnt_lo, int cnt_hi, uint64_t* out3);
 
 #ifdef __cplusplus
 }

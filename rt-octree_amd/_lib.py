@@ -126,6 +126,7 @@ SYMBOLS = {
     "rto_probe_valu_name": (C.c_char_p, [C.c_int]),
     "rto_probe_thresholds": (C.c_int, [C.c_uint32, C.c_uint32, _P]),
     "rto_probe_math": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
+    "rto_probe_sigmoid": (C.c_int, [C.c_int, C.c_uint32, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
     "rto_timer_reset": (C.c_int, [_P, _P]),
     "rto_timer_start": (C.c_int, [_P, C.c_int]),
     "rto_timer_stop": (C.c_int, [_P, C.c_int]),

@@ -431,7 +431,9 @@ int main(int argc, char** argv) {
         if (timed) rto_timer_start(ctx, RTO_T_TORCH);
         const bool packed = denoiser->fused() && filter_mode == RTO_FILTER_FACTORISED;
         // frames of a lean batched launch (below): no aux planes, the noisy image holds (r, g, b, alpha) -- the network reads that
-        const bool lean = rto_ctx_frames_are_lean(ctx, 0, n) != 0;
+        const int lean_state = rto_ctx_frames_are_lean(ctx, 0, n);
+        if (lean_state < 0) return RTO_E_INVALID;  // (cannot happen here: every batch rewrites all the slots it denoises)
+        const bool lean = lean_state == 1;
         if (packed)
             rc = rto_guidance_net_forward_packed_culled(denoiser->fused_handle(), stream, lean ? rto_ctx_noisy(ctx) : rto_ctx_aux(ctx), n, height,
                                                         width, lean ? RTO_NET_INPUT_RGBA : RTO_NET_AUX_SQUARES_IMPLIED, marks, mark_words, mark_bg);

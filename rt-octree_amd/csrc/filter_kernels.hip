@@ -662,7 +662,8 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
                 // itself: 94 16-byte reads per output over the four levels.  Pass A: the window-ROW sums Hs(y, x) = sum_dx
                 // P(y, x + dx), once per staged row and output column (dx ascending from 0: the order box_rows used), to LDS;
                 // pass B: a thread adds the 2S + 1 row sums of each of its outputs (rows ascending: box_rows' order again).
-                // Same additions in the same order -- bit-identical to the one-pass form -- from 52 reads per output.
+                // 52 reads per output.  (The paired pass A below adds a window row's inner values in another order than the
+                // one-pass form did: this tolerance route's sums are NOT bit-identical to round 4's, they differ by an ulp.)
                 constexpr int S = l + 1, HR = kFastH + 2 * S;
                 // (pass A, two adjacent output columns 2 xp, 2 xp + 1 per thread: the 2 S + 2 values of their windows are read
                 //  once, the 2 S - 1... values both windows hold are added once -- t1 + .. + t2S, ascending -- and each sum gets its

@@ -75,7 +75,7 @@ struct NetCull {
 #define RTO_NET_SQ0_WG 3
 #endif
 // IN (round 5): 0 = all 8 aux planes, 1 = SQ, 2 = SQ from the INTERLEAVED image a lean batched launch leaves ([n][H][W][4] =
-// r, g, b, alpha -- the values of aux planes 0..3, rto_ctx_set_tuning "lean_outputs"): one 16-byte load per staged pixel.
+// r, g, b, alpha -- the values of aux planes 0..3, rto_ctx_set_lean_outputs): one 16-byte load per staged pixel.
 template <int C1, int L, int IN, bool PACK>
 __global__ void __launch_bounds__(256, IN ? 4 : RTO_NET_SQ0_WG) guidance_fused(const float* __restrict__ aux,    // [n][8][H][W] (IN = 2: [n][H][W][4])
                                                        const _Float16* __restrict__ w1,  // [C1][96]   k = tap*8 + ci; k = 72: bias

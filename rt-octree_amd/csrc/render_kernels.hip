@@ -238,6 +238,7 @@ RTO_DEV void shade_leaf(const TreeDev& tree, const uint16_t* __restrict__ tv, co
     const int basis_dim = tree.basis_dim;
     if (basis_dim >= 0) {
         int off = 0;
+        float t3[3], o3[3];
 #define MUL_BASIS_I(k) (basis_fn[k] * half_bits_to_float(tv[off + (k)]))
         for (int c = 0; c < 3; ++c) {
             float tmp = basis_fn[0] * half_bits_to_float(tv[off]);
@@ -256,10 +257,12 @@ RTO_DEV void shade_leaf(const TreeDev& tree, const uint16_t* __restrict__ tv, co
                 case 4:
                     tmp += MUL_BASIS_I(1) + MUL_BASIS_I(2) + MUL_BASIS_I(3);
             }
-            out[c] += cnt / (1.f + det_expf(-tmp));
+            t3[c] = tmp;
             off += basis_dim;
         }
 #undef MUL_BASIS_I
+        sigmoid_cnt3(t3, cnt, o3);  // out[c] += cnt / (1.f + det_expf(-tmp)), rt_core.cuh:314-318
+        for (int c = 0; c < 3; ++c) out[c] += o3[c];
     } else {
         for (int j = 0; j < 3; ++j) out[j] += half_bits_to_float(tv[j]) * cnt;
     }
@@ -568,6 +571,7 @@ RTO_DEV void shade_leaf_packed(const TreeDev& tree, uint32_t slot, const float* 
     auto coef = [&](int k) -> float {
         return half_bits_to_float((uint16_t)((k & 1) ? (al[k >> 1] >> 16) : (al[k >> 1] & 0xffffu)));
     };
+    float t3[3], o3[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int off = c * B;
@@ -589,8 +593,11 @@ RTO_DEV void shade_leaf_packed(const TreeDev& tree, uint32_t slot, const float* 
         if constexpr (B >= 4) {
             tmp += basis_fn[1] * coef(off + 1) + basis_fn[2] * coef(off + 2) + basis_fn[3] * coef(off + 3);
         }
-        out[c] += cnt / (1.f + det_expf(-tmp));
+        t3[c] = tmp;
     }
+    sigmoid_cnt3(t3, cnt, o3);  // out[c] += cnt / (1.f + det_expf(-tmp)), rt_core.cuh:314-318
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] += o3[c];
     out[3] += cnt;
 }
 
@@ -2106,6 +2113,7 @@ RTO_DEV void shade_leaf_quant(const TreeDev& tree, uint32_t slot, const float* b
             v[k][2] = half_bits_to_float((uint16_t)(e.y & 0xffffu));
         }
     }
+    float t3[3], o3[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float tmp = basis_fn[0] * v[0][c];
@@ -2126,8 +2134,11 @@ RTO_DEV void shade_leaf_quant(const TreeDev& tree, uint32_t slot, const float* b
         if constexpr (B >= 4) {
             tmp += basis_fn[1] * v[1][c] + basis_fn[2] * v[2][c] + basis_fn[3] * v[3][c];
         }
-        out[c] += cnt / (1.f + det_expf(-tmp));
+        t3[c] = tmp;
     }
+    sigmoid_cnt3(t3, cnt, o3);  // out[c] += cnt / (1.f + det_expf(-tmp)), rt_core.cuh:314-318
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] += o3[c];
     out[3] += cnt;
 }
 

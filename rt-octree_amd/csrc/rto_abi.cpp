@@ -79,6 +79,7 @@ bool tree_fits_spp(const rto_tree* tree, int spp);
 // entry of the two-level image.
 int fast_path_for_spp(const rto_tree* tree, int spp, int wide_bits, rto::TreeDev* td);
 
+constexpr int kMaxSpp = 32;  // the largest of the supported set below: a hit entry's slot field is narrowest there
 bool spp_supported(int spp) {  // volrend.cu:266-278
     return spp == 1 || spp == 2 || spp == 3 || spp == 4 || spp == 6 || spp == 8 || spp == 16 || spp == 32;
 }
@@ -138,7 +139,7 @@ struct rto_ctx {
     int64_t last_slots = 0;
     int batch_fallback = 0;               // tuning / test hook, see rto_ctx_set_tuning
     bool lean = false;                    // rto_ctx_set_lean_outputs
-    int lean_first = 0, lean_n = 0;       // slots the last launch wrote lean (lean_n = 0: none)
+    std::vector<uint8_t> lean_slot;       // per frame slot: 1 = its last writer was a lean launch (no aux planes, noisy.a = alpha)
     int test_wide_bits = 0;               // test hook "wide_bits": pretend a hit entry has this many bits for an entry of the two-level image
     bool cull_single = false;             // tuning "cull_single": the single-frame kernel culls too.  Off by default: a LONE frame waits
                                           // for its longest rays (marked tiles), and the two extra launches cost it 14 us (0.375 ->
@@ -710,10 +711,22 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
         // per slot), not when the entries would not fit the hit-entry budget of every SPP (2^26 at SPP 32: such a tree must
         // stay able to fall back to the one-level walk, whose hits name slots), not with RTO_TREE_SLOT_RECORDS (A/B, tests).
         const int64_t n_entries = t->dev.widew ? (int64_t)t->dev.wide_entries + (int64_t)t->dev.wide_grid_nodes * 64 : 0;
-        const bool by_entry = n_entries > 0 && !(flags & RTO_TREE_COMPACT_RECORDS) && n_entries < (int64_t(1) << 26) && !getenv("RTO_TREE_SLOT_RECORDS");
+        // (the gate is fast_path_for_spp's own test at the largest supported SPP: a by-entry tree has no one-level fallback)
+        bool by_entry = n_entries > 0 && !(flags & RTO_TREE_COMPACT_RECORDS) && slots_fit_spp(n_entries, kMaxSpp) && !getenv("RTO_TREE_SLOT_RECORDS");
+        const int64_t n_rec_slots = n_rec;
         if (by_entry) n_rec = n_entries;
-        const size_t rb = (size_t)n_rec * rec * 2;
-        if (hipMalloc(&t->d_shrec, rb) == hipSuccess) {
+        size_t rb = (size_t)n_rec * rec * 2;
+        bool got = hipMalloc(&t->d_shrec, rb) == hipSuccess && !(by_entry && getenv("RTO_TEST_FAIL_ENTRY_RECORDS"));
+        if (!got && by_entry) {  //  the entry-ordered copy (up to ~8x the slots) does not fit: the slot-ordered one may
+            (void)hipGetLastError();
+            if (t->d_shrec) (void)hipFree(t->d_shrec);
+            t->d_shrec = nullptr;
+            by_entry = false;
+            n_rec = n_rec_slots;
+            rb = (size_t)n_rec * rec * 2;
+            got = hipMalloc(&t->d_shrec, rb) == hipSuccess;
+        }
+        if (got) {
             hipError_t e;
             if (by_entry) {
                 rto::TreeDev td = t->dev;  // (the look-up tables of the two-level image are set; the rest of it as far as the kernel reads it)
@@ -1184,6 +1197,7 @@ int rto_ctx_create_batch(int width, int height, int frames, int device, rto_ctx*
     c->width = width;
     c->height = height;
     c->frames = frames;
+    c->lean_slot.assign((size_t)frames, 0);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -1346,7 +1360,10 @@ int rto_ctx_set_lean_outputs(rto_ctx* c, int on) {
 }
 
 int rto_ctx_frames_are_lean(const rto_ctx* c, int first_slot, int n) {
-    return c && n > 0 && c->lean_n > 0 && first_slot >= c->lean_first && first_slot + n <= c->lean_first + c->lean_n ? 1 : 0;
+    if (!c || n < 1 || first_slot < 0 || first_slot + n > c->frames) return 0;
+    int lean = 0;
+    for (int i = first_slot; i < first_slot + n; ++i) lean += c->lean_slot[(size_t)i] ? 1 : 0;
+    return lean == n ? 1 : lean == 0 ? 0 : -1;  // -1: a mixed range -- no one route reads all of its slots correctly
 }
 
 int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value) {
@@ -1586,7 +1603,7 @@ int rto_launch_renderer(const rto_tree* tree, const rto_camera* cam, const rto_o
     }
 
     if (!keep_marks) ctx->marks_n = 0;  // (the generic kernel and the counting instantiation mark no tiles)
-    if (ctx->lean_n > 0 && ctx->sel >= ctx->lean_first && ctx->sel < ctx->lean_first + ctx->lean_n) ctx->lean_n = 0;  // (a single frame has full outputs)
+    ctx->lean_slot[(size_t)ctx->sel] = 0;  // (a single frame has full outputs; the other slots keep what they hold)
     // (the generic kernel reads tree->dev itself: child[] / data[] may just have been rebuilt by ensure_reference_arrays)
     hipError_t e = rto::launch_render(kernel, o->spp, kernel == RTO_KERNEL_FAST ? tdev : tree->dev, cd, od, ctx->rng, ctx->jump, fo,
                                       ctx->strip_rows, stream);
@@ -1611,7 +1628,6 @@ int rto_launch_renderer_batch(const rto_tree* tree, const rto_camera* cams, cons
 static int generic_frames(const rto_tree* tree, const rto_camera* cams, const int64_t* rng_jumps, int n, const rto_options* o,
                           rto_ctx* ctx, void* stream_, int slot0) {
     ctx->marks_n = 0;
-    ctx->lean_n = 0;  // (full outputs: the generic kernel knows no lean mode)
     if (tree->quant)
         return set_err(RTO_E_UNSUPPORTED, "a quantised tree kept quantised cannot take the generic kernel (too many leaf slots for the "
                                           "batched kernels at this spp, or the traversal kernel's LDS was refused)");
@@ -1667,7 +1683,7 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return set_err(RTO_E_HIP, "hipSetDevice failed");
     ctx->marks_n = 0;  // whatever happens below, the tile marks of an earlier launch no longer describe this context's frames
-    ctx->lean_n = 0;
+    for (int f = 0; f < n; ++f) ctx->lean_slot[(size_t)(slot0 + f)] = 0;  // (set again below if this launch stores lean; the generic fallback stores full outputs)
     rto::TreeDev tdev;
     if (fast_path_for_spp(tree, o->spp, ctx->test_wide_bits, &tdev) == 0 || ctx->batch_fallback == 1) {
         // No traversal image (N != 2, depth > 24, >= 2^29 leaf slots: the top-grid entry's budget) or more slots than a
@@ -1787,10 +1803,8 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     ctx->marks_n = n;
     ctx->marks_slot0 = slot0;
     ctx->marks_bg = o->background_brightness;
-    if (fb.lean) {
-        ctx->lean_first = slot0;
-        ctx->lean_n = n;
-    }
+    if (fb.lean)
+        for (int f = 0; f < n; ++f) ctx->lean_slot[(size_t)(slot0 + f)] = 1;
     return RTO_OK;
 }
 

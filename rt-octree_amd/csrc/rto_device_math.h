@@ -178,6 +178,64 @@ RTO_DEV float det_expf(float x) {
     return (float)(p * sc);
 }
 
+// det_expf for a finite argument |x| <= 87 (no special case can occur: the result is a normal float), in 21 vector
+// instructions instead of ~55 + three nested branches (round 6; shading spends three of these per hit entry): the same
+// reduction -- z, k = rint(z) as v_rndne_f64 (what the 1.5 * 2^52 add / subtract computes for |z| < 2^51), the two
+// un-fused Cody-Waite steps, so r is det_expf's r bit for bit -- then the same degree-11 polynomial as FUSED multiply-adds
+// and the scale 2^k as v_ldexp_f64 (a power of two commutes with the rounding).  The double differs from det_expf's by at
+// most ONE unit in the last place, never across a float rounding boundary: checked for every one of the 2 237 399 042 floats
+// with |x| <= 87 on the CPU (tools/probes/r6_expsweep.c: all operations are IEEE double, which v_fma_f64 / v_rndne_f64 /
+// v_ldexp_f64 implement exactly) and on the device against det_expf itself (tests: rto_probe_sigmoid, all 2^32 floats).
+RTO_DEV float det_expf_mid(float x) {
+    const double xd = (double)x;
+    const double kd = __builtin_rint(xd * 1.4426950408889634);
+    const double r = (xd - kd * 0.693147180558298016) - kd * 1.6465949582897082e-12;
+    double p = 1.0 / 39916800.0;
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return (float)__builtin_ldexp(p, (int)kd);
+}
+
+// cnt / d for d in [1, 2^126) and cnt = 1 .. 32 (a hit entry's sample count over 1 + e^-t): v_rcp_f32 (1 ulp), the quotient
+// estimate, its exact residual (one fma) and one correction -- 4 instructions for the ~11 of the IEEE division sequence
+// (v_div_scale x 2, v_rcp, 4 fma, v_div_fmas, v_div_fixup), which guards exponent ranges these operands cannot reach.
+// The same float as the division for EVERY such d and cnt (126 * 2^23 * 32 cases, rto_probe_sigmoid on the device:
+// v_rcp_f32's bits are the hardware's, so only the device can check it).
+RTO_DEV float div_small_by_ge1(float cnt, float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float q = cnt * r;
+    return __builtin_fmaf(__builtin_fmaf(-d, q, cnt), r, q);
+}
+
+// rt_core.cuh:314-318 for the three colour channels of one hit leaf: o[c] = cnt / (1 + exp(-t[c])).  Every lane whose three
+// arguments lie in [-87, 87] -- every lane, on any scene whose SH sums are not absurd -- takes the short forms above; a wave
+// with a lane outside (NaN, infinities, |t| > 87: overflow, underflow and subnormal results) sends that lane through the
+// plain statement.  Same floats either way.
+RTO_DEV void sigmoid_cnt3(const float* t, float cnt, float* o) {
+#ifdef RTO_SIGMOID_PLAIN  // (same-box A/B of round 6 only)
+    for (int c = 0; c < 3; ++c) o[c] = cnt / (1.f + det_expf(-t[c]));
+    return;
+#endif
+    const bool plain = !(__builtin_fabsf(t[0]) <= 87.f) || !(__builtin_fabsf(t[1]) <= 87.f) || !(__builtin_fabsf(t[2]) <= 87.f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = div_small_by_ge1(cnt, 1.f + det_expf_mid(-t[c]));
+    if (__builtin_expect(__ballot(plain) != 0ULL, 0)) {
+        if (plain) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c] = cnt / (1.f + det_expf(-t[c]));
+        }
+    }
+}
+
 // fp32-only deterministic exp for the filter taps; mirrors oracle/rto_oracle.c orc_fexp (every
 // multiply-add an explicit, correctly rounded fma: v_fma_f32 here, fmaf there)
 RTO_DEV float fexp_f32(float x) {

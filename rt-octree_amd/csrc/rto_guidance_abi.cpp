@@ -333,10 +333,14 @@ int rto_denoise(rto_guidance_net* net, rto_ctx* ctx, int n, int mode, void* stre
     int words = 0, first = 0, frames = 0;
     float bg = 0.f;
     if (rto_ctx_tile_marks(ctx, &marks, &words, &first, &frames, &bg) != RTO_OK || first != sel || frames < n) marks = nullptr;
-    // frames of a lean batched launch (rto_ctx_set_tuning "lean_outputs"): their aux planes were not written, the noisy image
+    // frames of a lean batched launch (rto_ctx_set_lean_outputs): their aux planes were not written, the noisy image
     // carries r, g, b, alpha -- the network reads that
     int net_flags = RTO_NET_AUX_SQUARES_IMPLIED;
-    if (rto_ctx_frames_are_lean(ctx, sel, n)) {
+    const int lean = rto_ctx_frames_are_lean(ctx, sel, n);
+    if (lean < 0)
+        return fail(RTO_E_INVALID, "rto_denoise: slots " + std::to_string(sel) + ".." + std::to_string(sel + n - 1) +
+                                       " mix lean and full outputs (a later launch rewrote some of them): denoise each run of slots by itself");
+    if (lean) {
         aux = noisy;
         net_flags = RTO_NET_INPUT_RGBA;
     }

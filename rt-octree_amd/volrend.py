@@ -335,7 +335,7 @@ class RenderContext:
         check(lib().rto_ctx_set_lean_outputs(self._h, int(bool(on))))
 
     def frames_are_lean(self, first=0, n=1):
-        return bool(lib().rto_ctx_frames_are_lean(self._h, int(first), int(n)))
+        return lib().rto_ctx_frames_are_lean(self._h, int(first), int(n)) == 1  # (0: all full; -1: a mixed range)
 
     def kernel_timing(self, on=True):
         """HIP-event timing of the traversal / shading kernels of launch_renderer_batch"""

@@ -109,7 +109,22 @@ def test_lean_launch_stores_planes_0_to_3_and_denoises_to_the_same_images(scene,
     lean.rng_advance(jumps[1] << 32)
     R.launch_renderer(dt, cams[1], opt, lean)
     torch.cuda.synchronize()
-    assert not lean.frames_are_lean(0, n)
+    #  the state is per slot: slot 1 is full now, slots 0, 2, 3 still hold lean data; the mixed range is refused
+    # instead of being denoised through stale aux planes, and every run of slots still denoises to the full route's images
+    from rt_octree_amd._lib import lib
+    assert not lean.frames_are_lean(0, n) and lib().rto_ctx_frames_are_lean(lean._h, 0, n) == -1
+    assert lean.frames_are_lean(0, 1) and not lean.frames_are_lean(1, 1) and lean.frames_are_lean(2, 2)
+    assert lib().rto_ctx_frames_are_lean(lean._h, 1, 1) == 0
     assert_bits_equal(aux_l[1].cpu().numpy(), aux_full[1].cpu().numpy(), "single frame after a lean launch: full aux planes")
     assert bool(torch.all(noisy_l[1, ..., 3] == 1.0))
+    lean.select_frame(0)
+    with pytest.raises(R.RtoError):
+        net.denoise(lean, n=n, mode=R.FILTER_EXACT)
+    for mode in (R.FILTER_FAST, R.FILTER_EXACT):
+        image_l.fill_(-7.0)
+        for first, cnt in ((0, 1), (1, 1), (2, 2)):
+            lean.select_frame(first)
+            net.denoise(lean, n=cnt, mode=mode)
+        torch.cuda.synchronize()
+        assert_bits_equal(image_l.cpu().numpy(), want[mode].cpu().numpy(), "runs of lean / full / lean slots, mode %d" % mode)
     lean.select_frame(0)

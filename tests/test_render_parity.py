@@ -613,6 +613,30 @@ def test_every_threshold_draw_matches_the_oracle():
     assert np.all(np.diff(got.astype(np.float64)) >= 0)  # -log(1 - u) is monotone in u
 
 
+def test_short_sigmoid_equals_the_plain_statement_for_every_float_and_sample_count():
+    """round 6: the shading kernels evaluate `cnt / (1.f + expf(-t))` (rt_core.cuh:314-318) through sigmoid_cnt3 -- det_expf
+    for |t| <= 87 with fused multiply-adds, the division as v_rcp_f32 + one exact-residual correction.  Same float as the plain
+    statement (whose det_expf the sweep below pins to the oracle) for ALL 2^32 floats t times every sample count 1 .. 32, and
+    the short division alone for every float d in [1, 2^126) times every count: exhaustive, on the device (v_rcp_f32's bits
+    are the hardware's)."""
+    import ctypes as C
+
+    from rt_octree_amd._lib import check, lib
+    out = (C.c_uint64 * 3)()
+    pairs = 0
+    for chunk in range(8):  # mode 0: all floats, 2^29 per launch
+        check(lib().rto_probe_sigmoid(0, chunk << 29, 1 << 29, 1, 32, out))
+        assert out[0] == 0, "sigmoid_cnt3 differs from cnt / (1 + det_expf(-t)) for %d pairs, first at t bits 0x%08x cnt %d" % (
+            out[0], out[1] >> 8, out[1] & 255)
+        pairs += out[2]
+    assert pairs == 32 << 32
+    lo, hi = 0x3f800000, 0x7e800000  # mode 1: every float in [1, 2^126)
+    check(lib().rto_probe_sigmoid(1, lo, hi - lo, 1, 32, out))
+    assert out[0] == 0, "div_small_by_ge1 differs from the IEEE division for %d pairs, first at d bits 0x%08x cnt %d" % (
+        out[0], out[1] >> 8, out[1] & 255)
+    assert out[2] == 32 * (hi - lo)
+
+
 @pytest.mark.parametrize("fn,name", [(0, "det_logf"), (1, "det_expf"), (2, "fexp_f32")])
 def test_device_math_equals_the_oracle_across_the_float_range(fn, name):
     """det_logf / det_expf / fexp_f32 stand in for the reference's `__logf` / `__expf` (DESIGN.md "Math"); device and

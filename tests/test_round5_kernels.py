@@ -49,11 +49,21 @@ def test_entry_ordered_and_slot_ordered_records_render_the_same_frames():
         del os.environ["RTO_TREE_SLOT_RECORDS"]
     assert dt_e.wide_nodes > 0 and dt_s.wide_nodes == dt_e.wide_nodes
     assert dt_e.device_bytes > dt_s.device_bytes  # (a first-level leaf of a pair owns 8 entries: more records than slots)
+    #  when the device refuses the larger, entry-ordered copy the upload retries with slot-ordered records instead
+    # of giving the aligned records up altogether (test hook: RTO_TEST_FAIL_ENTRY_RECORDS makes that first allocation "fail")
+    os.environ["RTO_TEST_FAIL_ENTRY_RECORDS"] = "1"
+    try:
+        dt_r = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+    finally:
+        del os.environ["RTO_TEST_FAIL_ENTRY_RECORDS"]
+    assert dt_r.device_bytes == dt_s.device_bytes and dt_r.wide_nodes == dt_e.wide_nodes
     W, H, spp = 160, 120, 6
     cams = [cameras(W, H, p)[1] for p in POSES[:4]]
     jumps = [100 + i for i in range(4)]
     a_e, a_s = batch_frames(dt_e, cams, spp, jumps), batch_frames(dt_s, cams, spp, jumps)
     assert_bits_equal(a_e, a_s, "batched frames, entry- vs slot-ordered records")
+    assert_bits_equal(batch_frames(dt_r, cams, spp, jumps), a_e, "batched frames after the retry with slot-ordered records")
+    dt_r.free()
     want = oracle_frame(ht, cameras(W, H, POSES[2])[0], spp, frame=102)
     assert_bits_equal(a_e[2], want[0], "entry-ordered records vs the oracle")
     for dt in (dt_e, dt_s):

@@ -106,9 +106,11 @@ def parse_args(argv=None):
                          "more gather per hit leaf in the shading kernel)")
     ap.add_argument("--tuning", default="",
                     help="development: rto_ctx_set_tuning keys for the batched path, e.g. cu_queues=32,queue_group=16")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="groups alternate over this many HIP streams (each with its own context): the tail of one "
-                         "group's kernels overlaps the next group's; per-kernel durations then include the sharing")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="launch groups of the headline passes (`value`, `value_exact`, `value_full_outputs`) alternate over this many "
+                         "HIP streams, each with its own context: the tail of one group's kernels overlaps the next group's head.  "
+                         "With more than one, a single-stream pass of the same frames runs first and supplies the per-kernel "
+                         "durations (roofline.*_ms, reference_timer): kernels that share the chip would not have clean ones")
     ap.add_argument("--torch-net", action="store_true", help="run GuidanceNet through PyTorch-ROCm (MIOpen) instead of the fused HIP kernel")
     ap.add_argument("--c4", action="store_true", help="shorthand for configs[3]: " + " ".join(C4_ARGS))
     ap.add_argument("--plan-only", action="store_true",
@@ -147,10 +149,11 @@ def tree_cache_path(args, scene=0):
 def workload_id(args, W, H):
     """key into profiles/pmc_traffic.json: the BASELINE configurations the counter passes were taken on.  None for
     anything the committed counters do not describe: another scene or tree, development tuning, another library
-    build (RTO_LIB), more than one stream."""
+    build (RTO_LIB).  (The stream count does not matter: the counters are per launch, and the launch durations they are divided by
+    come from the single-stream pass.)"""
     if args.tree or args.shuffle_nodes or args.scenes != 1 or args.quant_direct or args.shell != 2.5:
         return None
-    if args.tuning or os.environ.get("RTO_LIB") or args.streams != 1 or args.compact_records:
+    if args.tuning or os.environ.get("RTO_LIB") or args.compact_records:
         return None
     key = (W, H, args.spp, args.basis, args.depth, bool(args.no_denoise), args.radius, args.fx, args.cam_radius)
     return {(800, 800, 6, 16, 10, False, 1.5, 0.0, 4.0311): "c2", (800, 800, 1, 16, 10, True, 1.5, 0.0, 4.0311): "c5",
@@ -432,7 +435,7 @@ def main():
     def frame_of(step, scene_map):  # (scene, pose) of this rank's `step`-th frame
         return pose_schedule(step, rank, world, len(poses), n_scenes, scene_map)
 
-    def group(scene, idx, ev, lane=0, exact=False):
+    def group(scene, idx, ev, lane=0, exact=False, lean_g=None):
         """The frames `idx` (poses of one scene): traversal + shading, GuidanceNet, filter; all asynchronous
         on the lane's stream, no host sync (the reference synchronises once per frame,
         render_context.hpp:179-188).  Frame i of the reference run uses the RNG advanced (100 + i) times
@@ -440,9 +443,10 @@ def main():
         n = len(idx)
         lctx, lstream, lnet, laux = lanes[lane]
         lctx.rng_seed()
-        lctx.set_lean_outputs(lean)
-        net_in = dict(rgba=True) if lean else dict(squares_implied=True)
-        if lean:
+        use_lean = lean if lean_g is None else bool(lean_g)
+        lctx.set_lean_outputs(use_lean)
+        net_in = dict(rgba=True) if use_lean else dict(squares_implied=True)
+        if use_lean:
             laux = noisy_of[id(lctx)]  # the network reads the (r, g, b, alpha) image the launch leaves
         if ev:
             ev[0].record(lstream)
@@ -479,17 +483,20 @@ def main():
     def plan(n_frames, scene_map):
         return plan_groups(n_frames, B, rank, world, len(poses), n_scenes, scene_map)
 
-    def timed(scene_map, exact=False):
+    def timed(scene_map, exact=False, nl=None, lean_g=None):
+        """one timed pass: W warm-up steps, then exactly K steps between barrier + synchronize; the launch groups alternate over
+        the first `nl` lanes (streams)"""
+        lanes = all_lanes[:nl or len(all_lanes)]
         warm, work = plan(args.warmup * FS, scene_map), plan(n_frames, scene_map)
         events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in work]
         if work:  # allocation pass (untimed, whatever --warmup is): every lane sees the largest group once, so no
             # buffer of the library or of torch's allocator is created inside the timed region
             big = max(work, key=lambda g: len(g[1]))
             for ln in range(len(lanes)):
-                group(big[0], big[1], None, ln, exact)
+                group(big[0], big[1], None, ln, exact, lean_g)
             torch.cuda.synchronize(dev)
         for g, (sc, idx) in enumerate(warm):
-            group(sc, idx, None, g % len(lanes), exact)
+            group(sc, idx, None, g % len(lanes), exact, lean_g)
         torch.cuda.synchronize(dev)
         for lc, _, _, _ in lanes:
             lc.kernel_timing(True)
@@ -505,7 +512,7 @@ def main():
         host_ms = []
         for g, (sc, idx) in enumerate(work):
             t1 = time.perf_counter()
-            group(sc, idx, events[g], g % len(lanes), exact)
+            group(sc, idx, events[g], g % len(lanes), exact, lean_g)
             host_ms.append((time.perf_counter() - t1) * 1e3)
         t_issued = time.perf_counter() - t0
         torch.cuda.synchronize(dev)
@@ -539,40 +546,60 @@ def main():
     if denoise and not args.torch_net:
         for _, _, lnet, _ in lanes:  # the packed-map scratch at its final size: no allocation (= device sync) in a timed region
             lnet.reserve(B, H, W)
-    elapsed, kt, tstats, work = timed(maps[0])
+    NL = len(lanes)
+    all_lanes = lanes
+    # (VERDICT r5 task 4) the headline passes overlap launch-group tails over NL streams; the per-kernel durations and the
+    # Timer::report buckets come from a single-stream pass of the same frames, where no other kernel shares the chip
+    single = timed(maps[0], nl=1) if NL > 1 else None
+    elapsed, kt, tstats, work = timed(maps[0], nl=NL)
+    value_single = None
+    if single:
+        value_single = n_frames * world / single[0]
+        kt, tstats = single[1], single[2]
     alt = None
     if len(maps) > 1:
-        e2, _, t2, _ = timed(maps[1])
+        e2, _, t2, _ = timed(maps[1], nl=NL)
         alt = {"scene_map": maps[1], "value": n_frames * world / e2, "ms_per_step": e2 / args.steps * 1e3,
                "reference_timer_fps": t2["fps"]}
+    last_group, last_lane = work[-1], (len(work) - 1) % NL
+
+    def snapshot_last_group():
+        """frames of the last timed launch group, kept for the oracle spot check below (later passes reuse the buffers)"""
+        out = []
+        if rank == 0 and args.spot_pixels > 0 and not args.quant_direct and not args.tree:  # (rank 0 checks its own frames at any N)
+            lctx = lanes[last_lane][0]
+            nlast = len(last_group[1])
+            for slot in sorted({0, nlast // 2, nlast - 1}):
+                lctx.select_frame(slot)
+                # (lean launch: no aux planes -- the noisy image holds planes 0..3 as (r, g, b, alpha); planes 4..7 are their squares)
+                snap = (lctx.download_image(noisy=True, stream=lanes[last_lane][1]).transpose(2, 0, 1) if lctx.frames_are_lean(slot, 1)
+                        else lctx.download_aux(stream=lanes[last_lane][1]))
+                out.append((last_group[0], last_group[1][slot], snap))
+            lctx.select_frame(0)
+        return out
+
+    spot_frames = snapshot_last_group()
+    # (ADVICE r5) the same frames with the reference's full outputs (8 aux planes + image, 48 B per pixel): the like-for-like
+    # figure next to the lean headline, and an 8-plane spot check
+    full_pass, spot_frames_full = None, []
+    if lean:
+        e4, _, _, _ = timed(maps[0], nl=NL, lean_g=False)
+        full_pass = {"value": n_frames * world / e4, "ms_per_step": e4 / args.steps * 1e3}
+        spot_frames_full = snapshot_last_group()
     # the same frames once more through the bit-exact route (exact filter on fp32 maps): VERDICT r2 task 3
     exact_pass = None
     if denoise and not args.no_exact_pass and not args.exact_filter and not args.torch_net:
-        e3, _, t3, _ = timed(maps[0], exact=True)
-        exact_pass = {"value": n_frames * world / e3, "ms_per_step": e3 / args.steps * 1e3, "reference_timer": t3,
+        e3, _, t3, _ = timed(maps[0], exact=True, nl=NL)
+        exact_pass = {"value": n_frames * world / e3, "ms_per_step": e3 / args.steps * 1e3, "reference_timer": t3 if NL == 1 else None,
                       "route": "fused GuidanceNet -> fp32 weight / guidance planes -> filter_fused (bit-identical to the CPU oracle's filter)"}
-        group(work[-1][0], work[-1][1], None, (len(work) - 1) % len(lanes))  # leave the headline route's frames in the buffers
+    if full_pass or exact_pass:
+        group(work[-1][0], work[-1][1], None, last_lane)  # leave the headline route's frames in the buffers
         torch.cuda.synchronize(dev)
-    last_group, last_lane = work[-1], (len(work) - 1) % len(lanes)
     # empty-space culling: the share of 8x8 tile slots of the last launch group that was marched at all
     try:
         live_slots, all_slots = lanes[last_lane][0].queue_stats()
     except Exception:
         live_slots, all_slots = None, None
-
-    # ---------------- untimed: the reference's loop shape (one frame per launch, sync per frame) ----------------
-    # frames of the last timed launch group, kept for the oracle spot check below (later passes reuse the buffers)
-    spot_frames = []
-    if rank == 0 and args.spot_pixels > 0 and not args.quant_direct and not args.tree:  # (rank 0 checks its own frames at any N)
-        lctx = lanes[last_lane][0]
-        nlast = len(last_group[1])
-        for slot in sorted({0, nlast // 2, nlast - 1}):
-            lctx.select_frame(slot)
-            # (lean launch: no aux planes -- the noisy image holds planes 0..3 as (r, g, b, alpha); planes 4..7 are their squares)
-            snap = (lctx.download_image(noisy=True, stream=lanes[last_lane][1]).transpose(2, 0, 1) if lctx.frames_are_lean(slot, 1)
-                    else lctx.download_aux(stream=lanes[last_lane][1]))
-            spot_frames.append((last_group[0], last_group[1][slot], snap))
-        lctx.select_frame(0)
 
     # ---------------- untimed, N > 1: the path's one collective -- the final gather of RGBA8 frames to rank 0 ----------------
     # (rt-octree_amd/sharding.py gather_frames: one padded all_gather, RCCL over xGMI with device tensors; the same code
@@ -904,8 +931,18 @@ def main():
 
     # ---------------- CPU baseline (rank 0, N == 1 only; bounded sample) ----------------
     cpu = None
-    if world == 1 and args.cpu_frames > 0:
+    cpu_cache = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "rto_bench_cpu_baseline_%s.json" % hashlib.sha256(
+        repr((W, H, args.spp, args.basis, args.depth, args.shell, args.radius, args.tree, denoise, args.cpu_threads)).encode()).hexdigest()[:16])
+    if world > 1 and args.cpu_frames > 0 and os.path.exists(cpu_cache):
+        # (VERDICT r5 task 8) an N > 1 line carries the N = 1 run's CPU baseline of the same workload on this box
+        try:
+            cpu = dict(json.load(open(cpu_cache)), carried_from="the N = 1 run of this workload on this box (%s)" % cpu_cache)
+        except Exception:
+            cpu = None
+    if cpu is None and args.cpu_frames > 0:
         import orc
+        if world > 1:
+            args.cpu_frames = 1  # (no N = 1 line ran here before: a one-frame sample on rank 0 after the other ranks are done)
         if tree_host is None:
             z = np.load(paths[0])
             child, data, scale, offset = z["child"], z["data"], z["invradius3"], z["offset"]
@@ -974,39 +1011,50 @@ def main():
                "logical_cpus_visible": os.cpu_count(), "cores_note": "cores = min(affinity mask, cgroup CPU quota): what the box grants this process",
                "render_s_per_frame": t_render / nf_cpu, "net_s_per_frame": t_net / nf_cpu,
                "filter_s_per_frame": t_filter / nf_cpu, "steps_per_frame": cpu_steps / nf_cpu}
+        if world == 1:
+            try:
+                with open(cpu_cache + ".tmp", "w") as f:
+                    json.dump(cpu, f)
+                os.replace(cpu_cache + ".tmp", cpu_cache)
+            except OSError:
+                pass
 
     # ---------------- parity spot check (untimed): pixels of the last timed launch group vs the CPU oracle ----------------
-    parity = None
-    if spot_frames:
+    def spot_check(frames_list, what):
+        if not frames_list:
+            return None
         import ctypes as C
 
         import orc
-        zs = {}
         checked = mismatched = hit = 0
         rs = np.random.RandomState(12345)
-        for sc, i, aux in spot_frames:
-            if sc not in zs:
+        for sc, i, aux in frames_list:
+            if sc not in spot_trees:
                 z = np.load(paths[sc])
-                zs[sc] = orc.HostTree(z["child"], z["data"], z["invradius3"], z["offset"], str(z["data_format"]))
+                spot_trees[sc] = orc.HostTree(z["child"], z["data"], z["invradius3"], z["offset"], str(z["data_format"]))
             ocam = orc.camera(W, H, fx, fx, np.ascontiguousarray(poses[i][:3, :4].T, np.float32).reshape(-1))
             oopt = orc.default_options(spp=args.spp, denoise=int(denoise))
             base = orc.rng(frame=WARM_FRAMES_REF + i)
             for idx in list(rs.randint(0, W * H, args.spot_pixels)) + [0, W * H - 1, (H // 2) * W + W // 2]:
                 a8, px4 = (C.c_float * 8)(), (C.c_float * 4)()
-                orc.lib().orc_render_pixel(C.byref(zs[sc].c), C.byref(ocam), C.byref(oopt), C.byref(base), int(idx), a8, px4, None)
+                orc.lib().orc_render_pixel(C.byref(spot_trees[sc].c), C.byref(ocam), C.byref(oopt), C.byref(base), int(idx), a8, px4, None)
                 y, x = divmod(int(idx), W)
                 same = np.array_equal(np.array(a8[:aux.shape[0]], np.float32).view(np.uint32), np.ascontiguousarray(aux[:, y, x]).view(np.uint32))
                 checked += 1
                 mismatched += 0 if same else 1
                 hit += 1 if a8[3] > 0 else 0
-        parity = {"pixels_checked": checked, "mismatches": mismatched, "pixels_with_hits": hit,
-                  "frames": [[sc, i] for sc, i, _ in spot_frames],
-                  "values_per_pixel": int(spot_frames[0][2].shape[0]),
-                  "what": "8 aux planes (fp32 bits; after a lean launch: the 4 stored values = planes 0..3) of random pixels + corners + centre of frames of the LAST TIMED launch group "
-                          "against oracle/'s render_kernel + trace_ray for that pixel (orc_render_pixel); the oracle is the "
-                          "checker here, never the thing measured"}
         if mismatched:
-            print("[bench] PARITY FAILURE: %d of %d spot pixels differ from the oracle" % (mismatched, checked), file=sys.stderr)
+            print("[bench] PARITY FAILURE: %d of %d spot pixels differ from the oracle (%s)" % (mismatched, checked, what), file=sys.stderr)
+        return {"pixels_checked": checked, "mismatches": mismatched, "pixels_with_hits": hit,
+                "frames": [[sc, i] for sc, i, _ in frames_list],
+                "values_per_pixel": int(frames_list[0][2].shape[0]),
+                "what": what + ": aux planes (fp32 bits; after a lean launch: the 4 stored values = planes 0..3) of random pixels + "
+                        "corners + centre of frames of the LAST launch group of that timed pass against oracle/'s render_kernel + "
+                        "trace_ray for that pixel (orc_render_pixel); the oracle is the checker here, never the thing measured"}
+
+    spot_trees = {}
+    parity = spot_check(spot_frames, "headline pass")
+    parity_full = spot_check(spot_frames_full, "full-outputs pass (all 8 planes)")
 
     # ---------------- PSNR (untimed, pose 0): SPP-6 raw / denoised vs a high-SPP reference ----------------
     psnr = None
@@ -1089,6 +1137,8 @@ def main():
                           "levels (top grid, ancestor stack), so this is NOT a roofline of the timed kernel and may exceed the peak; kept for "
                           "continuity with rounds 1-3 (`algorithmic_frac` there)",
         "avg_launch_ms": kt["traverse_ms"],
+        "avg_launch_ms_source": "HIP events around the kernel on its launch stream, %s" % (
+            "single-stream pass (value_single_stream)" if NL > 1 else "the timed pass itself"),
         "measured_copy_bw": copy_gbps,
         "launches": kt["launches"], "frames_per_launch": frames_per_launch,
         "shade_kernel_avg_launch_ms": kt["shade_ms"], "thresholds_kernel_avg_launch_ms": kt["raygen_ms"],
@@ -1110,6 +1160,8 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
         "value_exact": exact_pass["value"] if exact_pass else None,
+        "value_full_outputs": full_pass["value"] if full_pass else None,
+        "value_single_stream": value_single,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32" if not denoise else "f32 (traversal, filter) + f16 x f16 -> f32 (GuidanceNet conv, %s)" % ("MIOpen" if args.torch_net else "fused MFMA kernel"),
@@ -1134,6 +1186,11 @@ def main():
             "value_exact": exact_pass["value"] if exact_pass else None,  # the same frames through the bit-exact filter route
             "reference_loop_fps": ref_loop["fps"] if ref_loop else None,  # the reference's loop shape: one launch + one host wait per frame
             "reference_loop_pipelined_wall_fps": (ref_loop.get("pipelined") or {}).get("wall_fps") if ref_loop else None,
+            "value_full_outputs": full_pass["value"] if full_pass else None,  # ... storing all 48 B per pixel like volrend.cu:187-212
+            "value_single_stream": value_single,  # the headline route on ONE stream (the pass the per-kernel durations come from)
+            "streams_note": ("`value`, `value_exact`, `value_full_outputs`: launch groups alternate over %d streams (contexts), the tail of "
+                             "one group's kernels overlaps the next group's head; roofline.*_ms and reference_timer: a single-stream "
+                             "pass of the same frames (`value_single_stream`)" % NL) if NL > 1 else "one stream",
             "lean_outputs": bool(lean),
             "world": world, "backend": (backend if world > 1 else None), "gpus_visible": n_dev,
             "launcher": ("none" if world == 1 else "bench.py itself (child torch.distributed.run)"
@@ -1146,6 +1203,7 @@ def main():
         "exact_route": exact_pass,
         "final_gather": gather,
         "parity_spot": parity,
+        "parity_spot_full_outputs": parity_full,
         "alt_scene_map": alt,
         "roofline": roof,
         "psnr": psnr,

@@ -492,31 +492,17 @@ RTO_DEV bool block_tile(const TileMap& tm, int b, int& tx, int& ty) {
     return ty < tm.tiles_y;
 }
 
-// Layout of the traversal -> shading hand-off buffer, per frame: entry i of pixel p at
-//   planar      [SPP][H*W]:  i * SIZE + p   (a wave's 64 hit stores go to 64 different lines once its lanes hold
-//                                            unrelated pixels)
-//   pixel-major [H*W][SPP]:  p * SPP + i   (a pixel's thresholds / hit list are one contiguous run: 24 B at SPP 6)
-//   split (default since round 3): entry 0 in a dense plane [H*W], entries 1.. pixel-major [H*W][SPP-1] behind it.
-//     The thresholds kernel ends the lists of a culled tile with eight 32-byte row segments instead of 64 scattered dwords
-//     (4 bytes stored at a 24-byte stride cost a 32-byte burst each: 0.66 -> 0.43 ms per 100 frames for marks + lists +
-//     thresholds).
-// Pixel-major replaced planar in round 2 (100 frames of 800x800 SPP 6 in one box: traversal 7.28 vs 7.34 ms,
-// shading 1.96 vs 2.17 ms).
-#ifdef RTO_HITS_PLANAR
-constexpr int kHitsLayout = 0;
-#elif defined(RTO_HITS_PIXEL_MAJOR)
-constexpr int kHitsLayout = 1;
-#else
-constexpr int kHitsLayout = 2;
-#endif
+// Layout of the traversal -> shading hand-off buffer, per frame ("split", round 3): entry 0 of every pixel in a dense plane
+// [H*W], entries 1.. pixel-major [H*W][SPP-1] behind it -- a pixel's thresholds / hit list behind entry 0 are one contiguous
+// run (20 B at SPP 6), and the thresholds kernel writes entry 0 of an 8x8 tile as eight 32-byte row segments instead of 64
+// dwords at a 24-byte stride (0.66 -> 0.43 ms per 100 frames for marks + lists + thresholds).  The planar [SPP][H*W] layout of
+// round 1 and the plain pixel-major one of round 2 (shading 1.96 vs 2.17 ms) are history.
 template <int SPP>
 RTO_DEV uint32_t hit_index(uint32_t pixel, uint32_t i, uint32_t SIZE) {
-    if (kHitsLayout == 0) return i * SIZE + pixel;
-    if (kHitsLayout == 1) return pixel * (uint32_t)SPP + i;
     return i == 0u ? pixel : SIZE + pixel * (uint32_t)(SPP - 1) + (i - 1u);
 }
-// distance between entries i and i + 1 of a pixel for i >= 1 (and for i = 0 in the first two layouts)
-RTO_DEV uint32_t hit_stride(uint32_t SIZE) { return kHitsLayout == 0 ? SIZE : 1u; }
+// distance between entries i and i + 1 of a pixel for i >= 1
+RTO_DEV uint32_t hit_stride(uint32_t) { return 1u; }
 
 // Hit list entry: leaf slot in the low hit_slot_bits(SPP) bits, (count - 1) above, kHitValid on top (rto_kernel_types.h).
 template <int SPP>
@@ -1245,9 +1231,6 @@ __global__ void __launch_bounds__(256) sample_kernel(const FrameBatch fb, const 
     const FrameDesc& fd = fb.f[blockIdx.y];
     // a pixel of a culled tile: an empty hit list, no draws (its RNG stream is its own: nobody observes the skipped ones)
     if (fb.tile_mask && !tile_marked(fb, (int)blockIdx.y, tile)) {  // (shade_kernel reads the marks, not a list)
-#ifdef RTO_SHADE_NO_MARKS
-        as_global(fd.hits)[hit_index<SPP>(idx, 0u, SIZE)] = 0u;
-#endif
         return;
     }
     Pcg32 rng;
@@ -1291,7 +1274,7 @@ RTO_DEV void flush_hits(RayState& rs, const TreeDev& tree, uint32_t* __restrict_
             e[i] = __float_as_uint(s_col[i * 256]);
             if constexpr (WIDE) {
                 constexpr uint32_t smask = (1u << hit_slot_bits(SPP)) - 1u;
-                // (off the march loop: the ray has ended; !translate: the shading kernel does it, FrameBatch::res_flags)
+                // (off the march loop: the ray has ended; !translate: entry-ordered records, TreeDev::rec_by_entry -- the entry IS the record)
                 if (translate) e[i] = (e[i] & ~smask) | wide_to_slot(tree, e[i] & smask);
             }
         }
@@ -1302,22 +1285,6 @@ RTO_DEV void flush_hits(RayState& rs, const TreeDev& tree, uint32_t* __restrict_
     for (int i = 1; i < SPP; ++i)
         if ((uint32_t)i < rs.nh) tp[(uint32_t)(i - 1) * hstride] = e[i];
     rs.nh = 0;
-}
-
-// thresholds I .. N-1 of a pixel (tp: its entry 1 in the hand-off buffer) into rows I .. N-1 of the wave's columns, LDS-direct
-template <int I, int N>
-RTO_DEV void dma_thresholds(const __attribute__((address_space(1))) uint32_t* tp, uint32_t hstride,
-                            __attribute__((address_space(3))) uint32_t* rows) {
-    if constexpr (I < N) {
-        // (a pixel's entries 1.. are consecutive: the immediate offset addresses them.  The hardware adds that offset to the
-        //  LDS address as well as to the memory address -- tools/probes/lds_dma_probe.hip, profiles/r5_c_lds_dma_probe.txt --
-        //  so the row base is moved back by as much)
-        if (kHitsLayout != 0)
-            __builtin_amdgcn_global_load_lds(tp, rows + I * 256 - (I - 1), 4, 4 * (I - 1), 0);
-        else
-            __builtin_amdgcn_global_load_lds(tp + (uint32_t)(I - 1) * hstride, rows + I * 256, 4, 0, 0);
-        dma_thresholds<I + 1, N>(tp, hstride, rows);
-    }
 }
 
 // REFILL = idle lanes that trigger a retire + refill round
@@ -1401,9 +1368,6 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
 #else
 #define RTO_DBG_AT(i) {}
 #endif
-#ifdef RTO_LEAF_K
-    uint32_t pend_w = 0u, pend_slot = 0u;  // the leaf word / slot a lane waits at (0: none; a leaf word carries kLeafTag)
-#endif
     // Two pairs of levels below the grid at most (a tree of depth <= G + 4: the NeRF-synthetic PlenOctrees' 9-10 levels) and the
     // ancestor "stack" is two registers: the restart node then comes from a select, not from an LDS read on the path of
     // every iteration (-2 % in one box, profiles/r4_r_ab_regstack.txt).  Deeper trees keep the LDS rows.  (wave-uniform)
@@ -1417,12 +1381,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
     uint32_t woff_grid_v = 24u - (uint32_t)tree.top_levels, woff_pair0_v = 22u - (uint32_t)tree.top_levels;
     uint32_t tgrid = 1u << (24 - tree.top_levels);
     asm volatile("" : "+v"(woff_grid_v), "+v"(woff_pair0_v), "+s"(tgrid));
-#ifdef RTO_HITS_DIRECT
-    constexpr bool kHitsDirect = true;
-#else
-    constexpr bool kHitsDirect = false;
-#endif
-    constexpr bool kOffsInLds = STACK == 1 && !kHitsDirect;
+    constexpr bool kOffsInLds = STACK == 1;
     RayState rs;
     // a lane marches a ray while rs.t < rs.tmax: that comparison IS the lane's state (an ended ray has t >= tmax or
     // tmax = -1), so the wave-level count of marching lanes is the ballot of one v_cmp instead of a loop-carried flag
@@ -1474,7 +1433,6 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                 const uint32_t take = (uint32_t)n_need < res_end - res_next ? (uint32_t)n_need : res_end - res_next;
                 const uint32_t first = res_next;
                 res_next += take;
-#ifndef RTO_HITS_DIRECT
                 if (idle && rs.nh) {  // the ended ray's hit list leaves in one go
                     if constexpr (kOffsInLds) {
                         rs.hoff = stack[0];
@@ -1482,7 +1440,6 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     }
                     flush_hits<SPP, WIDE>(rs, tree, hits, s_dst, hstride, !tree.rec_by_entry);
                 }
-#endif
                 if (idle) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32),
                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
@@ -1577,11 +1534,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
         do {
         {
             // ---- one node visit for every active lane
-#ifdef RTO_LEAF_K
-            if (active && pend_w == 0u) {
-#else
             if (active) {
-#endif
                 RTO_DBG_AT(0)
                 uint32_t slot, w;
                 if constexpr (WIDE) {
@@ -1612,11 +1565,7 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                     // (through the L1: non-temporal loads cost 15-50 %.  The byte offset as a 32-bit value -- the image has < 2^29
                     //  entries -- lets the load take its base from SGPRs and one VGPR of offset: no 64-bit address pair, no register
                     //  pinned to zero for its high half)
-#ifdef RTO_NODE_ADDR64  // (A/B: the 64-bit address pair of rounds 1-4)
-                    w = nodew[slot];
-#else
                     w = *(gptr_t)((const __attribute__((address_space(1))) char*)nodew + (uint32_t)(slot << 2));
-#endif
 #endif
                     if ((int32_t)w >= -(1 << 30)) {  // internal: two levels down (from the grid: into the level-G node)
                         RTO_DBG_AT(1)
@@ -1641,38 +1590,6 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                 slot = (rs.node << 1) | __builtin_amdgcn_ubfe(rs.pix, sh, 1u);  // node * 8 + child digit,
                 slot = (slot << 1) | __builtin_amdgcn_ubfe(rs.piy, sh, 1u);       // three v_lshl_or
                 slot = (slot << 1) | __builtin_amdgcn_ubfe(rs.piz, sh, 1u);
-#ifdef RTO_DBG_GRIDUNIQ
-                {  // how many distinct top-grid cells / nodew lines does one wave-level load touch?
-                    unsigned long long rem = __ballot(grid);
-                    int uniq = 0;
-                    while (rem) {
-                        const int src = __ffsll((long long)rem) - 1;
-                        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, src);
-                        rem &= ~__ballot(grid && key == k0);
-                        ++uniq;
-                    }
-                    unsigned long long remn = __ballot(!grid);
-                    int uniqn = 0;
-                    while (remn) {
-                        const int src = __ffsll((long long)remn) - 1;
-                        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)(slot >> 4), src);
-                        remn &= ~__ballot(!grid && (slot >> 4) == k0);
-                        ++uniqn;
-                    }
-                    if ((tid & 63) == __ffsll((long long)__ballot(true)) - 1) {
-                        if (uniq) {
-                            atomicAdd(queue + 2, 1ULL);
-                            atomicAdd(queue + 3, (unsigned long long)uniq);
-                            atomicAdd(queue + 4, (unsigned long long)__popcll(__ballot(grid)));
-                        }
-                        if (uniqn) {
-                            atomicAdd(queue + 5, 1ULL);
-                            atomicAdd(queue + 6, (unsigned long long)uniqn);
-                            atomicAdd(queue + 7, (unsigned long long)__popcll(__ballot(!grid)));
-                        }
-                    }
-                }
-#endif
                 // Both addresses exist in registers before either load is issued.  Left to itself the compiler sinks each
                 // address computation into its branch, and when a temporary of the second branch lands in the register the
                 // first branch's load is still writing, it has to put an s_waitcnt vmcnt(0) between the two loads -- the
@@ -1718,30 +1635,9 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
                 }
                 }  // (!WIDE)
                 if ((int32_t)w < -(1 << 30)) {  // leaf: the march step (rt_core.cuh:241-270)
-#ifdef RTO_LEAF_K
-                    pend_w = w;  // postponed: the lane waits at its leaf until enough lanes of the wave have reached one
-                    pend_slot = slot;
-#else
 #include "rto_march_leaf.inc"
-#endif
                 }
             }
-#ifdef RTO_LEAF_K
-            {
-                // Experiment (VERDICT r3 task 3): the leaf branch -- the bulk of the loop body -- runs only once RTO_LEAF_K lanes
-                // wait at a leaf, or when no active lane is left that could still descend.
-                const bool at_leaf = active && pend_w != 0u;
-                const unsigned long long lm = __builtin_amdgcn_ballot_w64(at_leaf);
-                const unsigned long long dm = __builtin_amdgcn_ballot_w64(active && pend_w == 0u);
-                if (__popcll(lm) >= RTO_LEAF_K || dm == 0ULL) {
-                    if (at_leaf) {
-                        const uint32_t w = pend_w, slot = pend_slot;
-                        pend_w = 0u;
-#include "rto_march_leaf.inc"
-                    }
-                }
-            }
-#endif
         }
             active = rs.t < rs.tmax;
             {
@@ -1750,7 +1646,6 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
             }
         } while (n_active > exit_at);
     }
-#ifndef RTO_HITS_DIRECT
     if (rs.nh) {  // rays that ended after the last refill round
         if constexpr (kOffsInLds) {
             rs.hoff = stack[0];
@@ -1758,7 +1653,6 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
         }
         flush_hits<SPP, WIDE>(rs, tree, hits, s_dst, hstride, !tree.rec_by_entry);
     }
-#endif
 #ifdef RTO_DBG_COUNTERS
 #pragma unroll
     for (int i = 0; i < 8; ++i) {  // queue words 1..7 / 9..15 are padding of the queue counters: wave counts, lane counts
@@ -1769,328 +1663,6 @@ __global__ void __launch_bounds__(256, WPS) render_persist(const TreeDev tree, c
 #endif
 }
 
-// ------------------------------------------------------------------ persistent kernel with a ray reservoir (round 5)
-//
-// render_persist_res: render_persist on the two-level image with the ray SET-UP taken out of the refill round.
-// render_persist sets a ray up (~600 instructions: camera transform, normalisations, the double-precision
-// reciprocals and slab test of rt_core.cuh:206-222) inside the refill round, for the idle lanes only -- so a round is
-// only worth its price once half the wave idles (REFILL = 32), and on average a quarter of a wave's lanes hold no ray
-// (48 of 64 live, 31 lanes per VALU instruction: VERDICT r4).  Here a wave sets up ONE WHOLE 8x8 TILE at a time, all
-// 64 lanes busy, camera in SGPRs (a tile is one frame: scalar loads), and parks the rays that enter the volume,
-// compacted, as 10-dword records in a wave-private reservoir in LDS (field-major: [field][record], conflict-free).
-// A refill round then only copies records into idle lanes (10 LDS reads + the thresholds) and is affordable at
-// KREF = 8..16 idle lanes: ~56-60 lanes of a wave march.  Per-ray arithmetic is unchanged; results are bit-identical.
-//
-// Record (dwords): dir[3] (scaled + renormalised, rt_core.cuh:206-208), invdir[3], delta_scale, tmin, tmax, pixel
-// index (y * W + x); with the NDC warp (LLFF) also cen[3] -- without it the origin is the same for every ray of a
-// frame and travels in SGPRs.
-#define RTO_RES_LDS_DMA_WAIT 1  // (rto_march_leaf.inc: state the dependence of the column reads on the LDS-direct loads)
-template <int SPP, int KREF, int WPS, bool DIRECT>
-__global__ void __launch_bounds__(256, WPS) render_persist_res(const TreeDev tree, const OptDev opt, const FrameBatch fb,
-                                                           unsigned long long* __restrict__ queue,
-                                                           uint32_t* __restrict__ hits, const uint32_t chunk) {
-    constexpr bool WIDE = true;
-    constexpr bool kHitsDirect = DIRECT;  // one store per hit at the moment it happens
-    // LDS rows of 256 dwords (a lane's column = dword tid of each row), all at compile-time offsets from ONE per-lane address:
-    //   [0, SPP]            sorted thresholds / parked hit entries (row SPP: the FLT_MAX sentinel, rt_core.cuh:192)
-    //   [SPP+1]             frame << 25 | pixel of the lane's ray (where its hit list goes: read once, when the ray has ended)
-    //   [SPP+2, SPP+11]     reservoir: field f of record r of wave w at dword f * 256 + w * 64 + r
-    //   [SPP+12, ...)       ancestor stack rows (none with the register stack), then 3 more reservoir rows (cen) with the NDC warp
-    extern __shared__ uint32_t s_mem[];
-    constexpr int kPidRow = SPP + 1, kResRow = SPP + 2, kStackRow = SPP + 12;
-    const int tid = threadIdx.x;
-    const int G = tree.top_levels;
-    uint32_t stk0 = 0u, stk1 = 0u;
-    const bool regstack = (tree.max_depth - G + 1) / 2 <= 2;  // (wave-uniform) see render_persist
-    constexpr bool kStackInRegs = false;                         // (not a compile-time fact here: rto_march_leaf.inc branches)
-    constexpr uint32_t g_vgpr = 0u, woff_grid_v = 0u, woff_pair0_v = 0u, tgrid = 0u;  // (named by the discarded branch of rto_march_leaf.inc)
-    const int stack_rows = regstack ? 0 : tree.max_depth + 1 - G;
-    float* const s_dst = reinterpret_cast<float*>(s_mem) + tid;
-    uint32_t* const stack = s_mem + kStackRow * 256 + tid;
-    uint32_t* const stack_g = stack;  // (rto_march_leaf.inc names it; unused on the two-level image)
-    const bool ndc = tree.ndc_width > 0;
-    __shared__ int s_qstart[kMaxQueues + 1];
-    __shared__ uint32_t s_qcount[kMaxQueues];
-#pragma unroll
-    for (int k = 0; k <= kMaxQueues; ++k)
-        if (tid == 64 + k) s_qstart[k] = fb.qstart[k];
-#pragma unroll
-    for (int k = 0; k < kMaxQueues; ++k)
-        if (tid == 128 + k) s_qcount[k] = k < fb.n_queues ? fb.qcount[k] : 0u;
-    s_dst[SPP * 256] = 3.402823466e+38f;  // no hit entry ever lands in this row (entry k < spp <= SPP)
-    if (G == 0 && !regstack) stack[0] = 0u;
-    __syncthreads();
-
-    const int W = fb.width, H = fb.height;
-    const uint32_t SIZE = (uint32_t)W * (uint32_t)H;
-    const uint32_t hstride = hit_stride(SIZE);
-    const uint32_t n_queues = (uint32_t)fb.n_queues;
-    uint32_t cur_q = n_queues > 1 ? ((uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % n_queues) : 0u;
-    uint32_t q_tried = 0, res_off = 0;
-
-    typedef const __attribute__((address_space(1))) uint32_t* gptr_t;
-    const uint32_t* nodew_p = tree.widew;
-    const uint32_t* __restrict__ qlist = fb.qlist;
-    float step_size = opt.step_size, sigma_thresh = opt.sigma_thresh;
-    asm volatile("" : "+s"(nodew_p), "+s"(step_size), "+s"(sigma_thresh));
-    const gptr_t nodew = (gptr_t)nodew_p;
-
-#ifdef RTO_DBG_COUNTERS
-    unsigned dbg_w[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    RayState rs;
-    rs.t = 0.f;
-    rs.tmax = -1.f;
-    rs.nh = 0;
-    const bool prefetch = (fb.res_flags & kResPrefetch) != 0;
-    const bool lds_dma = (fb.res_flags & kResLdsDma) != 0;
-    bool drained = false;                    // queues and reservoir exhausted (wave-uniform)
-    uint32_t res_next = 0, res_end = 0;      // the wave's private run of queue entries, in rays (64 per tile slot)
-    uint32_t rec_pos = 0, rec_cnt = 0;       // records [rec_pos, rec_cnt) of the reservoir wait for a lane (wave-uniform)
-    uint32_t rec_frame = 0;                  // frame of the reservoir's tile
-    float rec_cen0 = 0.f, rec_cen1 = 0.f, rec_cen2 = 0.f;  // its ray origin in tree space (no NDC warp)
-
-    // a ray's parked hit entries leave for the hand-off buffer: entry 0 into the dense plane, entries 1.. as one run (they name
-    // entries of the two-level image: the shading kernel translates, FrameBatch::res_flags & kResHitsWide)
-    auto flush = [&]() {
-        const uint32_t pid = __float_as_uint(s_dst[kPidRow * 256]);  // (the launcher keeps W * H < 2^25)
-        const uint32_t fbase = (pid >> 25) * (uint32_t)SPP * SIZE, pixel = pid & 0x1ffffffu;
-        hits[fbase + hit_index<SPP>(pixel, 0u, SIZE)] = __float_as_uint(s_dst[0]);
-        uint32_t* tp = hits + fbase + hit_index<SPP>(pixel, SPP > 1 ? 1u : 0u, SIZE);
-#pragma unroll
-        for (int i = 1; i < SPP; ++i)
-            if ((uint32_t)i < rs.nh) tp[(uint32_t)(i - 1) * hstride] = __float_as_uint(s_dst[i * 256]);
-        rs.nh = 0;
-    };
-
-    for (;;) {
-        bool refilling = false;  // a round that has begun fills EVERY idle lane, across tiles (wave-uniform)
-        for (;;) {
-            if (drained) break;
-            const bool idle = !(rs.t < rs.tmax);
-            const unsigned long long need = __builtin_amdgcn_ballot_w64(idle);
-            const int n_need = __popcll(need);
-            if (n_need == 0 || (!refilling && n_need < KREF)) break;
-            refilling = true;
-            if (rec_pos == rec_cnt) {  // ---- the reservoir is empty: set up the next tile of the queue, all 64 lanes
-                if (res_next == res_end) {
-                    for (;;) {  // own queue first, then the others in turn (wave-uniform)
-                        const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane(s_qstart[cur_q]);
-                        const uint32_t qtotal = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_qcount[cur_q]) * 64u;
-                        unsigned long long base = 0;
-                        if ((tid & 63) == 0) base = atomicAdd(queue + 8 + 8 * cur_q, (unsigned long long)chunk);
-                        const uint32_t base32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
-                        if (base32 < qtotal) {
-                            res_next = base32;
-                            res_end = base32 + chunk < qtotal ? base32 + chunk : qtotal;
-                            res_off = t0 * (uint32_t)fb.n;
-                            break;
-                        }
-                        if (++q_tried >= n_queues) {
-                            drained = true;
-                            break;
-                        }
-                        cur_q = cur_q + 1 == n_queues ? 0u : cur_q + 1;
-                    }
-                    if (drained) break;
-                }
-                const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)qlist[res_off + (res_next >> 6)]);
-                res_next += 64u;
-                const int frame = (int)(entry >> 20);
-                // Everything the set-up derives from launch constants is derived HERE, per tile: left alone, the compiler hoists
-                // those values (0.5 W, bbox +- 1e-6 in double, the NDC factors, lane & 7 ...) out of the kernel's loops into
-                // ~18 VGPRs that the march loop then has to spill around (the empty asm statements make the inputs opaque)
-                uint32_t ln = (uint32_t)tid;
-                int Wl = W, Hl = H;
-                OptDev o2 = opt;
-                TreeDev t2 = tree;
-                asm volatile("" : "+v"(ln), "+s"(Wl), "+s"(Hl));
-#pragma unroll
-                for (int i = 0; i < 6; ++i) asm volatile("" : "+s"(o2.render_bbox[i]));
-                asm volatile("" : "+s"(t2.ndc_width), "+s"(t2.ndc_height), "+s"(t2.ndc_focal));
-                const int x = (int)(entry & 1023u) * 8 + (int)(ln & 7u);
-                const int y = (int)((entry >> 10) & 1023u) * 8 + (int)((ln >> 3) & 7u);
-                RTO_DBG_AT(6)
-                // wave-uniform index into a table nobody writes while the kernel runs: the constant address space makes these
-                // scalar loads (the camera of the tile in 14 SGPRs)
-                typedef const __attribute__((address_space(4))) float* cptr_t;
-                const cptr_t fd = (cptr_t)(const void*)(fb.f + frame);
-                static_assert(offsetof(FrameDesc, fx) == 0 && offsetof(FrameDesc, transform) == 8, "fx, fy, transform[12] lead a FrameDesc");
-                CamDev cam;
-                cam.width = Wl;
-                cam.height = Hl;
-                cam.fx = fd[0];
-                cam.fy = fd[1];
-#pragma unroll
-                for (int i = 0; i < 12; ++i) cam.transform[i] = fd[2 + i];
-                if (prefetch && x < Wl && y < Hl) {
-                    // touch this pixel's thresholds: the refill rounds that hand the tile's rays out find them in the L2
-                    // instead of waiting for HBM with the whole wave (the values are not used here)
-                    const uint32_t pixel = (uint32_t)(y * Wl + x), fbase = (uint32_t)frame * (uint32_t)SPP * SIZE;
-                    uint32_t d0 = hits[fbase + hit_index<SPP>(pixel, 0u, SIZE)], d1 = 0u, d2 = 0u;
-                    if (SPP > 1) d1 = hits[fbase + hit_index<SPP>(pixel, 1u, SIZE)];
-                    if (SPP > 2) d2 = hits[fbase + hit_index<SPP>(pixel, (uint32_t)(SPP - 1), SIZE)];
-                    asm volatile("" ::"v"(d0), "v"(d1), "v"(d2));
-                }
-                float dir[3], vdir[3], cen[3], invdir[3], delta_scale, tmin, tmax;
-                ray_setup(x, y, cam, t2, dir, vdir, cen);
-                bool ok = ray_enter<true>(t2, o2, dir, cen, 1e9f, invdir, delta_scale, tmin, tmax);
-                // (a ray with tmin >= tmax takes no step -- `while (t < tmax)`, rt_core.cuh:241 -- and leaves its list empty)
-                ok = ok && x < Wl && y < Hl && tmin < tmax;
-                const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
-                const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(okm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okm, 0u));
-                if (ok) {
-                    float* r = reinterpret_cast<float*>(s_mem) + kResRow * 256 + (ln & 0xc0u) + slot;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        r[i * 256] = dir[i];
-                        r[(3 + i) * 256] = invdir[i];
-                    }
-                    r[6 * 256] = delta_scale;
-                    r[7 * 256] = tmin;
-                    r[8 * 256] = tmax;
-                    r[9 * 256] = __uint_as_float((uint32_t)(y * Wl + x));
-                    if (ndc) {
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) r[(10 + stack_rows + i) * 256] = cen[i];
-                    }
-                }
-                rec_pos = 0;
-                rec_cnt = (uint32_t)__popcll(okm);
-                rec_frame = (uint32_t)frame;
-                rec_cen0 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cen[0])));
-                rec_cen1 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cen[1])));
-                rec_cen2 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cen[2])));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (rec_cnt == 0u) continue;
-            }
-            // ---- hand records to the idle lanes (ballot + prefix sum)
-            const uint32_t avail = rec_cnt - rec_pos;
-            const uint32_t take = (uint32_t)n_need < avail ? (uint32_t)n_need : avail;
-            if (!DIRECT && idle && rs.nh) flush();  // the ended ray's hit list leaves in one go
-            if (idle) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-                if (rank < take) {
-                    uint32_t lt = (uint32_t)tid;
-                    asm volatile("" : "+v"(lt));  // (derive the wave's reservoir address here, not in a register held across the kernel)
-                    const float* r = reinterpret_cast<const float*>(s_mem) + kResRow * 256 + (lt & 0xc0u) + (rec_pos + rank);
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        rs.dir[i] = r[i * 256];
-                        rs.invdir[i] = r[(3 + i) * 256];
-                    }
-                    rs.delta_scale = r[6 * 256];
-                    rs.t = r[7 * 256];
-                    rs.tmax = r[8 * 256];
-                    const uint32_t pixel = __float_as_uint(r[9 * 256]);
-                    rs.cen[0] = rec_cen0;
-                    rs.cen[1] = rec_cen1;
-                    rs.cen[2] = rec_cen2;
-                    if (ndc) {
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) rs.cen[i] = r[(10 + stack_rows + i) * 256];
-                    }
-                    if (!DIRECT) s_dst[kPidRow * 256] = __uint_as_float(rec_frame << 25 | pixel);
-                    const uint32_t fbase = rec_frame * (uint32_t)SPP * SIZE;
-                    const uint32_t hoff = fbase + hit_index<SPP>(pixel, 0u, SIZE), hnext = fbase + hit_index<SPP>(pixel, SPP > 1 ? 1u : 0u, SIZE);
-                    if (DIRECT) {
-                        rs.hoff = hoff;
-                        rs.hnext = hnext;
-                    }
-                    // sorted thresholds of this pixel (sample_kernel left them in the hand-off buffer, where the ray's hit
-                    // list will overwrite them)
-                    rs.cur = __uint_as_float(hits[hoff]);
-                    const uint32_t* tp = hits + hnext;
-                    if (lds_dma) {
-                        // thresholds 1.. straight from memory into this lane's column (global_load_lds_dword: lane L of the wave
-                        // writes dword L of the row M0 points at -- exactly its column), no VGPR round trip and NO WAIT here:
-                        // the loads are in flight while the wave marches on; vmcnt is in order, so the first node word that
-                        // arrives after this round proves them landed (the hit branch waits explicitly before it reads a row)
-                        typedef const __attribute__((address_space(1))) uint32_t* gp_t;
-                        typedef __attribute__((address_space(3))) uint32_t* lp_t;
-                        dma_thresholds<1, SPP>((gp_t)tp, hstride, (lp_t)(s_mem + __builtin_amdgcn_readfirstlane((int)(lt & 0xc0u))));
-                    } else {
-#pragma unroll
-                        for (int i = 1; i < SPP; ++i) s_dst[i * 256] = __uint_as_float(tp[(uint32_t)(i - 1) * hstride]);
-                    }
-                    rs.spp = 0;
-                    rs.src = 0;
-                    float k24 = kPos24;  // (an SGPR operand, see render_persist)
-                    asm volatile("" : "+s"(k24));
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {  // (the march loop works on the scaled origin and direction: kPos24)
-                        rs.cen[i] *= k24;
-                        rs.dir[i] *= k24;
-                    }
-                    rs.cxy.x = rs.cen[0];
-                    rs.cxy.y = rs.cen[1];
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) rs.exit_add[i] = rs.invdir[i] > 0.f ? rs.invdir[i] : 0.f;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) rs.pos[i] = clamp_unit24(rs.cen[i] + rs.t * rs.dir[i]);
-                    rs.pix = (uint32_t)rs.pos[0];
-                    rs.piy = (uint32_t)rs.pos[1];
-                    rs.piz = (uint32_t)rs.pos[2];
-                    rs.node = 0u;
-                    rs.woff = 24u - (uint32_t)G;
-                    rs.wb = (uint32_t)G;
-                }
-            }
-            rec_pos += take;
-        }
-        bool active = rs.t < rs.tmax;
-        if (__builtin_amdgcn_ballot_w64(active) == 0ULL) {
-            if (drained) break;
-            continue;
-        }
-        const int exit_at = drained ? 0 : 64 - KREF;
-        int n_active;
-        do {
-            if (active) {  // ---- one node visit for every active lane (see render_persist)
-                RTO_DBG_AT(0)
-                uint32_t slot, w;
-                const uint32_t b = rs.wb;
-                slot = (rs.node << b) | __builtin_amdgcn_ubfe(rs.pix, rs.woff, b);
-                slot = (slot << b) | __builtin_amdgcn_ubfe(rs.piy, rs.woff, b);
-                slot = (slot << b) | __builtin_amdgcn_ubfe(rs.piz, rs.woff, b);
-                if (rs.node == 0u) { RTO_DBG_AT(7) }
-                w = nodew[slot];
-                if ((int32_t)w >= -(1 << 30)) {  // internal: two levels down (from the grid: into the level-G node)
-                    RTO_DBG_AT(1)
-                    rs.node = w;
-                    if (regstack) {
-                        const bool first = rs.woff == 24u - (uint32_t)G;
-                        stk0 = first ? w : stk0;
-                        stk1 = first ? stk1 : w;
-                    } else
-                        stack[(((24u - (uint32_t)G) - rs.woff) >> 1) * 256u] = w;
-                    rs.woff -= 2u;
-                    rs.wb = 2u;
-                }
-                if ((int32_t)w < -(1 << 30)) {  // leaf: the march step (rt_core.cuh:241-270)
-#include "rto_march_leaf.inc"
-                }
-            }
-            active = rs.t < rs.tmax;
-            {
-                const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
-                asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n_active) : "s"(am) : "scc");
-            }
-        } while (n_active > exit_at);
-    }
-    if (!DIRECT && rs.nh) flush();  // rays that ended after the last refill round
-#ifdef RTO_DBG_COUNTERS
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int wi = i == 0 ? 16 + 1 : i, li = i == 0 ? 16 + 2 : 8 + i;
-        if (dbg_w[i]) atomicAdd(queue + wi, (unsigned long long)dbg_w[i]);
-        if (dbg_l[i]) atomicAdd(queue + li, (unsigned long long)dbg_l[i]);
-    }
-#endif
-}
-#undef RTO_RES_LDS_DMA_WAIT
 
 // One hit leaf of a quantised tree, shaded straight from the codebooks (TreeDev::qrec / qcolors): the
 // coefficients are the very fp16 values N3Tree::load_npz would have expanded (n3tree.cpp:310-339),
@@ -2230,11 +1802,7 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
     // A pixel of a culled tile has no hit list (nobody wrote one: sample_kernel, render_persist): it is read off the tile
     // marks, a few hundred cached words per frame, instead of 4 * SPP bytes per pixel of stale memory -- two thirds of the
     // pixels of the bench scene.  (x, y) of the wave's first pixel by one wave-uniform division, the lanes' by carries.
-#ifdef RTO_SHADE_NO_MARKS  // (A/B: the culled tiles' pixels carry an explicit empty list instead)
-    const uint32_t* fmask = nullptr;
-#else
     const uint32_t* fmask = fb.tile_mask ? fb.tile_mask + (size_t)frame * fb.mask_words : nullptr;
-#endif
     const uint32_t keep_all = fmask ? fmask[fb.mask_words - 1] & 1u : 1u;
     const int tiles_x = (W + 7) >> 3;
     const int wy0 = (int)(wave_px0 / W), wx0 = (int)(wave_px0 - (int64_t)wy0 * W);
@@ -2254,54 +1822,18 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
         }
         if (live) {
             bool open = true;
-            if (kHitsLayout == 2) {  // the first entry from its dense plane, the run behind it
-#ifdef RTO_SHADE_LAZY_LIST
-                // (fetching the run only for a pixel whose first entry is valid saves 20 bytes per empty pixel and costs a
-                //  dependent round trip per wave: 2.03 instead of 1.95 ms per 100 frames)
-                uint32_t raw[SPP];
-                raw[0] = fhits[idx];
+            // the first entry from its dense plane, the run behind it (fetched eagerly: fetching the run only for a pixel whose
+            // first entry is valid saves 20 bytes per empty pixel and costs a dependent round trip per wave, 2.03 vs 1.95 ms)
+            uint32_t raw[SPP];
+            raw[0] = fhits[idx];
+            const RTO_GLOBAL uint32_t* hp = fhits + SIZE + idx * (SPP - 1);
 #pragma unroll
-                for (int i = 1; i < SPP; ++i) raw[i] = 0u;
-                if (raw[0] & kHitValid) {
-                    const RTO_GLOBAL uint32_t* hp = fhits + SIZE + idx * (SPP - 1);
+            for (int i = 1; i < SPP; ++i) raw[i] = hp[i - 1];
 #pragma unroll
-                    for (int i = 1; i < SPP; ++i) raw[i] = hp[i - 1];
-                }
-#else
-                uint32_t raw[SPP];
-                raw[0] = fhits[idx];
-                const RTO_GLOBAL uint32_t* hp = fhits + SIZE + idx * (SPP - 1);
-#pragma unroll
-                for (int i = 1; i < SPP; ++i) raw[i] = hp[i - 1];
-#endif
-#pragma unroll
-                for (int i = 0; i < SPP; ++i) {
-                    open = open && (raw[i] & kHitValid) != 0u;
-                    h[p][i] = open ? raw[i] : 0u;
-                    n[p] += open ? 1u : 0u;
-                }
-            } else if (kHitsLayout == 1) {  // the whole list is one contiguous run: fetch it, then find its end
-                const RTO_GLOBAL uint32_t* hp = fhits + idx * SPP;
-                uint32_t raw[SPP];
-#pragma unroll
-                for (int i = 0; i < SPP; ++i) raw[i] = hp[i];
-#pragma unroll
-                for (int i = 0; i < SPP; ++i) {
-                    open = open && (raw[i] & kHitValid) != 0u;
-                    h[p][i] = open ? raw[i] : 0u;
-                    n[p] += open ? 1u : 0u;
-                }
-            } else {
-                const RTO_GLOBAL uint32_t* hp = fhits + idx;
-#pragma unroll
-                for (int i = 0; i < SPP; ++i) {
-                    h[p][i] = 0u;
-                    if (open) {
-                        h[p][i] = hp[(int64_t)i * SIZE];
-                        open = (h[p][i] & kHitValid) != 0u;
-                        n[p] += open ? 1u : 0u;
-                    }
-                }
+            for (int i = 0; i < SPP; ++i) {
+                open = open && (raw[i] & kHitValid) != 0u;
+                h[p][i] = open ? raw[i] : 0u;
+                n[p] += open ? 1u : 0u;
             }
         }
         mine += n[p];
@@ -2372,9 +1904,7 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
             else
                 ray_basis(tree, opt, vdir, basis_fn);
             float o[4];
-            uint32_t leaf = hit_slot<SPP>(he);
-            if (fb.res_flags & kResHitsWide) leaf = wide_to_slot(tree, leaf);  // (block-uniform) the traversal left entries of the two-level image
-            leaf_contrib<MODE>(tree, leaf, basis_fn, (float)hit_count<SPP>(he), o);
+            leaf_contrib<MODE>(tree, hit_slot<SPP>(he), basis_fn, (float)hit_count<SPP>(he), o);
             s_c[wv][j] = o[0];
             s_c[wv][kShadeCap + j] = o[1];
             s_c[wv][2 * kShadeCap + j] = o[2];
@@ -2581,28 +2111,17 @@ hipError_t launch_render(int kernel, int spp, const TreeDev& tree, const CamDev&
 #ifndef RTO_WPS_DEFAULT
 #define RTO_WPS_DEFAULT 8
 #endif
-template <int SPP, int REFILL, int WPS, bool WIDE, int RES = 0>  // RES: 0 render_persist, 1 render_persist_res, 2 ... with direct hit stores
-static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb_in, int res_flags,
+template <int SPP, int REFILL, int WPS, bool WIDE>
+static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                     const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
                                     int chunk_override, bool cull, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
     // dynamic LDS: ancestor stack + thresholds per lane, then the frame table of THIS batch (96 B per frame: a batch of
     // one does not pay for 128)
-    // (RES, the reservoir kernel: no frame table -- a tile's camera arrives by scalar loads --, no stack rows when the ancestor
-    //  stack lives in registers, 10 dwords per lane of ray records, 13 with the NDC warp)
-    const bool res_regstack = (tree.max_depth - tree.top_levels + 1) / 2 <= 2;
-    const size_t lds = RES ? (size_t)(SPP + 2 + 10 + (res_regstack ? 0 : tree.max_depth + 1 - tree.top_levels) + (tree.ndc_width > 0 ? 3 : 0)) * 256 * sizeof(uint32_t)
-                           : (size_t)((WIDE && res_regstack ? 2 : tree.max_depth + 1 - tree.top_levels) + SPP + 1) * 256 * sizeof(uint32_t) + sizeof(float) * kCamFloats * (size_t)fb_in.n;
-    auto kern = [regs = res_regstack] {
-        (void)regs;
-        if constexpr (RES)
-            return &render_persist_res<SPP, REFILL, WPS, RES == 2>;
-        else
-            return WIDE && regs ? &render_persist<SPP, REFILL, WPS, WIDE, WIDE ? 1 : 0> : &render_persist<SPP, REFILL, WPS, WIDE, 0>;
-    }();
-    FrameBatch fb = fb_in;
-    // (the reservoir kernel never translates its hit entries: they name their records directly, TreeDev::rec_by_entry, or the
-    //  shading kernel translates)
-    fb.res_flags = RES ? ((res_flags & ~kResHitsWide) | (tree.rec_by_entry ? 0 : kResHitsWide)) : 0;
+    // (two pairs of levels below the grid at most: the ancestor stack is two registers and its LDS rows only park a ray's two
+    //  hand-off offsets)
+    const bool regstack = WIDE && (tree.max_depth - tree.top_levels + 1) / 2 <= 2;
+    const size_t lds = (size_t)((regstack ? 2 : tree.max_depth + 1 - tree.top_levels) + SPP + 1) * 256 * sizeof(uint32_t) + sizeof(float) * kCamFloats * (size_t)fb.n;
+    const auto kern = regstack ? &render_persist<SPP, REFILL, WPS, WIDE, WIDE ? 1 : 0> : &render_persist<SPP, REFILL, WPS, WIDE, 0>;
     const void* fn = reinterpret_cast<const void*>(kern);
     OccupancyCache local;
     if (!occ) occ = &local;
@@ -2695,14 +2214,13 @@ template <int SPP>
 static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                    const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
                                    int refill, bool cull, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream) {
-    // tuning: refill = 100000 * reservoir-kernel flags (kResPrefetch | kResHitsWide) + 1000 * tiles_per_dequeue + threshold
-    const int res_flags = refill / 100000;
+    // tuning: refill = 1000 * tiles_per_dequeue + 100 * waves/SIMD + threshold
     refill %= 100000;
     const int chunk_override = (refill / 1000) * 64;
     refill %= 1000;
     const bool wide = tree.widew != nullptr;
     if constexpr (SPP == 6) {  // tuning instantiations only for the benchmark configuration (and its usual two-level image)
-#define RTO_F(R, O) return launch_batch_impl<SPP, R, O, true>(tree, opt, fb, res_flags, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream)
+#define RTO_F(R, O) return launch_batch_impl<SPP, R, O, true>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream)
         if (wide) switch (refill) {  // A/B set kept for tools/ab_tuning.py: 100 * waves/SIMD + refill threshold
             case 808: RTO_F(8, 8);
             case 816: RTO_F(16, 8);
@@ -2719,29 +2237,6 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
             default: break;
         }
 #undef RTO_F
-#define RTO_R(K, O) return launch_batch_impl<SPP, K, O, true, 1>(tree, opt, fb, res_flags, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream)
-#define RTO_D(K, O) return launch_batch_impl<SPP, K, O, true, 2>(tree, opt, fb, res_flags, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream)
-        // (the reservoir kernel packs frame and pixel of a ray into one word: frames below 2^25 pixels)
-        if (wide && (int64_t)fb.width * fb.height < (int64_t(1) << 25)) switch (refill) {  // the reservoir kernel (round 5): 900 + idle-lane threshold at 8 waves per SIMD, 500 + at 7; 400 + / 300 + = direct hit stores
-            case 908: RTO_R(8, 8);
-            case 912: RTO_R(12, 8);
-            case 916: RTO_R(16, 8);
-            case 924: RTO_R(24, 8);
-            case 932: RTO_R(32, 8);
-            case 508: RTO_R(8, 7);
-            case 512: RTO_R(12, 7);
-            case 516: RTO_R(16, 7);
-            case 524: RTO_R(24, 7);
-            case 532: RTO_R(32, 7);
-            case 408: RTO_D(8, 8);
-            case 416: RTO_D(16, 8);
-            case 308: RTO_D(8, 7);
-            case 316: RTO_D(16, 7);
-            case 324: RTO_D(24, 7);
-            default: break;
-        }
-#undef RTO_D
-#undef RTO_R
     }
     // Refill once half the lanes are idle (larger refill rounds waste fewer issue slots on the partially filled ray set-up:
     // 32 idle lanes beat 16 by 4 %); registers budgeted for RTO_WPS_DEFAULT waves per SIMD.  Occupancy matters (round 3,
@@ -2750,14 +2245,11 @@ static hipError_t launch_batch_spp(const TreeDev& tree, const OptDev& opt, const
     // which change the register budget, not the number of resident waves).
     // The two-level traversal image when the tree has one (always, unless it would not fit its index space or the device's
     // memory: rto_abi.cpp build_wide_image), else the one-level image: the same pixels either way.
-    // Round 5: the reservoir kernel (render_persist_res; tuning refill = 500 + K / 900 + K, flags x 100000) was built to light the
-    // lanes the round-4 kernel leaves dark -- and is NOT the default: same-box A/B, 100 frames of C2: 4.27-4.32 ms at its best
-    // setting (K = 24, 7 waves per SIMD, prefetch + LDS-direct thresholds) against 4.11-4.20 for this kernel, which round 5 left
-    // spill-free at 59 VGPRs, without the hit-entry translation in its flush (TreeDev::rec_by_entry) and without the flat loads
-    // a laundered LDS pointer had put into its hit branch (profiles/r5_*_ab*.txt; DESIGN.md section 4 "Round 5").
+    // (Round 5's reservoir kernel -- whole-tile set-up, rays parked in LDS, refill rounds at 8-24 idle lanes -- lost its same-box
+    //  A/B, 4.27-4.32 against 4.11-4.20 ms per 100 C2 frames, and lives in tools/experiments/r5_lab_switches.patch.)
     if (wide)
-        return launch_batch_impl<SPP, 32, RTO_WPS_DEFAULT, true>(tree, opt, fb, 0, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream);
-    return launch_batch_impl<SPP, 32, RTO_WPS_DEFAULT, false>(tree, opt, fb, 0, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream);
+        return launch_batch_impl<SPP, 32, RTO_WPS_DEFAULT, true>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream);
+    return launch_batch_impl<SPP, 32, RTO_WPS_DEFAULT, false>(tree, opt, fb, jump, queue, hits, num_cus, chunk_override, cull, occ, ev, stream);
 }
 
 hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,

@@ -1299,7 +1299,7 @@ int rto_ctx_set_kernel(rto_ctx* c, int kernel) {
     return RTO_OK;
 }
 
-#if defined(RTO_DBG_COUNTERS) || defined(RTO_DBG_GRIDUNIQ)
+#ifdef RTO_DBG_COUNTERS
 extern "C" int rto_debug_read_queue(rto_ctx* c, uint64_t out[24]) {
     return hipMemcpy(out, c->queue, 24 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -4;
 }

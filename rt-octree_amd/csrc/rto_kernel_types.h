@@ -161,14 +161,9 @@ struct FrameBatch {
     uint32_t* chunk_base;
     int qchunk[kMaxQueues + 1];
     const FrameDesc* f;  // [n] in device memory (the context's table, written on the launch stream by write_frames_kernel)
-    // set by the launcher (render_persist_res): kResPrefetch = a tile's set-up touches its pixels' thresholds, so that the refill
-    // rounds find them in the L2; kResHitsWide = the hit entries name entries of the two-level image and the SHADING kernel
-    // translates them to leaf slots (wide_to_slot), not the traversal's flush
-    int res_flags;
     // rto_ctx_set_lean_outputs: the shading kernel stores the noisy image as (r, g, b, alpha) and nothing else -- no aux planes
     int lean;
 };
-constexpr int kResPrefetch = 1, kResHitsWide = 2, kResLdsDma = 4;  // kResLdsDma: thresholds go memory -> LDS directly (global_load_lds)
 struct FrameChunk {
     FrameDesc f[kFrameChunk];
 };

@@ -61,6 +61,12 @@ def test_bench_line_has_the_contract_fields():
     assert cf["value_exact"] == d["value_exact"] and cf["reference_loop_fps"] == rl["fps"]
     assert cf["reference_loop_pipelined_wall_fps"] == rl["pipelined"]["wall_fps"] and cf["groups_per_step"] == 1 and cf["frames_per_group"] == 4
     assert cf["lean_outputs"] is True and ps["values_per_pixel"] == 4
+    # round 6 (VERDICT r5 task 4): the headline passes run over two streams, the per-kernel durations come from a
+    # single-stream pass; the full-output figure (48 B per pixel, like volrend.cu:187-212) and an 8-plane spot check beside it
+    assert cf["streams"] == 2 and "single-stream" in cf["streams_note"] and "single-stream" in rf["avg_launch_ms_source"]
+    assert d["value_single_stream"] > 0 and d["value_full_outputs"] > 0 and cf["value_full_outputs"] == d["value_full_outputs"]
+    pf = d["parity_spot_full_outputs"]
+    assert pf["values_per_pixel"] == 8 and pf["pixels_checked"] >= 3 * 64 and pf["mismatches"] == 0
     pl = rl["pipelined"]
     assert pl["frames_in_flight"] == 4 and pl["wall_fps"] > 0 and pl["last_frame_bit_identical_to_the_sequential_loop"] in (True, None)
     assert rf["traffic_stale"] is None and len(rf["kernel_code_id"]) == 16
@@ -90,7 +96,7 @@ def test_counter_based_roofline_for_the_baseline_workloads():
     assert bench.workload_id(bench.parse_args(["--shuffle-nodes", "1"]), 800, 800) is None
     # counters describe ONE build of the kernel on ONE default configuration: development runs never wear them
     assert bench.workload_id(bench.parse_args(["--tuning", "refill=816"]), 800, 800) is None
-    assert bench.workload_id(bench.parse_args(["--streams", "2"]), 800, 800) is None
+    assert bench.workload_id(bench.parse_args(["--streams", "1"]), 800, 800) == "c2"  # (durations come from the single-stream pass either way)
     os.environ["RTO_LIB"] = "/nonexistent/librto.so"
     try:
         assert bench.workload_id(args, 800, 800) is None

@@ -4,9 +4,6 @@
     for dense SH9 / SH16 trees) against slot-ordered records (RTO_TREE_SLOT_RECORDS=1 at upload), through every kernel --
     batched, single-frame, the counting instantiation (one-level walk + two-level lookup of the hit's entry) and the generic
     kernel after the reference arrays were rebuilt FROM the entry-ordered records;
-  * the reservoir traversal kernel (render_persist_res, tuning refill = 500 + K / 900 + K, flags x 100000: 1 = thresholds
-    touched at set-up, 4 = LDS-direct threshold loads; 300 + K / 400 + K = one store per hit) -- not the default, but a kernel
-    of the library: bit-identical frames for every setting, also on a deep tree (LDS ancestor stack), an NDC tree and SPP 1;
   * a launch whose SPP leaves a hit entry too few bits for an entry of the two-level image, but enough for a leaf
     slot, walks the ONE-level image instead of dropping to the generic kernel (test hook: tuning "wide_bits")."""
 import os
@@ -79,38 +76,6 @@ def test_entry_ordered_and_slot_ordered_records_render_the_same_frames():
         ctx.free()
     dt_e.free()
     dt_s.free()
-
-
-RES_SETTINGS = [508, 516, 524, 532, 908, 916, 100516, 400516, 500524, 500508, 316, 500308, 416]
-
-
-@pytest.mark.parametrize("case", ["sh9_d8", "deep_d12", "spp1", "ndc"])
-def test_reservoir_kernel_settings_render_the_default_frames(case):
-    if case == "deep_d12":  # more than two pairs of levels below the grid: the LDS ancestor stack, not the register one
-        from test_render_parity import _chain_tree
-        tree = _chain_tree(13, seed=13)
-    else:
-        tree = synth.make_tree(depth_limit=8 if case == "sh9_d8" else 6, basis_dim=9 if case != "spp1" else 16, seed=11, shell=2.0)
-    dt = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
-    if case == "ndc":
-        dt.set_ndc(200.0, 150.0, 180.0)
-    assert dt.wide_nodes > 0
-    W, H, spp = (200, 152, 1) if case == "spp1" else (200, 152, 6)
-    if case == "deep_d12":  # (the chain tree's dense leaves sit near the centre: look at it from close by)
-        cams = [cameras(W, H, synth.look_at_c2w(pos, target=(0.1, -0.1, 0.05)))[1]
-                for pos in [(2.2, 1.7, 1.9), (-1.9, 2.4, 0.8), (0.4, 0.3, 2.9), (1.0, -2.0, 1.5), (-2.0, -1.0, 2.0)]]
-    else:
-        cams = [cameras(W, H, p)[1] for p in POSES[:5]]
-    jumps = [7 + 3 * i for i in range(5)]
-    base = batch_frames(dt, cams, spp, jumps)
-    assert np.any(base[:, 3] > 0)
-    settings = RES_SETTINGS if spp == 6 else []  # (the A/B instantiations exist for the benchmark's SPP only)
-    for code in settings:
-        got = batch_frames(dt, cams, spp, jumps, tuning=(("refill", code),))
-        assert_bits_equal(got, base, "%s: refill = %d" % (case, code))
-    if spp != 6:  # other SPPs: the round-4 kernel is the only batched traversal kernel -- the codes fall through to it
-        assert_bits_equal(batch_frames(dt, cams, spp, jumps, tuning=(("refill", 516),)), base, "spp 1, refill code ignored")
-    dt.free()
 
 
 def test_two_level_image_over_budget_walks_the_one_level_image():

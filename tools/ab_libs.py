@@ -15,7 +15,7 @@ def main():
     ap.add_argument("--args", default="")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
-    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-frames", "0", "--psnr-frames", "0", "--ref-loop-frames", "0",
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-frames", "0", "--psnr-frames", "0", "--ref-loop-frames", "0", "--streams", "1",
             "--no-exact-pass", "--count-frames", "0", "--spot-pixels", "16", "--steps", "6", "--warmup", "2", "--groups-per-step", "1"] + a.args.split()
     for r in range(a.rounds):
         for lib in a.libs:

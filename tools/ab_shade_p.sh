@@ -1,6 +1,6 @@
 #!/bin/bash
 # Development A/B: pixels per lane (RTO_SHADE_P) of the compacting shade kernel, dense and codebook-direct.
-B="python bench.py --steps 96 --warmup 16 --cpu-frames 0 --psnr-frames 0 --no-denoise"
+B="python bench.py --streams 1 --steps 96 --warmup 16 --cpu-frames 0 --psnr-frames 0 --no-denoise"
 pick() { grep -o '"value": [0-9.]*\|"shade_kernel_avg_launch_ms": [0-9.]*' | tr '\n' ' '; echo; }
 $B 2>/dev/null | pick
 T=$(ls /dev/shm/rto_bench_tree_*.npz | head -1)

@@ -11,7 +11,7 @@ if [ ! -f $DENSE ]; then  # (bench.py generates and caches the synthetic tree on
 fi
 Q=/dev/shm/rto_bench_tree_quant_r1.npz
 [ -f $Q ] || python3 tools/make_quant_tree.py $DENSE $Q --retain 1 > $O/${T}_quant_make.txt 2>&1
-B="bench.py --tree $Q --no-denoise --cpu-frames 0 --psnr-frames 0 --ref-loop-frames 0 --no-exact-pass --steps 4 --warmup 1"
+B="bench.py --streams 1 --tree $Q --no-denoise --cpu-frames 0 --psnr-frames 0 --ref-loop-frames 0 --no-exact-pass --steps 4 --warmup 1"
 timeout 900 python3 $B > $O/${T}_quant_bench_expanded.json 2> $O/${T}_quant_expanded.err
 timeout 900 python3 $B --quant-direct > $O/${T}_quant_bench_direct.json 2> $O/${T}_quant_direct.err
 for V in expanded direct; do

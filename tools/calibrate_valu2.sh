@@ -15,7 +15,7 @@ STUB=$PWD/rt-octree_amd/lib_ab/librto_1.so
 S="blocks_per_cu=1 blocks_per_cu=2 blocks_per_cu=3 blocks_per_cu=4 blocks_per_cu=5 blocks_per_cu=6"
 python3 tools/ab_tuning.py $S > $O/${TAG}_real_by_occupancy.txt 2>&1
 RTO_LIB=$STUB python3 tools/ab_tuning.py $S > $O/${TAG}_stub_by_occupancy.txt 2>&1
-B="bench.py --cpu-frames 0 --psnr-frames 0 --ref-loop-frames 0 --steps 2 --warmup 1 --no-denoise"
+B="bench.py --streams 1 --cpu-frames 0 --psnr-frames 0 --ref-loop-frames 0 --steps 2 --warmup 1 --no-denoise"
 for K in 1 2 4 6; do
   RTO_LIB=$STUB timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/${TAG}_stub_$K -- python3 $B --tuning blocks_per_cu=$K > /dev/null 2> $O/${TAG}_stub_$K.err || tail -2 $O/${TAG}_stub_$K.err
   python3 tools/pmc_summarize.py $O/${TAG}_stub_pmc_k$K.json $O/${TAG}_stub_$K > /dev/null

@@ -4,7 +4,7 @@
 #  then hangs in its finalisation until the job's limit -- round 3 lost 65 GPU-minutes to it.  Every pass runs under `timeout`.)
 O=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-B="bench.py --cpu-frames 0 --psnr-frames 0 --steps 32 --warmup 16 --no-denoise"
+B="bench.py --streams 1 --cpu-frames 0 --psnr-frames 0 --steps 32 --warmup 16 --no-denoise"
 i=0
 for SET in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum" \
            "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum" \

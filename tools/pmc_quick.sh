@@ -3,7 +3,7 @@
 O=gpurun_out
 TAG=${1:-q}
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-B="bench.py --cpu-frames 0 --psnr-frames 0 --ref-loop-frames 0 --steps 2 --warmup 1 --groups-per-step 1 --no-denoise $2"
+B="bench.py --streams 1 --cpu-frames 0 --psnr-frames 0 --ref-loop-frames 0 --steps 2 --warmup 1 --groups-per-step 1 --no-denoise $2"
 i=0
 for SET in "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
            "GRBM_GUI_ACTIVE TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum TCP_TA_DATA_STALL_CYCLES_sum" \

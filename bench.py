@@ -91,6 +91,7 @@ def parse_args(argv=None):
                     help="frames of the untimed work-unit count behind the algorithmic figures (0 = skip: profiling runs, whose "
                          "per-kernel counter means must hold the timed launches only)")
     ap.add_argument("--no-exact-pass", action="store_true", help="skip the second timed pass through the bit-exact filter route")
+    ap.add_argument("--no-full-pass", action="store_true", help="skip the timed pass with the reference's full outputs (value_full_outputs)")
     ap.add_argument("--tree", default="", help="render this tree.npz instead of the synthetic one")
     ap.add_argument("--shuffle-nodes", type=int, default=0, metavar="SEED",
                     help="store the synthetic tree's nodes in a random order (seed > 0): svox-refined trees have no "
@@ -120,6 +121,9 @@ def parse_args(argv=None):
     ap.add_argument("--full-outputs", action="store_true",
                     help="A/B: the batched launches of the timed region store all 48 B per pixel (8 aux planes + noisy image) instead of "
                          "the 16 B the fused denoise stage reads (rto_ctx_set_lean_outputs; same denoised images)")
+    ap.add_argument("--lean-level", type=int, default=2, choices=(1, 2),
+                    help="lean outputs of the headline pass: 2 = sparse (nothing stored for the pixels of culled tiles: rto_ctx_set_lean_outputs "
+                         "level 2, RTO_NET_INPUT_SPARSE), 1 = round 5's lean outputs")
     ap.add_argument("--no-filter-cull", action="store_true",
                     help="A/B: filter every tile, also those that see only culled (background) render tiles")
     ap.add_argument("--fp32-maps", action="store_true",
@@ -444,7 +448,9 @@ def main():
         lctx, lstream, lnet, laux = lanes[lane]
         lctx.rng_seed()
         use_lean = lean if lean_g is None else bool(lean_g)
-        lctx.set_lean_outputs(use_lean)
+        # sparse (level 2): only where both denoise kernels get the launch's tile marks and run the packed route
+        sparse = bool(use_lean and args.lean_level == 2 and packed_route and not exact and not args.no_filter_cull and args.net_cull)
+        lctx.set_lean_outputs(2 if sparse else (1 if use_lean else 0))
         net_in = dict(rgba=True) if use_lean else dict(squares_implied=True)
         if use_lean:
             laux = noisy_of[id(lctx)]  # the network reads the (r, g, b, alpha) image the launch leaves
@@ -452,7 +458,7 @@ def main():
             ev[0].record(lstream)
         R.launch_renderer_batch(trees[scene], [cams[i] for i in idx], opt, lctx, lstream,
                                 rng_jumps=[WARM_FRAMES_REF + i for i in idx])
-        lctx.set_lean_outputs(False)  # (every other pass of this script reads full outputs)
+        lctx.set_lean_outputs(0)  # (every other pass of this script reads full outputs)
         if ev:
             ev[1].record(lstream)
         if denoise:
@@ -460,7 +466,7 @@ def main():
             if packed_route and not exact:  # GuidanceNet -> fp16 maps in the handle's scratch -> factorised filter
                 # (network / filter tiles that see only culled = background render tiles are filled, not computed: same bits)
                 marks = None if args.no_filter_cull else lctx.tile_marks()
-                lnet.forward_packed(laux[:n], stream=lstream, cull=marks if args.net_cull else None, **net_in)
+                lnet.forward_packed(laux[:n], stream=lstream, cull=marks if args.net_cull else None, sparse=sparse, **net_in)
                 if ev:
                     ev[2].record(lstream)
                 lnet.filter_packed(lctx.noisy_ptr, lctx.image_ptr, stream=lstream, shape=(n, H, W), cull=marks)
@@ -582,7 +588,7 @@ def main():
     #  the same frames with the reference's full outputs (8 aux planes + image, 48 B per pixel): the like-for-like
     # figure next to the lean headline, and an 8-plane spot check
     full_pass, spot_frames_full = None, []
-    if lean:
+    if lean and not args.no_full_pass:
         e4, _, _, _ = timed(maps[0], nl=NL, lean_g=False)
         full_pass = {"value": n_frames * world / e4, "ms_per_step": e4 / args.steps * 1e3}
         spot_frames_full = snapshot_last_group()
@@ -1192,6 +1198,7 @@ def main():
                              "one group's kernels overlaps the next group's head; roofline.*_ms and reference_timer: a single-stream "
                              "pass of the same frames (`value_single_stream`)" % NL) if NL > 1 else "one stream",
             "lean_outputs": bool(lean),
+            "lean_level": (args.lean_level if lean else 0),  # 2: sparse -- the headline launches store nothing for the pixels of culled tiles
             "world": world, "backend": (backend if world > 1 else None), "gpus_visible": n_dev,
             "launcher": ("none" if world == 1 else "bench.py itself (child torch.distributed.run)"
                          if os.environ.get("RTO_BENCH_SELF_LAUNCHED") else "external (torchrun)"),

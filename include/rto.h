@@ -220,8 +220,16 @@ int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value);
  * lean batch leaves the other slots lean).  rto_ctx_frames_are_lean: 1 when slots [first_slot, first_slot + n) were all
  * written by a lean launch last, 0 when none was, -1 for a mixed range -- which rto_denoise refuses (RTO_E_INVALID): denoise
  * each run of slots by itself. */
-int rto_ctx_set_lean_outputs(rto_ctx* c, int on);
+int rto_ctx_set_lean_outputs(rto_ctx* c, int level);
 int rto_ctx_frames_are_lean(const rto_ctx* c, int first_slot, int n);
+/* Level 2 (round 6), SPARSE lean outputs: as level 1, and the launch stores NOTHING for the pixels of the 8x8 tiles its
+ * empty-space culling left unmarked (two thirds of the bench scene's pixels; they are the background: colour =
+ * background_brightness, alpha 0).  The noisy image is then valid inside marked tiles only; its consumers need the launch's
+ * tile marks (rto_ctx_tile_marks): rto_denoise with RTO_FILTER_FACTORISED does it by itself, the two-call form passes
+ * RTO_NET_INPUT_RGBA | RTO_NET_INPUT_SPARSE and the marks to rto_guidance_net_forward_packed_culled + rto_filtering_packed_culled.
+ * rto_ctx_download_image / _rgba8 of the noisy image fill the unmarked tiles in on the host.  The denoised image is complete and
+ * bit-identical to the other levels'.  rto_ctx_frames_lean_level: 0 / 1 / 2 when all of the slots agree, -1 otherwise. */
+int rto_ctx_frames_lean_level(const rto_ctx* c, int first_slot, int n);
 /* Per-kernel HIP-event timing of the batched path: when enabled, every rto_launch_renderer_batch
  * records events before the traversal kernel, between it and the shading kernel, and after (on the
  * launch stream; up to 256 launches between reads).  _read synchronises on the recorded events and
@@ -353,6 +361,11 @@ int rto_guidance_net_forward(const rto_guidance_net* net, void* stream, const fl
  * alpha): the values of aux planes 0..3 (volrend.cu:187-194), as a LEAN batched launch leaves them in the context's noisy
  * buffer (rto_ctx_set_lean_outputs).  Squares implied.  Bit-identical maps to the aux-buffer input. */
 #define RTO_NET_INPUT_RGBA 2
+/* RTO_NET_INPUT_SPARSE (round 6; with RTO_NET_INPUT_RGBA, tile marks and the packed route only) -- the image is that of a SPARSE
+ * lean launch (rto_ctx_set_lean_outputs level 2): it holds nothing for the pixels of unmarked (culled) render tiles, which are
+ * the background by construction; the network takes (background x 3, alpha 0) for them and stores no maps for the tiles it
+ * skips -- rto_filtering_packed_culled with the same marks substitutes both.  Same denoised images, bit for bit. */
+#define RTO_NET_INPUT_SPARSE 4
 int rto_guidance_net_forward_ex(const rto_guidance_net* net, void* stream, const float* aux, int n, int H, int W,
                                 float* weight_map, float* guidance_map, int flags);
 /* The denoise stage (Denoiser::denoise, denoiser.cpp:31-61) as two launches that keep the maps in their native

@@ -85,6 +85,7 @@ SYMBOLS = {
     "rto_ctx_set_tuning": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "rto_ctx_set_lean_outputs": (C.c_int, [_P, C.c_int]),
     "rto_ctx_frames_are_lean": (C.c_int, [_P, C.c_int, C.c_int]),
+    "rto_ctx_frames_lean_level": (C.c_int, [_P, C.c_int, C.c_int]),
     "rto_ctx_queue_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rto_ctx_tile_marks": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "rto_ctx_kernel_timing": (C.c_int, [_P, C.c_int]),

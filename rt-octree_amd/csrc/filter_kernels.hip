@@ -167,7 +167,28 @@ struct FilterCull {
     const uint32_t* mask;
     int mask_words, tiles_x;
     const float4* fill;  // [tile height][tile width]: the output tile of a workgroup that sees only background
+    // SPARSE lean frames (round 6; filter_fast on packed maps only): img_in holds no pixel of an unmarked render tile -- it is the
+    // background (bg, bg, bg) -- and the packed maps none of a network tile that saw only background (guidance_fused skipped
+    // it): its 8 fp16 values are fill_maps.  The staging loop substitutes both.
+    int sparse;
+    float bg;
+    uint4 fill_maps;
 };
+
+// guidance_fused's decision to skip a 32 x 8 output tile (guidance_kernels.hip: its 36 x 12 input region lies inside the image
+// and in unmarked render tiles), restated for the filter that has to know which map pixels were never stored
+__device__ __forceinline__ bool net_tile_was_skipped(const uint32_t* fm, int mask_words, int tiles_x8, int H, int W, int ntx, int nty) {
+    const int x0 = ntx * 32 - 2, y0 = nty * 8 - 2;
+    if (ntx < 0 || nty < 0 || ntx * 32 >= W || nty * 8 >= H) return false;
+    if (x0 < 0 || y0 < 0 || x0 + 36 > W || y0 + 12 > H) return false;  // (its zero padding is not background: computed)
+    if (fm[mask_words - 1] & 1u) return false;                           // keep-all frame
+    for (int ty = y0 >> 3; ty <= (y0 + 11) >> 3; ++ty)
+        for (int tx = x0 >> 3; tx <= (x0 + 35) >> 3; ++tx) {
+            const uint32_t t = (uint32_t)(ty * tiles_x8 + tx);
+            if ((fm[t >> 5] >> (t & 31u)) & 1u) return false;
+        }
+    return true;
+}
 constexpr int kMapHalo = 2;  // a GuidanceNet map value depends on the 5x5 aux pixels around it (two 3x3 convolutions)
 
 // A workgroup whose staged region (outputs + halo, RW x RH pixels from (rx0, ry0)), grown by the network's receptive field,
@@ -488,6 +509,43 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
         while (ts < strip && tx_first + ts < tiles_x && ((skip >> ts) & 1u)) ++ts;
         return (ts < strip && tx_first + ts < tiles_x) ? ts : kFastStrip;
     };
+    // sparse frames: the network tiles under this strip's staged region whose maps were never stored -- bit (row - nty0) * 8 +
+    // (column - ntx0) of `nskip`; the region spans at most strip + 2 <= 7 columns and 4 rows of 32 x 8 tiles
+    const uint32_t* const fmask = cull.mask ? cull.mask + (size_t)blockIdx.z * cull.mask_words : nullptr;
+    const int ntx0 = (tx_first * kFastW - L) >> 5, nty0 = y0 >> 3;
+    // ... and the marks of the render tiles (8 x 8) under it, one word per tile row: bit (column - rtx0) of rmark[row - nty0]
+    // (at most (strip * 32 + 2 L + 7) / 8 + 1 <= 22 columns, 4 rows); wave-uniform values in SGPRs: a staged element's test is
+    // shifts and selects, no load, no division
+    const int rtx0 = (tx_first * kFastW - L) >> 3;
+    uint32_t nskip = 0, rmark[4] = {0, 0, 0, 0};
+    if (PACKED && cull.sparse) {
+        static_assert(!PACKED || (kFastStrip + 2 <= 8 && (kFastH + 2 * L + 7) / 8 + 1 <= 4 && (kFastStrip * kFastW + 2 * L + 7) / 8 + 1 <= 32),
+                      "bit budget of the skipped-network-tile mask and of the render-tile rows");
+        __shared__ uint32_t s_sp[5];
+        if (tid < 5) s_sp[tid] = 0;
+        __syncthreads();
+        if (tid < 32 && net_tile_was_skipped(fmask, cull.mask_words, cull.tiles_x, H, W, ntx0 + (tid & 7), nty0 + (tid >> 3)))
+            atomicOr(&s_sp[4], 1u << tid);
+        if (tid < 128) {  // render tile (row tid >> 5, column tid & 31) of the region
+            const int ty = nty0 + (tid >> 5), tx = rtx0 + (tid & 31);
+            bool marked = false;
+            if (tx >= 0 && ty >= 0 && tx < cull.tiles_x && ty * 8 < H) {
+                const uint32_t t = (uint32_t)(ty * cull.tiles_x + tx);
+                marked = (((fmask[t >> 5] >> (t & 31u)) | fmask[cull.mask_words - 1]) & 1u) != 0u;
+            }
+            if (marked) atomicOr(&s_sp[tid >> 5], 1u << (tid & 31));
+        }
+        __syncthreads();
+        nskip = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_sp[4]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rmark[r] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_sp[r]);
+    }
+    auto maps_stored = [&](int gx, int gy) { return ((nskip >> ((((gy >> 3) - nty0) << 3) + ((gx >> 5) - ntx0))) & 1u) == 0u; };
+    auto pixel_stored = [&](int gx, int gy) {  // its render tile is marked: the shading kernel wrote it
+        const int r = (gy >> 3) - nty0;
+        const uint32_t w = r == 0 ? rmark[0] : r == 1 ? rmark[1] : r == 2 ? rmark[2] : rmark[3];
+        return ((w >> ((gx >> 3) - rtx0)) & 1u) != 0u;
+    };
 
     // what a tile's computation needs from memory, as it arrives: the staged noisy pixels, the guidance values of the staged
     // elements and the weights of this thread's outputs (packed: raw fp16 maps, converted when the tile's turn comes)
@@ -519,22 +577,32 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
         in_tile = (int32_t)v >= 0;
         return (int)(v & 2047u);
     };
-    auto gindex = [&](int x0, int i) {  // staged element i of this thread -> global index (or -1 outside the image)
+    auto gindex_xy = [&](int x0, int i, int& gx, int& gy) {  // staged element i of this thread -> global index (or -1 outside the image)
         int ty, tx;
         bool in_tile;
         elem(i, ty, tx, in_tile);
-        const int gx = x0 + tx, gy = y0 + ty;
+        gx = x0 + tx;
+        gy = y0 + ty;
         return (in_tile && gx >= 0 && gx < W && gy >= 0 && gy < H) ? gy * W + gx : -1;  // (a frame has < 2^31 pixels)
+    };
+    auto gindex = [&](int x0, int i) {
+        int gx, gy;
+        return gindex_xy(x0, i, gx, gy);
     };
     auto fetch = [&](int tile, Fetched& f) {
         const int x0 = tile * kFastW - L, px = tile * kFastW + lx;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const int gi = gindex(x0, i);
+            int gx, gy;
+            const int gi = gindex_xy(x0, i, gx, gy);
             if constexpr (PACKED) {
                 f.rgb[i] = gi >= 0 ? img_in[gi] : make_float4(0.f, 0.f, 0.f, 0.f);
                 f.hg[i] = half4_t{0, 0, 0, 0};
                 if (gi >= 0) f.hg[i] = *reinterpret_cast<const half4_t*>(packed + (int64_t)gi * 8 + 4);
+                if (cull.sparse && gi >= 0) {  // (loaded whatever the address holds, then replaced: no dependent round trip)
+                    if (!pixel_stored(gx, gy)) f.rgb[i] = make_float4(cull.bg, cull.bg, cull.bg, 0.f);
+                    if (!maps_stored(gx, gy)) f.hg[i] = __builtin_bit_cast(half4_t, make_uint2(cull.fill_maps.z, cull.fill_maps.w));
+                }
             } else {
                 if (tid + i * 256 < NE) s_rgb[tid + i * 256] = gi >= 0 ? img_in[gi] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -547,6 +615,7 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
             if constexpr (PACKED) {
                 f.hw[r] = half4_t{0, 0, 0, 0};
                 if (in) f.hw[r] = *reinterpret_cast<const half4_t*>(packed + ((int64_t)(py0 + r) * W + px) * 8);
+                if (cull.sparse && in && !maps_stored(px, py0 + r)) f.hw[r] = __builtin_bit_cast(half4_t, make_uint2(cull.fill_maps.x, cull.fill_maps.y));
             } else {
 #pragma unroll
                 for (int l = 0; l < L; ++l) f.wl[l][r] = in ? weight[l * HW + (int64_t)(py0 + r) * W + px] : 0.f;
@@ -752,7 +821,9 @@ static int fast_strip_for(int tiles_x, int tiles_y, int n) {
 }
 
 hipError_t launch_filter_fast_packed(const void* packed_maps, int H, int W, int n, const float* img_in, float* img_out,
-                                     const uint32_t* tile_mask, int mask_words, const float* fill_tile, hipStream_t stream) {
+                                     const uint32_t* tile_mask, int mask_words, const float* fill_tile, int sparse, float background,
+                                     const uint32_t* fill_maps, hipStream_t stream) {
+    if (sparse && (!tile_mask || !fill_maps)) return hipErrorInvalidValue;
     const int tiles_x = (W + kFastW - 1) / kFastW, tiles_y = (H + kFastH - 1) / kFastH, strip = fast_strip_for(tiles_x, tiles_y, n);
     // (grid.x such that ceil(tiles_x / grid.x) == the strip the kernel derives: ceil(tiles_x / strip) workgroups per tile row)
     const dim3 grid((tiles_x + strip - 1) / strip, tiles_y, n), block(256);
@@ -762,6 +833,9 @@ hipError_t launch_filter_fast_packed(const void* packed_maps, int H, int W, int 
     cull.mask_words = mask_words;
     cull.tiles_x = (W + 7) / 8;
     cull.fill = reinterpret_cast<const float4*>(fill_tile);
+    cull.sparse = sparse ? 1 : 0;
+    cull.bg = background;
+    cull.fill_maps = sparse ? make_uint4(fill_maps[0], fill_maps[1], fill_maps[2], fill_maps[3]) : make_uint4(0u, 0u, 0u, 0u);
     hipLaunchKernelGGL((filter_fast<4, true>), grid, block, lds, stream, reinterpret_cast<const float*>(packed_maps),
                        (const float*)nullptr, reinterpret_cast<const float4*>(img_in), reinterpret_cast<float4*>(img_out), H, W, cull);
     return hipGetLastError();
@@ -800,13 +874,13 @@ static hipError_t launch_filter_impl(const float* weight, const float* guidance,
 
 hipError_t launch_filter(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
                          float* img_out, hipStream_t stream) {
-    return launch_filter_impl(weight, guidance, L, H, W, n, img_in, img_out, nullptr, nullptr, nullptr, FilterCull{nullptr, 0, 0, nullptr}, stream);
+    return launch_filter_impl(weight, guidance, L, H, W, n, img_in, img_out, nullptr, nullptr, nullptr, FilterCull{nullptr, 0, 0, nullptr, 0, 0.f, make_uint4(0u, 0u, 0u, 0u)}, stream);
 }
 
 hipError_t launch_filter_culled(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,
                                 float* img_out, const uint32_t* tile_mask, int mask_words, const float* fill_tile, hipStream_t stream) {
     return launch_filter_impl(weight, guidance, L, H, W, n, img_in, img_out, nullptr, nullptr, nullptr,
-                              FilterCull{tile_mask, mask_words, (W + 7) / 8, reinterpret_cast<const float4*>(fill_tile)}, stream);
+                              FilterCull{tile_mask, mask_words, (W + 7) / 8, reinterpret_cast<const float4*>(fill_tile), 0, 0.f, make_uint4(0u, 0u, 0u, 0u)}, stream);
 }
 
 // rgb_filtered == nullptr: inference forward; else all three save arrays are written too
@@ -814,7 +888,7 @@ hipError_t launch_filter_train(const float* weight, const float* guidance, int L
                                const float* img_in, float* img_out, float* rgb_filtered, float* max_map,
                                float* inv_kernel_sum, hipStream_t stream) {
     return launch_filter_impl(weight, guidance, L, H, W, n, img_in, img_out, rgb_filtered, max_map, inv_kernel_sum,
-                              FilterCull{nullptr, 0, 0, nullptr}, stream);
+                              FilterCull{nullptr, 0, 0, nullptr, 0, 0.f, make_uint4(0u, 0u, 0u, 0u)}, stream);
 }
 
 static hipError_t launch_filter_impl(const float* weight, const float* guidance, int L, int H, int W, int n, const float* img_in,

@@ -56,6 +56,11 @@ struct NetCull {
     int mask_words, tiles_x;
     uint4 fill;      // PACK: the 8 fp16 outputs of a pixel whose 5x5 aux neighbourhood is background
     float planes[8]; // otherwise: the same as 4 softmax weights + 4 guidance values
+    // SPARSE lean frames (round 6, rto_ctx_set_lean_outputs level 2; IN = 2, PACK): the renderer stored no pixel of an unmarked
+    // (culled) render tile -- such a pixel IS the background (bg, bg, bg, alpha 0), so the staging loop substitutes it -- and
+    // this kernel stores no maps for the tiles it skips: the filter substitutes `fill` for them the same way
+    int sparse;
+    float bg;
 };
 
 // C1 = mid channels (multiple of 16, <= 64), L = kernel levels (2L <= 16)
@@ -187,10 +192,16 @@ __global__ void __launch_bounds__(256, IN ? 4 : RTO_NET_SQ0_WG) guidance_fused(c
             const int gi = in ? gy * W + gx : 0;  // (8 * H * W < 2^31: rto_ctx_create's size check)
             if constexpr (IN == 2) {
                 const float4 t = reinterpret_cast<const float4*>(aux)[gi];
-                v[it][0] = in ? t.x : 0.f;
-                v[it][1] = in ? t.y : 0.f;
-                v[it][2] = in ? t.z : 0.f;
-                v[it][3] = in ? t.w : 0.f;
+                bool stored = true;  // (sparse: the pixel's render tile is marked, i.e. the shading kernel wrote it)
+                if (cull.sparse) {
+                    const uint32_t* fm = cull.mask + (size_t)blockIdx.z * cull.mask_words;
+                    const uint32_t rt = in ? (uint32_t)((gy >> 3) * cull.tiles_x + (gx >> 3)) : 0u;
+                    stored = (((fm[rt >> 5] >> (rt & 31u)) | fm[cull.mask_words - 1]) & 1u) != 0u;
+                }
+                v[it][0] = in ? (stored ? t.x : cull.bg) : 0.f;
+                v[it][1] = in ? (stored ? t.y : cull.bg) : 0.f;
+                v[it][2] = in ? (stored ? t.z : cull.bg) : 0.f;
+                v[it][3] = in ? (stored ? t.w : 0.f) : 0.f;
             } else {
 #pragma unroll
                 for (int c = 0; c < NLD; ++c) {
@@ -204,7 +215,7 @@ __global__ void __launch_bounds__(256, IN ? 4 : RTO_NET_SQ0_WG) guidance_fused(c
     unsigned long long st[8];
     st[0] = __builtin_amdgcn_s_memtime();
 #endif
-    if (cull.mask) {  // the skipped tiles first (interior tiles: every pixel of them is inside the image)
+    if (cull.mask && !(PACK && cull.sparse)) {  // the skipped tiles first (interior tiles: every pixel of them is inside the image)
         for (int ts = 0; ts < kStrip && tx_first + ts < tiles_x; ++ts)
             if ((skip_tiles >> ts) & 1u) {
                 const int64_t pix = (int64_t)(y0 + (tid >> 5)) * W + (tx_first + ts) * kGW + (tid & 31);
@@ -418,7 +429,7 @@ __global__ void __launch_bounds__(256, IN ? 4 : RTO_NET_SQ0_WG) guidance_fused(c
 hipError_t launch_guidance_net(const float* aux, const void* w1, const void* w2, const float* b2, int c1,
                                int levels, int n, int H, int W, float* weight_out, float* guidance_out,
                                int in_mode, const uint32_t* tile_mask, int mask_words, const uint32_t* fill_k,
-                               const float* fill_planes, hipStream_t stream) {
+                               const float* fill_planes, int sparse, float background, hipStream_t stream) {
     if (c1 != 32 || levels != 4 || in_mode < 0 || in_mode > 2) return hipErrorInvalidValue;  // the reference configuration (blender.txt:21-25)
     const int tiles_x = (W + kGW - 1) / kGW;
     const dim3 grid((tiles_x + kStrip - 1) / kStrip, (H + kGH - 1) / kGH, n), block(256);
@@ -429,6 +440,9 @@ hipError_t launch_guidance_net(const float* aux, const void* w1, const void* w2,
     cull.tiles_x = (W + 7) / 8;
     cull.fill = cull.mask && pack ? make_uint4(fill_k[0], fill_k[1], fill_k[2], fill_k[3]) : make_uint4(0u, 0u, 0u, 0u);
     for (int i = 0; i < 8; ++i) cull.planes[i] = cull.mask && !pack ? fill_planes[i] : 0.f;
+    cull.sparse = sparse && cull.mask && pack && in_mode == 2 ? 1 : 0;
+    if (sparse && !cull.sparse) return hipErrorInvalidValue;  // (sparse frames come with tile marks, as the RGBA image, on the packed route)
+    cull.bg = background;
 #define RTO_NET(IN, PK)                                                                                                   \
     hipLaunchKernelGGL((guidance_fused<32, 4, IN, PK>), grid, block, 0, stream, aux, (const _Float16*)w1, (const _Float16*)w2,     \
                        b2, weight_out, guidance_out, H, W, cull)

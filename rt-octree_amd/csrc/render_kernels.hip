@@ -1774,14 +1774,37 @@ RTO_DEV void leaf_contrib(const TreeDev& tree, uint32_t slot, const float* basis
 #define RTO_SHADE_WPS_SH25 3
 #endif
 constexpr int shade_wps(int mode) { return (mode == 76 || mode == -25 || mode == -16) ? RTO_SHADE_WPS_SH25 : RTO_SHADE_WPS; }
+#ifdef RTO_DBG_COUNTERS
+// where a shading wave's lifetime goes (tools/dbg_shade_phases.py): per wave (blockIdx.x * 4 + wave, up to 2^19 of them) the s_memtime
+// stamps 0..5 and its number of hit entries; plain stores, reduced on the host (atomics would slow the very kernel they time)
+constexpr int kShadeStampWaves = 1 << 19;
+__device__ unsigned long long g_shade_phase[kShadeStampWaves * 8];
+#define RTO_SHADE_STAMP(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ph[i] = __builtin_amdgcn_s_memtime(); }
+#else
+#define RTO_SHADE_STAMP(i) {}
+#endif
+// Waves per workgroup: ONE (round 6).  The waves of this kernel never talk to each other (wave-level barriers only), and their
+// lifetimes differ by a factor of eight -- a wave over culled tiles ends after ~7 k clocks, one with 500 hit entries after ~58 k
+// (tools/dbg_shade_phases.py, profiles/r6_d_shade_phases.txt) -- but a workgroup's LDS and wave slots are released only when its
+// LAST wave ends: with 4 waves per workgroup the SIMDs held 2.9 waves of the 4 they have room for.
+#ifndef RTO_SHADE_WG_WAVES
+#define RTO_SHADE_WG_WAVES 1
+#endif
+constexpr int kShadeWaves = RTO_SHADE_WG_WAVES;
 template <int SPP, int P, int MODE>
-__global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeDev tree, const OptDev opt, const FrameBatch fb) {
-    __shared__ uint32_t s_h[4][kShadeCap];       // packed hit entry
-    __shared__ uint16_t s_q[4][kShadeCap];       // its pixel, relative to the wave's first pixel
-    __shared__ float s_c[4][3 * kShadeCap];      // its contribution, [channel][entry]
+__global__ void __launch_bounds__(64 * kShadeWaves, shade_wps(MODE)) shade_kernel(const TreeDev tree, const OptDev opt, const FrameBatch fb,
+                                                                              const uint32_t* __restrict__ hits0) {
+    __shared__ uint32_t s_h[kShadeWaves][kShadeCap];       // packed hit entry
+    __shared__ uint16_t s_q[kShadeWaves][kShadeCap];       // its pixel, relative to the wave's first pixel
+    __shared__ float s_c[kShadeWaves][3 * kShadeCap];      // its contribution, [channel][entry]
     const int W = fb.width, H = fb.height;
     const int64_t SIZE = (int64_t)W * H;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#ifdef RTO_DBG_COUNTERS
+    unsigned long long ph[8];
+    for (int i = 0; i < 8; ++i) ph[i] = 0;
+    RTO_SHADE_STAMP(0)
+#endif
     // Workgroup -> (pixel block, frame), XCD-aware: workgroups go round-robin over the 8 XCDs, so id & 7
     // picks the XCD; the same pixel block of ALL frames of the batch lands on one XCD, frame after frame.
     // Neighbouring poses hit the same leaves there, so a leaf's SH record is fetched from HBM once per
@@ -1790,15 +1813,17 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
     const uint32_t bid = blockIdx.x, q = bid >> 3;
     const uint32_t frame = q % (uint32_t)fb.n;
     const uint32_t pblock = (q / (uint32_t)fb.n) * 8u + (bid & 7u);
-    const int64_t wave_px0 = ((int64_t)pblock * 4 + wv) * (64 * P);
+    const int64_t wave_px0 = ((int64_t)pblock * kShadeWaves + wv) * (64 * P);
     if (wave_px0 >= SIZE) return;  // wave-uniform
     const FrameDesc& fd = fb.f[frame];  // block-uniform index: scalar loads
-    const RTO_GLOBAL uint32_t* const fhits = as_global((const uint32_t*)fd.hits);
+    // (the frame's hand-off lists: from the launch's base, not from the frame table -- a wave's first loads then depend on its
+    //  kernel arguments only; a shading wave spends a fifth of its life before its hit lists have arrived, profiles/r6_d_shade_phases.txt)
+    const RTO_GLOBAL uint32_t* const fhits = as_global(hits0) + (size_t)frame * (size_t)SPP * (size_t)SIZE;
 
     // ---- each lane: the hit lists of its P pixels (pixel p*64 + lane of the wave: coalesced)
     uint32_t h[P][SPP];
     uint32_t n[P];
-    uint32_t mine = 0;
+    uint32_t mine = 0, live_bits = 0;  // bit p: pixel p of this lane lies in a marked tile
     // A pixel of a culled tile has no hit list (nobody wrote one: sample_kernel, render_persist): it is read off the tile
     // marks, a few hundred cached words per frame, instead of 4 * SPP bytes per pixel of stale memory -- two thirds of the
     // pixels of the bench scene.  (x, y) of the wave's first pixel by one wave-uniform division, the lanes' by carries.
@@ -1811,15 +1836,16 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
         const int64_t idx = wave_px0 + p * 64 + lane;
         n[p] = 0;
         bool live = idx < SIZE;
-        if (live && !keep_all) {
+        if (live && fmask) {  // (the mark word is requested before the frame's keep-all flag is back: no dependent second trip)
             int x = wx0 + p * 64 + lane, y = wy0;
             while (x >= W) {
                 x -= W;
                 ++y;
             }
             const uint32_t t = (uint32_t)((y >> 3) * tiles_x + (x >> 3));
-            live = ((fmask[t >> 5] >> (t & 31u)) & 1u) != 0u;
+            live = (((fmask[t >> 5] >> (t & 31u)) | keep_all) & 1u) != 0u;
         }
+        live_bits |= live ? 1u << p : 0u;
         if (live) {
             bool open = true;
             // the first entry from its dense plane, the run behind it (fetched eagerly: fetching the run only for a pixel whose
@@ -1846,6 +1872,7 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
         if (lane >= d) inc += t;
     }
     const uint32_t total = __shfl(inc, 63, 64);
+    RTO_SHADE_STAMP(1)  // tile marks + hit lists are here (the prefix sum consumed them)
     uint32_t start[P];
     {
         uint32_t sacc = inc - mine;
@@ -1884,6 +1911,7 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- one entry per lane
+        RTO_SHADE_STAMP(2)  // (last window's) entries published
         const uint32_t cnt_w = min(total - w0, (uint32_t)kShadeCap);
         for (uint32_t j = lane; j < cnt_w; j += 64) {
             const uint32_t he = s_h[wv][j];
@@ -1897,6 +1925,9 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
             float dir[3], vdir[3], cen[3];
             ray_setup(x, y, cam, tree, dir, vdir, cen);  // only vdir is needed (rt_core.cuh:278)
             float basis_fn[RTO_BASIS_MAX_DEV];
+            // (view direction + basis once per hit PIXEL, parked in LDS, removes ~200 of these ~430 instructions per entry and was
+            //  built twice -- round 4 and round 6, tools/experiments/r6_shade_basis_table.patch -- and lost both times: 1.54 vs
+            //  1.48 ms on C2, 1.24 vs 1.02 on C5: this arithmetic runs while the entry's record is in flight and costs nothing)
             if constexpr (MODE > 0)  // (the launcher picks MODE from the tree: SH, data_dim = MODE)
                 ray_basis_sh<(MODE - 1) / 3>(opt, vdir, basis_fn);
             else if constexpr (MODE < 0)  // quantised SH tree, -MODE basis functions
@@ -1913,6 +1944,7 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- pixel lanes add their entries up, in hit order
+        RTO_SHADE_STAMP(3)  // (last window's) entries shaded
 #pragma unroll
         for (int p = 0; p < P; ++p) {
 #pragma unroll
@@ -1930,6 +1962,7 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
         __builtin_amdgcn_wave_barrier();
     }
 
+    RTO_SHADE_STAMP(4)  // sums done
     RTO_GLOBAL float* const g_aux = as_global(fd.aux);
     typedef float f4_t __attribute__((ext_vector_type(4)));  // (HIP's float4 has no assignment across address spaces)
     RTO_GLOBAL f4_t* const g_image = (RTO_GLOBAL f4_t*)as_global(fd.image);
@@ -1949,7 +1982,8 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
         const float remain = opt.background_brightness * (1.f - out[p][3]);
         const float r = out[p][0] + remain, g = out[p][1] + remain, b = out[p][2] + remain, al = out[p][3];
         if (fb.lean) {
-            g_image[idx] = f4_t{r, g, b, al};
+            // (sparse, level 2: nothing for a pixel of an unmarked tile -- it is the background and its consumers know it)
+            if (fb.lean == 1 || ((live_bits >> p) & 1u)) g_image[idx] = f4_t{r, g, b, al};
         } else {
             RTO_GLOBAL float* a = g_aux + idx;
             a[0] = r;
@@ -1963,6 +1997,16 @@ __global__ void __launch_bounds__(256, shade_wps(MODE)) shade_kernel(const TreeD
             g_image[idx] = f4_t{r, g, b, 1.0f};
         }
     }
+#ifdef RTO_DBG_COUNTERS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left
+    RTO_SHADE_STAMP(5)
+    if (lane == 0 && blockIdx.x * (uint32_t)kShadeWaves + (uint32_t)wv < (uint32_t)kShadeStampWaves) {
+        unsigned long long* o = g_shade_phase + (size_t)(blockIdx.x * (uint32_t)kShadeWaves + (uint32_t)wv) * 8;
+        for (int i = 0; i <= 5; ++i) o[i] = ph[i];
+        o[6] = total;
+        o[7] = 1;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------ frame table
@@ -2185,9 +2229,9 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
 #define RTO_SHADE_P 2
 #endif
     constexpr int SP = SPP <= 8 ? RTO_SHADE_P : 1;  // pixels per lane of the shading kernel (its hit lists live in registers)
-    const unsigned pblocks = (unsigned)((size + 256 * SP - 1) / (256 * SP));
+    const unsigned pblocks = (unsigned)((size + 64 * kShadeWaves * SP - 1) / (64 * kShadeWaves * SP));
     const dim3 sgrid(((pblocks + 7u) / 8u) * 8u * (unsigned)fb.n);  // see shade_kernel: (pixel block, frame) <- block id
-#define RTO_SHADE(M) hipLaunchKernelGGL((shade_kernel<SPP, SP, M>), sgrid, dim3(256), 0, stream, tree, opt, fb)
+#define RTO_SHADE(M) hipLaunchKernelGGL((shade_kernel<SPP, SP, M>), sgrid, dim3(64 * kShadeWaves), 0, stream, tree, opt, fb, (const uint32_t*)hits)
     if (tree.qrec) {  // (the host admits SH4/9/16/25 only)
         if (tree.basis_dim == 4)
             RTO_SHADE(-4);
@@ -2271,6 +2315,18 @@ hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, 
         default: return hipErrorInvalidValue;
     }
 }
+
+#ifdef RTO_DBG_COUNTERS
+hipError_t debug_shade_phases(unsigned long long* out, bool reset) {  // out: kShadeStampWaves * 8 words
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_shade_phase), sizeof(unsigned long long) * kShadeStampWaves * 8);
+    if (e == hipSuccess && reset) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_shade_phase));
+        if (e == hipSuccess) e = hipMemset(p, 0, sizeof(unsigned long long) * kShadeStampWaves * 8);
+    }
+    return e;
+}
+#endif
 
 hipError_t launch_write_frames(const FrameDesc* host, int n, FrameDesc* dev_table, hipStream_t stream) {
     for (int f0 = 0; f0 < n; f0 += kFrameChunk) {

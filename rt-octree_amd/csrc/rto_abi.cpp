@@ -138,8 +138,9 @@ struct rto_ctx {
     int last_n_queues = 0;                // of the last batched launch (rto_ctx_queue_stats)
     int64_t last_slots = 0;
     int batch_fallback = 0;               // tuning / test hook, see rto_ctx_set_tuning
-    bool lean = false;                    // rto_ctx_set_lean_outputs
-    std::vector<uint8_t> lean_slot;       // per frame slot: 1 = its last writer was a lean launch (no aux planes, noisy.a = alpha)
+    int lean = 0;                         // rto_ctx_set_lean_outputs: 0 full, 1 lean, 2 lean + sparse
+    std::vector<uint8_t> lean_slot;       // per frame slot: the level of its last writer (1: no aux planes, noisy.a = alpha; 2: and
+                                          // nothing stored for the pixels of unmarked tiles)
     int test_wide_bits = 0;               // test hook "wide_bits": pretend a hit entry has this many bits for an entry of the two-level image
     bool cull_single = false;             // tuning "cull_single": the single-frame kernel culls too.  Off by default: a LONE frame waits
                                           // for its longest rays (marked tiles), and the two extra launches cost it 14 us (0.375 ->
@@ -643,6 +644,10 @@ int upload_tree(const int32_t* child, const uint16_t* data, int64_t capacity, in
         // (6 levels: measured again in round 3 with 7 waves per SIMD -- 5 levels 7.1-7.25 ms per 100 frames, 6: 6.88-7.0,
         //  7 (16 MB): 6.85-6.96, 8 (134 MB): 6.93-6.99)
         top_levels = max_depth - 1 < 6 ? max_depth - 1 : 6;
+        if (const char* ev = getenv("RTO_TOP_LEVELS")) {  // (A/B hook: levels the top grid covers, 3..8; same pixels for every value)
+            const int g = atoi(ev);
+            if (g >= 3 && g <= 8 && g <= max_depth - 1) top_levels = g;
+        }
         const size_t gbytes = (size_t)8 << (3 * top_levels);
         if (hipMalloc(&t->d_topgrid, gbytes) != hipSuccess) return fail(RTO_E_HIP, "hipMalloc(topgrid) failed");
         hipError_t e = rto::launch_build_topgrid((const uint32_t*)t->d_nodew, top_levels, (uint2*)t->d_topgrid, nullptr);
@@ -1304,6 +1309,9 @@ extern "C" int rto_debug_read_queue(rto_ctx* c, uint64_t out[24]) {
     return hipMemcpy(out, c->queue, 24 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -4;
 }
 extern "C" int rto_debug_zero_queue(rto_ctx* c) { return hipMemset(c->queue + 2, 0, 48) == hipSuccess ? 0 : -4; }
+extern "C" int rto_debug_shade_phases(uint64_t* out /* 2^19 waves x 8 words */, int reset) {
+    return rto::debug_shade_phases((unsigned long long*)out, reset != 0) == hipSuccess ? 0 : -4;
+}
 #endif
 
 // Host-only check of the two-level traversal image (no device needed): builds it for child[] (breadth-first node order) and
@@ -1353,10 +1361,19 @@ int rto_wide_image_probe(const int32_t* child, const uint16_t* sigma_bits, int64
     return RTO_OK;
 }
 
-int rto_ctx_set_lean_outputs(rto_ctx* c, int on) {
+int rto_ctx_set_lean_outputs(rto_ctx* c, int level) {
     if (!c) return set_err(RTO_E_INVALID, "rto_ctx_set_lean_outputs: null context");
-    c->lean = on != 0;
+    if (level < 0 || level > 2) return set_err(RTO_E_INVALID, "rto_ctx_set_lean_outputs: level 0 (full), 1 (lean) or 2 (lean + sparse)");
+    c->lean = level;
     return RTO_OK;
+}
+
+int rto_ctx_frames_lean_level(const rto_ctx* c, int first_slot, int n) {
+    if (!c || n < 1 || first_slot < 0 || first_slot + n > c->frames) return 0;
+    const int l0 = c->lean_slot[(size_t)first_slot];
+    for (int i = first_slot + 1; i < first_slot + n; ++i)
+        if (c->lean_slot[(size_t)i] != l0) return -1;
+    return l0;
 }
 
 int rto_ctx_frames_are_lean(const rto_ctx* c, int first_slot, int n) {
@@ -1761,7 +1778,7 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     const size_t px = frame_px(ctx);
     rto::FrameDesc frames[rto::kMaxBatch];
     fb.f = ctx->d_frames;
-    fb.lean = ctx->lean && o->denoise ? 1 : 0;
+    fb.lean = o->denoise ? ctx->lean : 0;
     for (int f = 0; f < n; ++f) {
         if (cams[f].width != ctx->width || cams[f].height != ctx->height)
             return set_err(RTO_E_INVALID, "camera size does not match the render context");
@@ -1804,7 +1821,7 @@ static int launch_batch_at(const rto_tree* tree, const rto_camera* cams, const i
     ctx->marks_slot0 = slot0;
     ctx->marks_bg = o->background_brightness;
     if (fb.lean)
-        for (int f = 0; f < n; ++f) ctx->lean_slot[(size_t)(slot0 + f)] = 1;
+        for (int f = 0; f < n; ++f) ctx->lean_slot[(size_t)(slot0 + f)] = (uint8_t)fb.lean;
     return RTO_OK;
 }
 
@@ -1888,6 +1905,36 @@ int rto_ctx_filtering(rto_ctx* c, void* stream, const float* weight_map, const f
     return rto_filtering(stream, weight_map, guidance_map, L, c->height, c->width, rto_ctx_noisy(c), rto_ctx_image(c));
 }
 
+// The noisy image of a SPARSE lean frame holds nothing in the tiles its launch left unmarked: they are the background (colour =
+// the launch's background brightness, alpha 0 -- a lean frame's alpha is aux plane 3).  Filled in on the host after the copy,
+// from the marks the launch left on the device; T = float (x4 per pixel) or uint8_t (the truncated bytes, main_headless.cpp:535-538).
+}  // extern "C"
+template <class T>
+static int fill_unmarked_tiles(rto_ctx* c, hipStream_t stream, T* host, T colour) {
+    if (c->lean_slot[(size_t)c->sel] != 2) return RTO_OK;
+    if (c->marks_n < 1 || !c->tile_mask || c->sel < c->marks_slot0 || c->sel >= c->marks_slot0 + c->marks_n)
+        return set_err(RTO_E_INVALID, "the selected slot holds a sparse lean frame whose tile marks a later launch replaced: its noisy image "
+                                      "cannot be completed");
+    std::vector<uint32_t> m((size_t)c->mask_words);
+    HIP_TRY(hipMemcpyAsync(m.data(), c->tile_mask + (size_t)(c->sel - c->marks_slot0) * c->mask_words, m.size() * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (m.back() & 1u) return RTO_OK;  // keep-all frame: every tile was rendered
+    const int tx_n = (c->width + 7) / 8, ty_n = (c->height + 7) / 8;
+    for (int ty = 0; ty < ty_n; ++ty)
+        for (int tx = 0; tx < tx_n; ++tx) {
+            const uint32_t t = (uint32_t)(ty * tx_n + tx);
+            if ((m[t >> 5] >> (t & 31u)) & 1u) continue;
+            for (int y = ty * 8; y < std::min(ty * 8 + 8, c->height); ++y)
+                for (int x = tx * 8; x < std::min(tx * 8 + 8, c->width); ++x) {
+                    T* p = host + ((size_t)y * c->width + x) * 4;
+                    p[0] = p[1] = p[2] = colour;
+                    p[3] = T(0);
+                }
+        }
+    return RTO_OK;
+}
+extern "C" {
+
 int rto_ctx_download_rgba8(rto_ctx* c, void* stream_, int which, uint8_t* host_out) {
     if (!c || !host_out) return set_err(RTO_E_INVALID, "rto_ctx_download_rgba8: null argument");
     DeviceGuard guard(c->device);
@@ -1896,6 +1943,7 @@ int rto_ctx_download_rgba8(rto_ctx* c, void* stream_, int which, uint8_t* host_o
     HIP_TRY(rto::launch_rgba8(which ? rto_ctx_noisy(c) : rto_ctx_image(c), c->rgba8, px, stream));
     HIP_TRY(hipMemcpyAsync(host_out, c->rgba8, (size_t)px * 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    if (which) return fill_unmarked_tiles<uint8_t>(c, stream, host_out, (uint8_t)(c->marks_bg * 255));
     return RTO_OK;
 }
 
@@ -1906,6 +1954,7 @@ int rto_ctx_download_image(rto_ctx* c, void* stream_, int which, float* host_out
     const size_t bytes = (size_t)c->width * c->height * 4 * sizeof(float);
     HIP_TRY(hipMemcpyAsync(host_out, which ? rto_ctx_noisy(c) : rto_ctx_image(c), bytes, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    if (which) return fill_unmarked_tiles<float>(c, stream, host_out, c->marks_bg);
     return RTO_OK;
 }
 

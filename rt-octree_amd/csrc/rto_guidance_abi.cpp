@@ -24,6 +24,7 @@ struct rto_guidance_net {
     std::mutex fill_mu;
     float* fill_tile = nullptr;  // device [32][32][4] (factorised filter) then [8][32][4] (exact filter)
     float fill_planes[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // the background maps as fp32 planes hold them: 4 softmax weights, 4 guidance values
+    bool packed_sparse = false;  // the packed maps hold nothing for the tiles the network skipped (RTO_NET_INPUT_SPARSE)
     uint32_t fill_k[4] = {0, 0, 0, 0};  // ... and the network's 8 fp16 outputs for a pixel whose neighbourhood is background
     float fill_bg = 0.f;
     bool fill_valid = false;
@@ -110,7 +111,7 @@ int rto_guidance_net_forward_ex(const rto_guidance_net* net, void* stream, const
         return fail(RTO_E_INVALID, "rto_guidance_net_forward: bad argument");
     DeviceScope scope(net->device);
     const hipError_t e = rto::launch_guidance_net(aux, net->w1, net->w2, net->b2, net->c1, net->levels, n, H, W,
-                                                  weight_map, guidance_map, net_in_mode(flags), nullptr, 0, nullptr, nullptr,
+                                                  weight_map, guidance_map, net_in_mode(flags), nullptr, 0, nullptr, nullptr, 0, 0.f,
                                                   (hipStream_t)stream);
     if (e != hipSuccess) return fail(RTO_E_HIP, std::string("GuidanceNet launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
@@ -169,10 +170,15 @@ int rto_guidance_net_forward_packed_culled(rto_guidance_net* net, void* stream, 
         if (const int rc = check_marks("rto_guidance_net_forward_packed_culled", net, tile_marks, words_per_frame, H, W)) return rc;
         if (const int rc = ensure_fill_tile(net, background, (hipStream_t)stream)) return rc;
     }
+    const bool sparse = (flags & RTO_NET_INPUT_SPARSE) != 0;
+    if (sparse && (!tile_marks || !(flags & RTO_NET_INPUT_RGBA)))
+        return fail(RTO_E_INVALID, "rto_guidance_net_forward_packed_culled: RTO_NET_INPUT_SPARSE needs the tile marks of the launch and RTO_NET_INPUT_RGBA");
     const hipError_t e = rto::launch_guidance_net(aux, net->w1, net->w2, net->b2, net->c1, net->levels, n, H, W,
                                                   (float*)net->packed, nullptr, net_in_mode(flags),
-                                                  tile_marks, words_per_frame, tile_marks ? net->fill_k : nullptr, nullptr, (hipStream_t)stream);
+                                                  tile_marks, words_per_frame, tile_marks ? net->fill_k : nullptr, nullptr, sparse ? 1 : 0, background,
+                                                  (hipStream_t)stream);
     if (e != hipSuccess) return fail(RTO_E_HIP, std::string("GuidanceNet launch failed: ") + hipGetErrorString(e));
+    net->packed_sparse = sparse;
     net->packed_n = n;
     net->packed_h = H;
     net->packed_w = W;
@@ -194,9 +200,12 @@ int rto_filtering_packed(const rto_guidance_net* net, void* stream, const float*
                                        std::to_string(net->packed_h) + " x " + std::to_string(net->packed_w));
     if (pointer_device(img_out) != net->device || pointer_device(img_in) != net->device)
         return fail(RTO_E_INVALID, "rto_filtering_packed: the images are not memory of the network's device");
+    if (net->packed_sparse)
+        return fail(RTO_E_INVALID, "rto_filtering_packed: the packed maps are sparse (RTO_NET_INPUT_SPARSE): the filter needs the same tile marks "
+                                   "(rto_filtering_packed_culled)");
     DeviceScope scope(net->device);
     const hipError_t e = rto::launch_filter_fast_packed(net->packed, net->packed_h, net->packed_w, net->packed_n, img_in, img_out,
-                                                        nullptr, 0, nullptr, (hipStream_t)stream);
+                                                        nullptr, 0, nullptr, 0, 0.f, nullptr, (hipStream_t)stream);
     if (e != hipSuccess) return fail(RTO_E_HIP, std::string("filter launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
 }
@@ -234,14 +243,14 @@ static int ensure_fill_tile(rto_guidance_net* net, float bg, hipStream_t stream)
         !ok(hipMalloc((void**)&d_out, img.size() * sizeof(float))) || !ok(hipMalloc(&d_maps, px * 8 * sizeof(uint16_t))) ||
         !ok(hipMemcpyAsync(d_aux, aux.data(), aux.size() * sizeof(float), hipMemcpyHostToDevice, stream)) ||
         !ok(hipMemcpyAsync(d_img, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, stream)) ||
-        !ok(rto::launch_guidance_net(d_aux, net->w1, net->w2, net->b2, net->c1, net->levels, 1, S, S, (float*)d_maps, nullptr, false, nullptr, 0, nullptr, nullptr, stream)) ||
-        !ok(rto::launch_filter_fast_packed(d_maps, S, S, 1, d_img, d_out, nullptr, 0, nullptr, stream)) ||
+        !ok(rto::launch_guidance_net(d_aux, net->w1, net->w2, net->b2, net->c1, net->levels, 1, S, S, (float*)d_maps, nullptr, false, nullptr, 0, nullptr, nullptr, 0, 0.f, stream)) ||
+        !ok(rto::launch_filter_fast_packed(d_maps, S, S, 1, d_img, d_out, nullptr, 0, nullptr, 0, 0.f, nullptr, stream)) ||
         !ok(hipMemcpy2DAsync(net->fill_tile, (size_t)T * 4 * sizeof(float), d_out + ((size_t)T * S + T) * 4, (size_t)S * 4 * sizeof(float),
                              (size_t)T * 4 * sizeof(float), T, hipMemcpyDeviceToDevice, stream)) ||
         !ok(hipMemcpyAsync(net->fill_k, (const char*)d_maps + ((size_t)(S / 2) * S + S / 2) * 16, 16, hipMemcpyDeviceToHost, stream)) ||
         // the same through fp32 planes and the exact filter (rto_guidance_net_forward_culled / rto_filtering_culled)
         !ok(hipMalloc((void**)&d_w, 4 * px * sizeof(float))) || !ok(hipMalloc((void**)&d_g, 4 * px * sizeof(float))) ||
-        !ok(rto::launch_guidance_net(d_aux, net->w1, net->w2, net->b2, net->c1, net->levels, 1, S, S, d_w, d_g, false, nullptr, 0, nullptr, nullptr, stream)) ||
+        !ok(rto::launch_guidance_net(d_aux, net->w1, net->w2, net->b2, net->c1, net->levels, 1, S, S, d_w, d_g, false, nullptr, 0, nullptr, nullptr, 0, 0.f, stream)) ||
         !ok(rto::launch_filter(d_w, d_g, net->levels, S, S, 1, d_img, d_out, stream)) ||
         !ok(hipMemcpy2DAsync(net->fill_tile + (size_t)T * T * 4, (size_t)T * 4 * sizeof(float), d_out + ((size_t)YE * S + T) * 4,
                              (size_t)S * 4 * sizeof(float), (size_t)T * 4 * sizeof(float), TE, hipMemcpyDeviceToDevice, stream)) ||
@@ -276,7 +285,8 @@ int rto_filtering_packed_culled(rto_guidance_net* net, void* stream, const float
     DeviceScope scope(net->device);
     if (const int rc = ensure_fill_tile(net, background, (hipStream_t)stream)) return rc;
     const hipError_t e = rto::launch_filter_fast_packed(net->packed, net->packed_h, net->packed_w, net->packed_n, img_in, img_out,
-                                                        tile_marks, words_per_frame, net->fill_tile, (hipStream_t)stream);
+                                                        tile_marks, words_per_frame, net->fill_tile, net->packed_sparse ? 1 : 0, background,
+                                                        net->fill_k, (hipStream_t)stream);
     if (e != hipSuccess) return fail(RTO_E_HIP, std::string("filter launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
 }
@@ -291,7 +301,7 @@ int rto_guidance_net_forward_culled(rto_guidance_net* net, void* stream, const f
     if (const int rc = ensure_fill_tile(net, background, (hipStream_t)stream)) return rc;
     const hipError_t e = rto::launch_guidance_net(aux, net->w1, net->w2, net->b2, net->c1, net->levels, n, H, W, weight_map, guidance_map,
                                                   net_in_mode(flags), tile_marks, words_per_frame, nullptr,
-                                                  net->fill_planes, (hipStream_t)stream);
+                                                  net->fill_planes, 0, 0.f, (hipStream_t)stream);
     if (e != hipSuccess) return fail(RTO_E_HIP, std::string("GuidanceNet launch failed: ") + hipGetErrorString(e));
     return RTO_OK;
 }
@@ -343,6 +353,14 @@ int rto_denoise(rto_guidance_net* net, rto_ctx* ctx, int n, int mode, void* stre
     if (lean) {
         aux = noisy;
         net_flags = RTO_NET_INPUT_RGBA;
+        if (rto_ctx_frames_lean_level(ctx, sel, n) == 2) {  // sparse: nothing was stored for the pixels of culled tiles
+            if (!marks)
+                return fail(RTO_E_INVALID, "rto_denoise: sparse lean frames need the tile marks of the launch that rendered them (another launch "
+                                           "into this context replaced them)");
+            if (mode != RTO_FILTER_FACTORISED)
+                return fail(RTO_E_UNSUPPORTED, "rto_denoise: sparse lean frames (rto_ctx_set_lean_outputs level 2) take the factorised route only");
+            net_flags |= RTO_NET_INPUT_SPARSE;
+        }
     }
     if (mode == RTO_FILTER_FACTORISED) {
         if (const int rc = rto_guidance_net_forward_packed_culled(net, stream, aux, n, H, W, net_flags, marks, words, bg)) return rc;

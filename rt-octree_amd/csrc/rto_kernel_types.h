@@ -161,7 +161,8 @@ struct FrameBatch {
     uint32_t* chunk_base;
     int qchunk[kMaxQueues + 1];
     const FrameDesc* f;  // [n] in device memory (the context's table, written on the launch stream by write_frames_kernel)
-    // rto_ctx_set_lean_outputs: the shading kernel stores the noisy image as (r, g, b, alpha) and nothing else -- no aux planes
+    // rto_ctx_set_lean_outputs: the shading kernel stores the noisy image as (r, g, b, alpha) and nothing else -- no aux planes;
+    // 2: and nothing at all for the pixels of unmarked tiles (sparse)
     int lean;
 };
 struct FrameChunk {

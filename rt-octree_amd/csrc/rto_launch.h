@@ -64,4 +64,7 @@ hipError_t launch_pack_quant(const uint16_t* qmap, const uint16_t* retained, int
 
 hipError_t launch_rgba8(const float* rgba, uint8_t* out, int64_t n_pixels, hipStream_t stream);
 
+#ifdef RTO_DBG_COUNTERS
+hipError_t debug_shade_phases(unsigned long long* out16, bool reset);  // tools/dbg_shade_phases.py
+#endif
 }  // namespace rto

@@ -244,11 +244,13 @@ class FusedGuidanceNet:
         from ._lib import check, lib
         check(lib().rto_guidance_net_reserve(self._h, int(n), int(H), int(W)))
 
-    def forward_packed(self, aux, stream=None, squares_implied=False, cull=None, rgba=False):
+    def forward_packed(self, aux, stream=None, squares_implied=False, cull=None, rgba=False, sparse=False):
         """the network, its 8 fp16 output channels kept packed in the handle's scratch (rto_guidance_net_forward_packed).
         cull = RenderContext.tile_marks() of the launch that rendered aux (frames in order): network tiles whose inputs are
         all background get the network's background output without being computed (same bits).
-        rgba: `aux` is the noisy image [n, H, W, 4] = (r, g, b, alpha) of a lean batched launch (RTO_NET_INPUT_RGBA)"""
+        rgba: `aux` is the noisy image [n, H, W, 4] = (r, g, b, alpha) of a lean batched launch (RTO_NET_INPUT_RGBA)
+        sparse (with rgba and cull): ... of a SPARSE lean launch (RenderContext.set_lean_outputs(2)): pixels of unmarked tiles are
+        taken as background, the skipped tiles' maps are not stored; filter_packed with the same marks completes the route"""
         from ._lib import check, lib
         if rgba:
             n, H, W, c = aux.shape
@@ -263,7 +265,8 @@ class FusedGuidanceNet:
             if frames < n:
                 raise ValueError("forward_packed: %d frames but tile marks of %d" % (n, frames))
         check(lib().rto_guidance_net_forward_packed_culled(self._h, V._stream_ptr(s), aux.data_ptr(), n, H, W,
-                                                           2 if rgba else (1 if squares_implied else 0), marks, int(words), float(bg)))
+                                                           (2 if rgba else (1 if squares_implied else 0)) | (4 if sparse else 0),
+                                                           marks, int(words), float(bg)))
         self._packed_shape = (n, H, W)
 
     def filter_packed(self, img_in, img_out, stream=None, shape=None, cull=None):

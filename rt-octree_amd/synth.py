@@ -106,13 +106,20 @@ class SynthTree:
         (np.savez_compressed if compressed else np.savez)(path, **kw)
         return path
 
-    def save_quant_npz(self, path, n_retain=1, compressed=False):
+    def save_quant_npz(self, path, n_retain=1, compressed=False, quantiser="luminance"):
         """The quantised schema of octree/compression.py (decoded by n3tree.cpp:279-340): basis
         functions 0..n_retain-1 stay fp16 (`data_retained`), every other basis function gets a
         65536-entry RGB codebook (`quant_colors`) + a uint16 index per leaf slot (`quant_map`).
-        The quantiser here is a cheap stand-in for the reference's k-means: slots are ordered by
-        luminance of the coefficient triple and cut into 65536 equal-count cells, codebook entry =
-        cell mean.  Returns the decoded dense data (what N3Tree::load_npz would expand to)."""
+        quantiser "luminance": a cheap stand-in -- slots ordered by luminance of the coefficient triple and
+        cut into 65536 equal-count cells, codebook entry = cell mean.  "median_cut" (round 6): Heckbert's
+        median cut over the triples of the leaves with sigma > 0, as renderer/scripts/compress_octree.py:68-119
+        applies svox's `quantize_median_cut` (that C extension is not in the reference tree; this is the published
+        algorithm: 16 rounds of splitting every box at the median of its widest axis, palette = box means, id =
+        the box's position in the split tree; slots with sigma = 0 get id 0 and sigma 0).
+        Returns the decoded dense data (what N3Tree::load_npz would expand to)."""
+        if quantiser == "median_cut":
+            return self._save_quant_median_cut(path, n_retain, compressed)
+        assert quantiser == "luminance"
         cap, D = self.capacity, self.data_dim
         nb = (D - 1) // 3
         assert self.data_format.startswith("SH") and 0 <= n_retain <= nb
@@ -153,6 +160,82 @@ class SynthTree:
                 dec[:, c * nb + j + n_retain] = col[:, c]
         dec[:, D - 1] = flat[:, D - 1]
         return dec.reshape(self.data.shape)
+
+
+def median_cut_ids(tri, bits=16, device=None):
+    """Heckbert median cut of the rows of tri [m, 3] (float32) into 2^bits boxes: `bits` rounds, every box split at the median
+    of its widest axis.  -> (palette [2^bits, 3] float32 = box means, ids [m] int64 = box of each row, in split-tree order).
+    torch, on the GPU when there is one (a round is one 64-bit sort of m keys)."""
+    import torch
+    dev = device or ("cuda" if torch.cuda.is_available() else "cpu")
+    x = torch.as_tensor(np.ascontiguousarray(tri, np.float32), device=dev)
+    m = x.shape[0]
+    box = torch.zeros(m, dtype=torch.int64, device=dev)
+    for lvl in range(bits):
+        nb = 1 << lvl
+        lo = torch.full((nb, 3), float("inf"), device=dev).scatter_reduce(0, box[:, None].expand(-1, 3), x, "amin")
+        hi = torch.full((nb, 3), float("-inf"), device=dev).scatter_reduce(0, box[:, None].expand(-1, 3), x, "amax")
+        axis = torch.argmax(hi - lo, dim=1)                       # widest axis of every box (empty boxes: any)
+        val = x.gather(1, axis[box][:, None])[:, 0]
+        # order the rows by (box, value along the box's axis): one sort of a 64-bit key
+        u = val.view(torch.int32).to(torch.int64)
+        u = torch.where(u < 0, ~u & 0x7fffffff, u | 0x80000000)  # float bits -> unsigned keys of the same order
+        order = torch.argsort((box << 32) | u)
+        sb = box[order]
+        cnt = torch.bincount(sb, minlength=nb)
+        start = torch.cumsum(cnt, 0) - cnt
+        rank = torch.arange(m, device=dev) - start[sb]
+        upper = rank >= (cnt[sb] + 1) // 2                        # the median stays in the lower half
+        nbx = torch.empty_like(box)
+        nbx[order] = sb * 2 + upper.to(torch.int64)
+        box = nbx
+    nb = 1 << bits
+    cnt = torch.bincount(box, minlength=nb).clamp(min=1).to(torch.float32)
+    pal = torch.zeros((nb, 3), device=dev).index_add_(0, box, x) / cnt[:, None]
+    return pal.cpu().numpy(), box.cpu().numpy()
+
+
+def _save_quant_median_cut(self, path, n_retain, compressed):
+    cap, D = self.capacity, self.data_dim
+    nb = (D - 1) // 3
+    assert self.data_format.startswith("SH") and 0 <= n_retain <= nb
+    n_child = cap * 8
+    flat = self.data.reshape(n_child, D)
+    sig = flat[:, D - 1].astype(np.float32)
+    snz = sig > 0.0  # compress_octree.py:72-73 (its --sigma_thresh; leaves below it lose their density)
+    nq = nb - n_retain
+    retained = np.zeros((n_retain, n_child, 3), np.float16)
+    for k in range(n_retain):
+        for c in range(3):
+            retained[k, snz, c] = flat[snz, c * nb + k]
+    qcolors = np.zeros((nq, 65536, 3), np.float16)
+    qmap = np.zeros((nq, n_child), np.uint16)
+    for j in range(nq):
+        k = j + n_retain
+        tri = np.stack([flat[snz, c * nb + k] for c in range(3)], 1).astype(np.float32)
+        pal, ids = median_cut_ids(tri)
+        qcolors[j] = pal.astype(np.float16)
+        qmap[j, snz] = ids.astype(np.uint16)
+    sigma = np.where(snz, flat[:, D - 1], np.float16(0)).astype(np.float16).reshape(cap, 2, 2, 2)
+    kw = dict(data_dim=np.int64(D), data_format=np.array(self.data_format),
+              invradius3=self.scale.astype(np.float32), offset=self.offset.astype(np.float32),
+              child=self.child, quant_colors=qcolors, quant_map=qmap.reshape(nq, cap, 2, 2, 2), sigma=sigma)
+    if n_retain:
+        kw["data_retained"] = retained.reshape(n_retain, cap, 2, 2, 2, 3)
+    (np.savez_compressed if compressed else np.savez)(path, **kw)
+    dec = np.zeros((n_child, D), np.float16)
+    for k in range(n_retain):
+        for c in range(3):
+            dec[:, c * nb + k] = retained[k, :, c]
+    for j in range(nq):
+        col = qcolors[j][qmap[j]]
+        for c in range(3):
+            dec[:, c * nb + j + n_retain] = col[:, c]
+    dec[:, D - 1] = sigma.reshape(-1)
+    return dec.reshape(self.data.shape)
+
+
+SynthTree._save_quant_median_cut = _save_quant_median_cut
 
 
 def make_tree(depth_limit=6, basis_dim=9, seed=20230418, shell=1.25, radius=1.5, sdf=scene_sdf,

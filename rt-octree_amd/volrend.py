@@ -331,8 +331,12 @@ class RenderContext:
 
     def set_lean_outputs(self, on=True):
         """rto_ctx_set_lean_outputs: batched launches with denoise on store the noisy image as (r, g, b, alpha) and no aux
-        planes -- 16 instead of 48 bytes per pixel; consumers: FusedGuidanceNet(..., rgba=True) on noisy_ptr, denoise()"""
-        check(lib().rto_ctx_set_lean_outputs(self._h, int(bool(on))))
+        planes -- 16 instead of 48 bytes per pixel; consumers: FusedGuidanceNet(..., rgba=True) on noisy_ptr, denoise().
+        on = 2 (sparse): and nothing at all for the pixels of culled tiles; consumers additionally pass sparse=True + the marks"""
+        check(lib().rto_ctx_set_lean_outputs(self._h, int(on)))
+
+    def frames_lean_level(self, first=0, n=1):
+        return lib().rto_ctx_frames_lean_level(self._h, int(first), int(n))  # 0 full / 1 lean / 2 sparse; -1: a mixed range
 
     def frames_are_lean(self, first=0, n=1):
         return lib().rto_ctx_frames_are_lean(self._h, int(first), int(n)) == 1  # (0: all full; -1: a mixed range)

@@ -86,3 +86,60 @@ def test_c4_1080p_sh25_denoised_batch():
     fast = ctx.download_image()
     assert np.allclose(fast[..., :3], exact[..., :3], rtol=2e-5, atol=2e-6)
     assert np.all((exact[..., :3] >= -1e-6) & (exact[..., :3] <= 1 + 1e-5))
+
+
+def test_c4_bench_tree_one_complete_1080p_frame():
+    """VERDICT r5 task 5: parity at BENCH size for configs[3] -- the very tree `bench.py --c4` times (depth 10, SH25, 4.03 M
+    nodes, radius 1.12; its /dev/shm cache file is shared with the bench), the bench's cameras (T&T intrinsics, orbit radius
+    2.6) and RNG jumps: a batched launch, ONE COMPLETE 1920x1080 frame against the oracle -- all 8 aux planes of all 2 073 600
+    pixels and the RGBA8 bytes, bit for bit (volrend.cu:84-213 through orc.render_frame) -- and a second frame's spot pixels."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    args = bench.parse_args(["--c4"])
+    path = bench.tree_cache_path(args, 0)
+    if not os.path.exists(path):  # exactly bench.py's generation call
+        th = synth.make_tree(depth_limit=args.depth, basis_dim=args.basis, shell=args.shell, radius=args.radius,
+                             sdf=synth.scene_variant(0), seed=20230418)
+        th.save_npz(path + ".tmp_test.npz")
+        os.replace(path + ".tmp_test.npz", path)
+        del th
+    z = np.load(path)
+    child, data, scale, offset, fmt = z["child"], z["data"], z["invradius3"], z["offset"], str(z["data_format"])
+    assert fmt == "SH25" and child.shape[0] > 4_000_000
+    ht = orc.HostTree(child, data, scale, offset, fmt)
+    dt = R.N3Tree(path)  # the loader path the bench takes
+    W, H, spp, fx = args.width, args.height, args.spp, args.fx
+    assert (W, H, spp, fx) == (1920, 1080, 6, 1160.0)
+    poses = synth.orbit_poses(bench.n_poses_for(1), radius=args.cam_radius)
+    pick = [0, 57, 133]  # poses of the bench's launch groups
+    cams = []
+    for i in pick:
+        c = R.Camera(W, H, fx, fx)
+        c.set_c2w(poses[i])
+        cams.append(c)
+    jumps = [bench.WARM_FRAMES_REF + i for i in pick]
+    ctx = R.RenderContext(W, H, frames=len(pick))
+    ctx.rng_seed()
+    R.launch_renderer_batch(dt, cams, R.RenderOptions(spp=spp, denoise=True), ctx, rng_jumps=jumps)
+    aux_o, rgba_o = oracle_whole_frame(ht, cams[1], fx, spp, jumps[1])
+    ctx.select_frame(1)
+    aux = ctx.download_aux()
+    assert (aux[3] > 0).mean() > 0.2
+    assert_bits_equal(aux, aux_o, "bench C4 tree, pose %d: whole 1080p frame, aux planes" % pick[1])
+    assert np.array_equal(ctx.download_rgba8(noisy=True), orc.rgba8(rgba_o)), "bench C4 tree: RGBA8 of the whole frame"
+    ctx.select_frame(2)
+    aux2 = ctx.download_aux()
+    ocam = orc.camera(W, H, fx, fx, cams[2].transform.reshape(-1))
+    oopt = orc.default_options(spp=spp)
+    base = orc.rng(frame=jumps[2])
+    rs = np.random.RandomState(7)
+    for idx in list(rs.randint(0, W * H, 128)) + [0, W * H - 1, (H // 2) * W + W // 2]:
+        a8, rgba = (C.c_float * 8)(), (C.c_float * 4)()
+        assert orc.lib().orc_render_pixel(C.byref(ht.c), C.byref(ocam), C.byref(oopt), C.byref(base), int(idx), a8, rgba, None) == 0
+        y, x = divmod(int(idx), W)
+        assert_bits_equal(aux2[:, y, x], np.array(a8[:], np.float32), "bench C4 tree pose %d pixel %d" % (pick[2], idx))
+    ctx.free()
+    dt.free()

@@ -128,3 +128,81 @@ def test_lean_launch_stores_planes_0_to_3_and_denoises_to_the_same_images(scene,
         torch.cuda.synchronize()
         assert_bits_equal(image_l.cpu().numpy(), want[mode].cpu().numpy(), "runs of lean / full / lean slots, mode %d" % mode)
     lean.select_frame(0)
+
+
+@pytest.mark.parametrize("W,H,bg", [(400, 304, 1.0), (333, 257, 0.25)])
+def test_sparse_lean_launch_denoises_to_the_same_images(scene, W, H, bg):
+    """round 6, rto_ctx_set_lean_outputs level 2: as lean, and NOTHING is stored for the pixels of the tiles the launch's culling
+    left unmarked -- the noisy image is poisoned beforehand and the poison must survive there -- yet the factorised route
+    (one-call rto_denoise; two-call form with RTO_NET_INPUT_SPARSE + the marks) denoises to the full route's images bit for bit:
+    the network takes the background for those pixels and stores no maps for the tiles it skips, the filter substitutes both.
+    The noisy image comes back complete from rto_ctx_download_image / _rgba8; the bit-exact filter route refuses sparse frames."""
+    dt, net = scene
+    n = 4
+    cams = cams_for(W, H, n)
+    opt = R.RenderOptions(spp=6, denoise=True, background_brightness=bg)
+    jumps = [100 + i for i in range(n)]
+    full = R.RenderContext(W, H, frames=n)
+    full.rng_seed()
+    R.launch_renderer_batch(dt, cams, opt, full, rng_jumps=jumps)
+    aux_f, noisy_f, image_f = views(full, n)
+    full.select_frame(0)
+    net.denoise(full, n=n, mode=R.FILTER_FAST)
+    torch.cuda.synchronize()
+    want = image_f.clone()
+
+    sp = R.RenderContext(W, H, frames=n)
+    aux_s, noisy_s, image_s = views(sp, n)
+    POISON = -12345.0
+    noisy_s.fill_(POISON)
+    sp.set_lean_outputs(2)
+    sp.rng_seed()
+    R.launch_renderer_batch(dt, cams, opt, sp, rng_jumps=jumps)
+    torch.cuda.synchronize()
+    assert sp.frames_lean_level(0, n) == 2 and sp.frames_are_lean(0, n)
+    marks = sp.tile_marks()
+    assert marks is not None
+    for f in range(n):
+        sp.select_frame(f)
+        patched = sp.download_image(noisy=True)  # completed on the host
+        raw = noisy_s[f].cpu().numpy()
+        unm = raw[..., 0] == POISON
+        assert np.all(raw[unm] == POISON), "a sparse launch stored only part of a culled pixel"
+        assert unm.mean() > 0.2, "the test scene must have culled tiles"
+        # unmarked pixels come in whole 8x8 tiles and are the background after the host-side completion
+        for (y, x) in [(0, 0), (H - 1, W - 1)]:
+            assert unm[y, x] == unm[(y // 8) * 8, (x // 8) * 8]
+        assert np.all(patched[unm][:, :3] == np.float32(bg)) and np.all(patched[unm][:, 3] == 0.0)
+        # ... and everything equals the lean / full route's values: (r, g, b) = the full noisy image, alpha = aux plane 3
+        assert_bits_equal(patched[..., :3], noisy_f[f, ..., :3].cpu().numpy(), "sparse noisy image (completed) vs the full route")
+        assert_bits_equal(patched[..., 3], aux_f[f, 3].cpu().numpy(), "sparse alpha vs aux plane 3")
+        r8 = sp.download_rgba8(noisy=True)
+        assert np.array_equal(r8[..., :3], (patched[..., :3] * 255).astype(np.uint8))
+    sp.select_frame(0)
+    image_s.fill_(-7.0)
+    net.denoise(sp, n=n, mode=R.FILTER_FAST)  # picks the sparse route by itself
+    torch.cuda.synchronize()
+    assert_bits_equal(image_s.cpu().numpy(), want.cpu().numpy(), "rto_denoise on sparse lean frames")
+    with pytest.raises(R.RtoError):
+        net.denoise(sp, n=n, mode=R.FILTER_EXACT)
+    image_s.fill_(-7.0)
+    net.forward_packed(noisy_s, rgba=True, sparse=True, cull=marks)
+    net.filter_packed(sp.noisy_ptr, sp.image_ptr, shape=(n, H, W), cull=marks)
+    torch.cuda.synchronize()
+    assert_bits_equal(image_s.cpu().numpy(), want.cpu().numpy(), "two-call form with RTO_NET_INPUT_SPARSE")
+    with pytest.raises(R.RtoError):  # sparse maps without the marks: refused
+        net.filter_packed(sp.noisy_ptr, sp.image_ptr, shape=(n, H, W))
+    # a later launch into the context replaces the marks: the sparse frames can then no longer be completed or denoised
+    sp.set_lean_outputs(0)
+    one = R.RenderContext(W, H)
+    sp.select_frame(0)
+    sp.rng_seed()
+    R.launch_renderer(dt, cams[0], opt, sp)  # slot 0 becomes a full frame, the marks of the batch are gone
+    torch.cuda.synchronize()
+    assert sp.frames_lean_level(0, 1) == 0 and sp.frames_lean_level(1, 3) == 2 and sp.frames_lean_level(0, n) == -1
+    sp.select_frame(1)
+    with pytest.raises(R.RtoError):
+        sp.download_image(noisy=True)
+    with pytest.raises(R.RtoError):
+        net.denoise(sp, n=3, mode=R.FILTER_FAST)
+    one.free()

@@ -26,12 +26,14 @@ def _cams(W, H, n):
     return out
 
 
-@pytest.mark.parametrize("basis,n_retain,spp", [(9, 1, 6), (4, 0, 4), (16, 2, 6), (25, 1, 2)])
-def test_direct_equals_decoded_and_oracle(tmp_path, basis, n_retain, spp):
+@pytest.mark.parametrize("basis,n_retain,spp,quantiser", [(9, 1, 6, "luminance"), (4, 0, 4, "luminance"), (16, 2, 6, "luminance"),
+                                                          (25, 1, 2, "luminance"), (16, 1, 6, "median_cut")])
+def test_direct_equals_decoded_and_oracle(tmp_path, basis, n_retain, spp, quantiser):
+    """(round 6: also for codebooks made by a real median cut over the leaves of positive density, compress_octree.py:68-119)"""
     W, H = 96, 64
     tree = synth.make_tree(depth_limit=6, basis_dim=basis, seed=11)
     path = str(tmp_path / "tree.npz")
-    decoded = tree.save_quant_npz(path, n_retain=n_retain)
+    decoded = tree.save_quant_npz(path, n_retain=n_retain, quantiser=quantiser)
     direct = R.N3Tree(path, quant_direct=True)
     dense = R.N3Tree(path)
     assert direct.data_dim == dense.data_dim == 3 * basis + 1  # (the footprint only wins once slots outnumber codebook entries)

@@ -172,3 +172,33 @@ def test_two_pairs_below_the_grid_random_views(seed):
     assert_bits_equal(ctx.download_aux(), got[1], "single-frame kernel, depth %d, seed %d" % (depth, seed))
     ctx.free()
     dt.free()
+
+
+def test_top_grid_levels_never_change_pixels():
+    """round 6 A/B hook RTO_TOP_LEVELS (levels the top grid of the traversal images covers, default 6): derived data, so the
+    frames of the batched and the single-frame kernels are the default's for every value"""
+    tree = synth.make_tree(depth_limit=9, basis_dim=9, seed=21, shell=2.0)
+    W, H, spp = 200, 152, 6
+    cams = [cameras(W, H, p)[1] for p in POSES[:3]]
+    jumps = [11, 12, 13]
+    base = None
+    for g in (None, 4, 5, 7, 8):
+        if g is not None:
+            os.environ["RTO_TOP_LEVELS"] = str(g)
+        try:
+            dt = R.N3Tree.from_arrays(tree.child, tree.data, tree.scale, tree.offset, tree.data_format)
+        finally:
+            os.environ.pop("RTO_TOP_LEVELS", None)
+        got = batch_frames(dt, cams, spp, jumps)
+        ctx = R.RenderContext(W, H)
+        ctx.rng_seed()
+        ctx.rng_advance(jumps[1] << 32)
+        R.launch_renderer(dt, cams[1], R.RenderOptions(spp=spp, denoise=False), ctx)
+        one = ctx.download_aux()
+        ctx.free()
+        dt.free()
+        if base is None:
+            base = got
+            assert np.any(base[:, 3] > 0)
+        assert_bits_equal(got, base, "batched frames with a top grid of %s levels" % g)
+        assert_bits_equal(one, base[1], "single-frame kernel with a top grid of %s levels" % g)

@@ -16,7 +16,7 @@ def main():
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-frames", "0", "--psnr-frames", "0", "--ref-loop-frames", "0", "--streams", "1",
-            "--no-exact-pass", "--count-frames", "0", "--spot-pixels", "16", "--steps", "6", "--warmup", "2", "--groups-per-step", "1"] + a.args.split()
+            "--no-exact-pass", "--no-full-pass", "--count-frames", "0", "--spot-pixels", "16", "--steps", "6", "--warmup", "2", "--groups-per-step", "1"] + a.args.split()
     for r in range(a.rounds):
         for lib in a.libs:
             env = dict(os.environ, RTO_LIB=os.path.abspath(lib))

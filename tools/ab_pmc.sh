@@ -4,7 +4,7 @@
 T=$1; A=$2; shift 2
 O=gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-B="bench.py $A --streams 1 --cpu-frames 0 --psnr-frames 0 --ref-loop-frames 0 --spot-pixels 0 --count-frames 0 --no-exact-pass --steps 2 --warmup 1"
+B="bench.py $A --streams 1 --cpu-frames 0 --psnr-frames 0 --ref-loop-frames 0 --spot-pixels 0 --count-frames 0 --no-exact-pass --no-full-pass --steps 2 --warmup 1"
 for L in "$@"; do
   N=$(basename $L .so)
   i=0

@@ -9,7 +9,7 @@ O=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 STUB=$PWD/rt-octree_amd/lib_ab/librto_1.so   # tools/ab_variants.sh build "" "-DRTO_STUB_LOADS"
 if [ -f $STUB ]; then
-  RTO_LIB=$STUB timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/${T}_stub -- python3 bench.py --streams 1 --cpu-frames 0 --psnr-frames 0 --ref-loop-frames 0 --spot-pixels 0 --count-frames 0 --no-exact-pass --steps 2 --warmup 1 --groups-per-step 1 --no-denoise > /dev/null 2> $O/${T}_stub.err
+  RTO_LIB=$STUB timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/${T}_stub -- python3 bench.py --streams 1 --cpu-frames 0 --psnr-frames 0 --ref-loop-frames 0 --spot-pixels 0 --count-frames 0 --no-exact-pass --no-full-pass --steps 2 --warmup 1 --groups-per-step 1 --no-denoise > /dev/null 2> $O/${T}_stub.err
   python3 tools/pmc_summarize.py $O/${T}_stubbed_loads_pmc.json $O/${T}_stub > /dev/null; rm -rf $O/${T}_stub
   cp $O/${T}_stubbed_loads_pmc.json profiles/
 fi

@@ -16,10 +16,11 @@ def main():
     ap.add_argument("dense")
     ap.add_argument("out")
     ap.add_argument("--retain", type=int, default=1)
+    ap.add_argument("--quantiser", choices=("luminance", "median_cut"), default="luminance")
     a = ap.parse_args()
     z = np.load(a.dense)
     t = synth.SynthTree(z["child"], z["data"], z["invradius3"], z["offset"], str(z["data_format"]), 0, {})
-    t.save_quant_npz(a.out, n_retain=a.retain)
+    t.save_quant_npz(a.out, n_retain=a.retain, quantiser=a.quantiser)
     print("dense %.1f MB -> quantised %.1f MB" % (os.path.getsize(a.dense) / 1e6, os.path.getsize(a.out) / 1e6))
 
 

@@ -12,7 +12,7 @@ for C in $CFGS; do
     c5) A="--spp 1 --no-denoise" ; STEPS=2 ;;
     c4) A="--c4" ; STEPS=2 ;;
   esac
-  B="bench.py $A --streams 1 --cpu-frames 0 --psnr-frames 0 --ref-loop-frames 0 --spot-pixels 0 --count-frames 0 --no-exact-pass --steps $STEPS --warmup 1 --groups-per-step 1"
+  B="bench.py $A --streams 1 --cpu-frames 0 --psnr-frames 0 --ref-loop-frames 0 --spot-pixels 0 --count-frames 0 --no-exact-pass --no-full-pass --steps $STEPS --warmup 1 --groups-per-step 1"
   # (the plain bench lines: tools/bench_lines.sh, once the counters of this run are installed)
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_${C}_trace -- python3 $B > $O/${TAG}_${C}_bench_under_rocprof.json 2>/dev/null
   cp $(find $O/${TAG}_${C}_trace -name '*kernel_stats.csv' | head -1) $O/${TAG}_${C}_kernel_stats.csv

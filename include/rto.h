@@ -147,7 +147,7 @@ int rto_tree_load_npz(const char* path, int device, rto_tree** out);
 /* RTO_TREE_COMPACT_RECORDS: the aligned coefficient copy holds a record only for the leaf slots a ray can hit -- density
  * > 0: a hit needs sigma > sigma_thresh (rt_core.cuh:252) -- found through a 4-byte-per-slot index (8.6 M of 17 M slots of
  * the benchmark tree: 1.3 instead of 2.2 GB resident, 0.75x the file).  Same pixels; the shading kernels pay one more
- * dependent gather per hit leaf (measured: DESIGN.md section 3).  Launches with sigma_thresh < 0 are refused for such a
+ * dependent gather per hit leaf (measured: DESIGN_HISTORY.md section 3).  Launches with sigma_thresh < 0 are refused for such a
  * tree (RTO_E_UNSUPPORTED).  Ignored where no aligned copy is built (RTO_TREE_COMPACT, SH25, RGBA, quantised-direct). */
 #define RTO_TREE_COMPACT_RECORDS 8
 /* RTO_TREE_NO_CULLING: do not build the empty-space culling cells (the batched path then marches every ray, as rounds 1-2

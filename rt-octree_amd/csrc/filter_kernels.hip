@@ -56,7 +56,7 @@ RTO_DEV void filter_level(const float* __restrict__ g, const float4* __restrict_
     // Scalar FMAs (v_fma_f32), one tap at a time.  Rounds 1-2 ran this loop on packed pairs -- v_pk_fma_f32, exps of two
     // neighbouring taps at once (-DRTO_FILTER_PK=1 rebuilds it) -- the same bits and the same speed (a packed instruction
     // issues at half rate), until round 3 found the packed build's bits wrong in lanes 48..63 of some waves whenever another
-    // process kept the GPU busy with MFMA-dense kernels (DESIGN.md "Determinism when the GPU is shared").  Of all kernels only this one
+    // process kept the GPU busy with MFMA-dense kernels (DESIGN_HISTORY.md "Determinism when the GPU is shared").  Of all kernels only this one
     // held v_pk_fma_f32; v_pk_add / v_pk_mul (filter_fast, shading) never showed it.
 #if !RTO_FILTER_PK
     float2v rg = {0.f, 0.f}, bs = {0.f, 0.f};
@@ -518,27 +518,26 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
     // shifts and selects, no load, no division
     const int rtx0 = (tx_first * kFastW - L) >> 3;
     uint32_t nskip = 0, rmark[4] = {0, 0, 0, 0};
-    if (PACKED && cull.sparse) {
+    if (PACKED && cull.sparse && next_live(0) < kFastStrip) {  // (a strip without a computed tile stages nothing)
         static_assert(!PACKED || (kFastStrip + 2 <= 8 && (kFastH + 2 * L + 7) / 8 + 1 <= 4 && (kFastStrip * kFastW + 2 * L + 7) / 8 + 1 <= 32),
                       "bit budget of the skipped-network-tile mask and of the render-tile rows");
-        __shared__ uint32_t s_sp[5];
-        if (tid < 5) s_sp[tid] = 0;
-        __syncthreads();
-        if (tid < 32 && net_tile_was_skipped(fmask, cull.mask_words, cull.tiles_x, H, W, ntx0 + (tid & 7), nty0 + (tid >> 3)))
-            atomicOr(&s_sp[4], 1u << tid);
-        if (tid < 128) {  // render tile (row tid >> 5, column tid & 31) of the region
-            const int ty = nty0 + (tid >> 5), tx = rtx0 + (tid & 31);
+        // (every wave evaluates all of it for itself -- 32 + 128 predicates, a few cached mask words each -- and takes the bits by
+        //  ballot: no LDS, no barrier, and the loads go out with the kernel's first ones)
+        const int ln = tid & 63;
+        const bool sk = ln < 32 && net_tile_was_skipped(fmask, cull.mask_words, cull.tiles_x, H, W, ntx0 + (ln & 7), nty0 + (ln >> 3));
+        nskip = (uint32_t)__builtin_amdgcn_ballot_w64(sk);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {  // render tile (row 2 * half + (lane >> 5), column lane & 31) of the region
+            const int ty = nty0 + 2 * half + (ln >> 5), tx = rtx0 + (ln & 31);
             bool marked = false;
             if (tx >= 0 && ty >= 0 && tx < cull.tiles_x && ty * 8 < H) {
                 const uint32_t t = (uint32_t)(ty * cull.tiles_x + tx);
                 marked = (((fmask[t >> 5] >> (t & 31u)) | fmask[cull.mask_words - 1]) & 1u) != 0u;
             }
-            if (marked) atomicOr(&s_sp[tid >> 5], 1u << (tid & 31));
+            const unsigned long long b = __builtin_amdgcn_ballot_w64(marked);
+            rmark[2 * half] = (uint32_t)b;
+            rmark[2 * half + 1] = (uint32_t)(b >> 32);
         }
-        __syncthreads();
-        nskip = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_sp[4]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rmark[r] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_sp[r]);
     }
     auto maps_stored = [&](int gx, int gy) { return ((nskip >> ((((gy >> 3) - nty0) << 3) + ((gx >> 5) - ntx0))) & 1u) == 0u; };
     auto pixel_stored = [&](int gx, int gy) {  // its render tile is marked: the shading kernel wrote it
@@ -596,13 +595,15 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
             int gx, gy;
             const int gi = gindex_xy(x0, i, gx, gy);
             if constexpr (PACKED) {
-                f.rgb[i] = gi >= 0 ? img_in[gi] : make_float4(0.f, 0.f, 0.f, 0.f);
-                f.hg[i] = half4_t{0, 0, 0, 0};
-                if (gi >= 0) f.hg[i] = *reinterpret_cast<const half4_t*>(packed + (int64_t)gi * 8 + 4);
-                if (cull.sparse && gi >= 0) {  // (loaded whatever the address holds, then replaced: no dependent round trip)
-                    if (!pixel_stored(gx, gy)) f.rgb[i] = make_float4(cull.bg, cull.bg, cull.bg, 0.f);
-                    if (!maps_stored(gx, gy)) f.hg[i] = __builtin_bit_cast(half4_t, make_uint2(cull.fill_maps.z, cull.fill_maps.w));
-                }
+                // (sparse: whether a value exists in memory is known from registers BEFORE its load is issued, so the load is simply
+                //  not issued for the lanes that take the constant -- a select on the loaded value would make this prefetch wait for it)
+                const bool ld_rgb = gi >= 0 && (!cull.sparse || pixel_stored(gx, gy));
+                const bool ld_map = gi >= 0 && (!cull.sparse || maps_stored(gx, gy));
+                const float bgv = gi >= 0 ? cull.bg : 0.f;  // (only ever used when sparse)
+                f.rgb[i] = make_float4(bgv, bgv, bgv, 0.f);
+                if (ld_rgb) f.rgb[i] = img_in[gi];
+                f.hg[i] = gi >= 0 ? __builtin_bit_cast(half4_t, make_uint2(cull.fill_maps.z, cull.fill_maps.w)) : half4_t{0, 0, 0, 0};
+                if (ld_map) f.hg[i] = *reinterpret_cast<const half4_t*>(packed + (int64_t)gi * 8 + 4);
             } else {
                 if (tid + i * 256 < NE) s_rgb[tid + i * 256] = gi >= 0 ? img_in[gi] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -613,9 +614,8 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
         for (int r = 0; r < kFastRows; ++r) {
             const bool in = px < W && py0 + r < H;
             if constexpr (PACKED) {
-                f.hw[r] = half4_t{0, 0, 0, 0};
-                if (in) f.hw[r] = *reinterpret_cast<const half4_t*>(packed + ((int64_t)(py0 + r) * W + px) * 8);
-                if (cull.sparse && in && !maps_stored(px, py0 + r)) f.hw[r] = __builtin_bit_cast(half4_t, make_uint2(cull.fill_maps.x, cull.fill_maps.y));
+                f.hw[r] = in ? __builtin_bit_cast(half4_t, make_uint2(cull.fill_maps.x, cull.fill_maps.y)) : half4_t{0, 0, 0, 0};
+                if (in && (!cull.sparse || maps_stored(px, py0 + r))) f.hw[r] = *reinterpret_cast<const half4_t*>(packed + ((int64_t)(py0 + r) * W + px) * 8);
             } else {
 #pragma unroll
                 for (int l = 0; l < L; ++l) f.wl[l][r] = in ? weight[l * HW + (int64_t)(py0 + r) * W + px] : 0.f;

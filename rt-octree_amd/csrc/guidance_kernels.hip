@@ -73,7 +73,7 @@ struct NetCull {
 // consumer (filter_fast<L, true>) applies softmax_weights() below to the logits itself.
 // Launch bounds per instantiation: with all 8 aux planes in flight (SQ = false) the kernel needs 134 VGPRs; bounded to 128
 // (4 workgroups per CU) it spilled 2-4 of them to scratch and ran slower.  It was also the kernel in whose company the
-// bit-exact filter first lost its determinism on a shared GPU (DESIGN.md "Determinism when the GPU is shared": the cause
+// bit-exact filter first lost its determinism on a shared GPU (DESIGN_HISTORY.md "Determinism when the GPU is shared": the cause
 // turned out to be v_pk_fma_f32 under MFMA load from other processes, this kernel being the longest MFMA kernel around); no
 // kernel of the denoise stage uses scratch now (tests/test_codegen.py).  -DRTO_NET_SQ0_WG=4 rebuilds the old bound.
 #ifndef RTO_NET_SQ0_WG
@@ -129,16 +129,26 @@ __global__ void __launch_bounds__(256, IN ? 4 : RTO_NET_SQ0_WG) guidance_fused(c
     // Tiles of the strip whose input region (tile + halo 2) lies inside the image and in culled render tiles read nothing
     // but background: every output pixel is cull.fill.  Bit ts of `skip_tiles`; workgroup-uniform.
     uint32_t skip_tiles = 0;
+    constexpr int RX = (IW + 7) / 8 + 1, RY = (IH + 7) / 8 + 1;  // render tiles an input region can touch, per axis
+    __shared__ uint32_t s_rtm[kStrip];  // sparse input: bit sy * RX + sx = render tile (sx, sy) of strip tile ts's input region is marked
     if (cull.mask) {
         __shared__ uint32_t s_live;
         if (tid == 0) s_live = 0;
+        if (tid < kStrip) s_rtm[tid] = 0;
         __syncthreads();
-        constexpr int RX = (IW + 7) / 8 + 1, RY = (IH + 7) / 8 + 1;  // render tiles an input region can touch, per axis
-        static_assert(kStrip * RX * RY <= 256, "one thread per (strip tile, render tile)");
+        static_assert(kStrip * RX * RY <= 256 && RX * RY <= 32, "one thread per (strip tile, render tile)");
         if (tid < kStrip * RX * RY) {
             const int ts = tid / (RX * RY), sub = tid - ts * (RX * RY), sy = sub / RX, sx = sub - sy * RX;
             const int x0 = (tx_first + ts) * kGW - 2, ry0 = y0 - 2;
             bool live = false;
+            if (cull.sparse && tx_first + ts < tiles_x) {  // (also for regions that reach over the frame: their in-frame pixels may be unstored)
+                const int tx = (x0 >> 3) + sx, ty = (ry0 >> 3) + sy;
+                if (tx >= 0 && ty >= 0 && tx < cull.tiles_x && ty * 8 < H) {
+                    const uint32_t* fm = cull.mask + (size_t)blockIdx.z * cull.mask_words;
+                    const uint32_t t = (uint32_t)(ty * cull.tiles_x + tx);
+                    if (((fm[t >> 5] >> (t & 31u)) | fm[cull.mask_words - 1]) & 1u) atomicOr(&s_rtm[ts], 1u << sub);
+                }
+            }
             if (tx_first + ts < tiles_x) {
                 if (x0 < 0 || ry0 < 0 || x0 + IW > W || ry0 + IH > H) {
                     live = true;  // the zero padding is not background
@@ -183,6 +193,10 @@ __global__ void __launch_bounds__(256, IN ? 4 : RTO_NET_SQ0_WG) guidance_fused(c
     constexpr int NLD = SQ ? kCIn / 2 : kCIn;  // planes actually read
     float v[NIT][NLD];
     auto fetch = [&](int x0) {  // issue the loads of the tile whose first output column is x0
+        // (sparse: the marks of the render tiles under this tile's input region, in an SGPR -- whether a pixel was stored is known
+        //  before its load is issued, which is then simply not issued: no dependent mask load, no select that waits for the pixel)
+        const uint32_t rtm = cull.sparse ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rtm[x0 / kGW - tx_first]) : 0u;
+        const int rtx0 = (x0 - 2) >> 3, rty0 = (y0 - 2) >> 3;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int e = tid + it * 256;
@@ -191,17 +205,15 @@ __global__ void __launch_bounds__(256, IN ? 4 : RTO_NET_SQ0_WG) guidance_fused(c
             const bool in = e < NPIX && gx >= 0 && gx < W && gy >= 0 && gy < H;
             const int gi = in ? gy * W + gx : 0;  // (8 * H * W < 2^31: rto_ctx_create's size check)
             if constexpr (IN == 2) {
-                const float4 t = reinterpret_cast<const float4*>(aux)[gi];
-                bool stored = true;  // (sparse: the pixel's render tile is marked, i.e. the shading kernel wrote it)
-                if (cull.sparse) {
-                    const uint32_t* fm = cull.mask + (size_t)blockIdx.z * cull.mask_words;
-                    const uint32_t rt = in ? (uint32_t)((gy >> 3) * cull.tiles_x + (gx >> 3)) : 0u;
-                    stored = (((fm[rt >> 5] >> (rt & 31u)) | fm[cull.mask_words - 1]) & 1u) != 0u;
-                }
-                v[it][0] = in ? (stored ? t.x : cull.bg) : 0.f;
-                v[it][1] = in ? (stored ? t.y : cull.bg) : 0.f;
-                v[it][2] = in ? (stored ? t.z : cull.bg) : 0.f;
-                v[it][3] = in ? (stored ? t.w : 0.f) : 0.f;
+                // (sparse: a pixel of an unmarked render tile was never stored -- it is the background)
+                const bool stored = !cull.sparse || ((rtm >> (((gy >> 3) - rty0) * RX + ((gx >> 3) - rtx0))) & 1u) != 0u;
+                const float bgv = in && cull.sparse ? cull.bg : 0.f;
+                float4 t = make_float4(bgv, bgv, bgv, 0.f);
+                if (in && stored) t = reinterpret_cast<const float4*>(aux)[gi];
+                v[it][0] = t.x;
+                v[it][1] = t.y;
+                v[it][2] = t.z;
+                v[it][3] = t.w;
             } else {
 #pragma unroll
                 for (int c = 0; c < NLD; ++c) {

@@ -3,7 +3,7 @@
 render_persist issues two gathers per node visit -- 4 bytes of the traversal image for the lanes inside the tree, 8
 bytes of the top grid for the others -- and its speed depends on both being in flight together.  Round 2 found a build
 in which the register allocator had put an `s_waitcnt vmcnt(0)` BETWEEN the two loads (a temporary of the second branch
-reused the first load's destination register): same instructions, same memory traffic, 14 % slower ("A
+reused the first load's destination register): same instructions, same memory traffic, 14 % slower (DESIGN_HISTORY.md, "A
 register-allocation cliff").  The kernel now forms both addresses before either load; this test keeps it that way."""
 import os
 import re

@@ -180,6 +180,8 @@ def lib():
         _preload_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
+            if os.environ.get("RTO_LIB") and os.environ.get("RTO_LIB_OLDER_BUILD") and not hasattr(L, name):
+                continue  # (same-box A/B against the library of an OLDER revision, tools/ab_rev.sh: symbols added since are absent)
             fn = getattr(L, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args

@@ -206,3 +206,53 @@ def test_sparse_lean_launch_denoises_to_the_same_images(scene, W, H, bg):
     with pytest.raises(R.RtoError):
         net.denoise(sp, n=3, mode=R.FILTER_FAST)
     one.free()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_sparse_lean_equals_lean_on_random_sizes_and_poses(scene, seed):
+    """the sparse route's tile arithmetic (render tiles 8x8, network tiles 32x8 + halo 2, filter tiles 32x16 + halo 4 + 2) on frame
+    sizes that are no multiple of anything, narrower than a strip, with cameras close to / far from / looking past the model (whole
+    frames kept or culled) and several backgrounds: denoised images and the completed noisy image equal the lean route's bit for bit"""
+    dt, net = scene
+    rs = np.random.RandomState(1000 + seed)
+    W = int(rs.choice([24, 40, 71, 97, 130, 161, 200, 257, 320, 403]))
+    H = int(rs.choice([17, 33, 48, 75, 96, 131, 180, 241]))
+    n = int(rs.randint(1, 5))
+    bg = float(rs.choice([0.0, 0.25, 1.0]))
+    fx = synth.blender_focal(W) * float(rs.uniform(0.5, 2.0))
+    cams = []
+    for _ in range(n):
+        kind = rs.randint(0, 4)
+        if kind == 0:  # the usual orbit
+            pose = synth.orbit_poses(16)[rs.randint(0, 16)]
+        elif kind == 1:  # close to the model: culling keeps the whole frame or most of it
+            pose = synth.look_at_c2w(tuple(rs.uniform(-1.2, 1.2, 3)), target=tuple(rs.uniform(-0.3, 0.3, 3)))
+        elif kind == 2:  # far away: a few marked tiles in the middle
+            pose = synth.look_at_c2w(tuple(rs.uniform(6, 9, 3) * rs.choice([-1, 1], 3)), target=(0.0, 0.0, 0.0))
+        else:  # looking past it: the model in a corner or out of view
+            pose = synth.look_at_c2w(tuple(rs.uniform(2.5, 4, 3)), target=tuple(rs.uniform(-3, 3, 3)))
+        c = R.Camera(W, H, fx, fx)
+        c.set_c2w(pose)
+        cams.append(c)
+    opt = R.RenderOptions(spp=6, denoise=True, background_brightness=bg)
+    jumps = [int(j) for j in rs.randint(0, 500, n)]
+    out = {}
+    for level in (1, 2):
+        ctx = R.RenderContext(W, H, frames=n)
+        aux_v, noisy_v, image_v = views(ctx, n)
+        noisy_v.fill_(float("nan"))
+        image_v.fill_(-7.0)
+        ctx.set_lean_outputs(level)
+        ctx.rng_seed()
+        R.launch_renderer_batch(dt, cams, opt, ctx, rng_jumps=jumps)
+        noisy = []
+        for f in range(n):
+            ctx.select_frame(f)
+            noisy.append(ctx.download_image(noisy=True))
+        ctx.select_frame(0)
+        net.denoise(ctx, n=n, mode=R.FILTER_FAST)
+        torch.cuda.synchronize()
+        out[level] = (np.stack(noisy), image_v.cpu().numpy().copy())
+        ctx.free()
+    assert_bits_equal(out[2][0], out[1][0], "noisy image (completed) %dx%d n %d bg %g" % (W, H, n, bg))
+    assert_bits_equal(out[2][1], out[1][1], "denoised image %dx%d n %d bg %g" % (W, H, n, bg))

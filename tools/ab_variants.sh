@@ -8,11 +8,11 @@ D=rt-octree_amd/lib_ab
 if [ "$1" = build ]; then
   shift; rm -rf $D; mkdir -p $D; i=0
   for X in "$@"; do
-    touch rt-octree_amd/csrc/*.hip
+    touch rt-octree_amd/csrc/*.hip rt-octree_amd/csrc/*.cpp
     make -C rt-octree_amd/csrc -j8 EXTRA="$X" >/dev/null 2>&1 || { echo "build failed: $X"; exit 1; }
     cp rt-octree_amd/lib/librto.so $D/librto_$i.so; echo "$X" > $D/flags_$i.txt; i=$((i+1))
   done
-  touch rt-octree_amd/csrc/*.hip; make -C rt-octree_amd/csrc -j8 >/dev/null 2>&1
+  touch rt-octree_amd/csrc/*.hip rt-octree_amd/csrc/*.cpp; make -C rt-octree_amd/csrc -j8 >/dev/null 2>&1
   ls -la $D
 else
   R=${2:-3}

@@ -346,14 +346,14 @@ int rto_denoise(rto_guidance_net* net, rto_ctx* ctx, int n, int mode, void* stre
     // frames of a lean batched launch (rto_ctx_set_lean_outputs): their aux planes were not written, the noisy image
     // carries r, g, b, alpha -- the network reads that
     int net_flags = RTO_NET_AUX_SQUARES_IMPLIED;
-    const int lean = rto_ctx_frames_are_lean(ctx, sel, n);
+    const int lean = rto_ctx_frames_lean_level(ctx, sel, n);  // 0 full, 1 lean, 2 sparse; -1: the slots disagree
     if (lean < 0)
         return fail(RTO_E_INVALID, "rto_denoise: slots " + std::to_string(sel) + ".." + std::to_string(sel + n - 1) +
-                                       " mix lean and full outputs (a later launch rewrote some of them): denoise each run of slots by itself");
+                                       " mix full, lean and sparse outputs (a later launch rewrote some of them): denoise each run of slots by itself");
     if (lean) {
         aux = noisy;
         net_flags = RTO_NET_INPUT_RGBA;
-        if (rto_ctx_frames_lean_level(ctx, sel, n) == 2) {  // sparse: nothing was stored for the pixels of culled tiles
+        if (lean == 2) {  // sparse: nothing was stored for the pixels of culled tiles
             if (!marks)
                 return fail(RTO_E_INVALID, "rto_denoise: sparse lean frames need the tile marks of the launch that rendered them (another launch "
                                            "into this context replaced them)");

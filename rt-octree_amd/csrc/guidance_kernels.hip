@@ -40,10 +40,15 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
 constexpr int kGW = 32, kGH = 8;  // output tile
+// Tiles per workgroup, along x.  Round 2 chose 5 when every tile was computed (strips of 1 / 2 / 5 / 7..25: 0.70 / 0.64 / 0.60 /
+// 0.59-0.62 ms per 50 frames).  With the culling two thirds of the workgroups only test their tiles' marks and leave, and each of
+// those costs a launch and a dependent load: round 6 re-measured 5 / 7 / 9 / 13 tiles per workgroup at 0.686 / 0.862 / 0.626 /
+// 0.616 ms per 100 C2 frames (7 splits a 25-tile row 7 + 7 + 7 + 4) and 1.86 / - / 1.45 / 1.38 ms on C4 (60-tile rows):
+// 13 = the most that the one-thread-per-(tile, render tile) mark test below fits into 256 threads (profiles/r6_m_ab_strips*.txt)
 #ifndef RTO_NET_STRIP
-#define RTO_NET_STRIP 5
+#define RTO_NET_STRIP 13
 #endif
-constexpr int kStrip = RTO_NET_STRIP;  // tiles per workgroup, along x
+constexpr int kStrip = RTO_NET_STRIP;
 constexpr int kCIn = 8;           // aux channels (render_context.hpp:23)
 
 __device__ __forceinline__ float relu6(float x) { return fminf(fmaxf(x, 0.f), 6.f); }
@@ -88,7 +93,7 @@ __global__ void __launch_bounds__(256, IN ? 4 : RTO_NET_SQ0_WG) guidance_fused(c
                                                        const float* __restrict__ b2,     // [16]
                                                        float* __restrict__ weight_out,   // [n][L][H][W]
                                                        float* __restrict__ guidance_out, // [n][L][H][W]
-                                                       int H, int W, const NetCull cull) {
+                                                       int H, int W, const NetCull cull, const int strip /* tiles per workgroup, <= kStrip */) {
     constexpr int IW = kGW + 4, IH = kGH + 4;  // input tile with halo 2
     constexpr int AW = kGW + 2, AH = kGH + 2;  // layer-1 activation tile with halo 1
     constexpr int NT1 = C1 / 16;               // output-channel tiles of layer 1
@@ -116,7 +121,7 @@ __global__ void __launch_bounds__(256, IN ? 4 : RTO_NET_SQ0_WG) guidance_fused(c
     // 0.70 ms, 2 0.64, 5 0.60, 7..25 0.59-0.62.  (While stage B still spent ~75 VALU instructions per group the kernel
     // was issue-bound and strips gained nothing.)
     const int tiles_x = (W + kGW - 1) / kGW;
-    const int tx_first = blockIdx.x * kStrip;
+    const int tx_first = blockIdx.x * strip;
     const int y0 = blockIdx.y * kGH;
     const int64_t HW = (int64_t)H * W;
     constexpr bool SQ = IN != 0;
@@ -137,7 +142,7 @@ __global__ void __launch_bounds__(256, IN ? 4 : RTO_NET_SQ0_WG) guidance_fused(c
         if (tid < kStrip) s_rtm[tid] = 0;
         __syncthreads();
         static_assert(kStrip * RX * RY <= 256 && RX * RY <= 32, "one thread per (strip tile, render tile)");
-        if (tid < kStrip * RX * RY) {
+        if (tid < strip * RX * RY) {
             const int ts = tid / (RX * RY), sub = tid - ts * (RX * RY), sy = sub / RX, sx = sub - sy * RX;
             const int x0 = (tx_first + ts) * kGW - 2, ry0 = y0 - 2;
             bool live = false;
@@ -167,8 +172,8 @@ __global__ void __launch_bounds__(256, IN ? 4 : RTO_NET_SQ0_WG) guidance_fused(c
         skip_tiles = (uint32_t)__builtin_amdgcn_readfirstlane((int)~s_live);
     }
     auto next_live = [&](int ts) {  // first tile >= ts of the strip that has to be computed (kStrip: none)
-        while (ts < kStrip && tx_first + ts < tiles_x && ((skip_tiles >> ts) & 1u)) ++ts;
-        return (ts < kStrip && tx_first + ts < tiles_x) ? ts : kStrip;
+        while (ts < strip && tx_first + ts < tiles_x && ((skip_tiles >> ts) & 1u)) ++ts;
+        return (ts < strip && tx_first + ts < tiles_x) ? ts : kStrip;
     };
 
     // Weights first: their loads overlap stage A instead of stalling the first MFMAs of each layer.
@@ -228,7 +233,7 @@ __global__ void __launch_bounds__(256, IN ? 4 : RTO_NET_SQ0_WG) guidance_fused(c
     st[0] = __builtin_amdgcn_s_memtime();
 #endif
     if (cull.mask && !(PACK && cull.sparse)) {  // the skipped tiles first (interior tiles: every pixel of them is inside the image)
-        for (int ts = 0; ts < kStrip && tx_first + ts < tiles_x; ++ts)
+        for (int ts = 0; ts < strip && tx_first + ts < tiles_x; ++ts)
             if ((skip_tiles >> ts) & 1u) {
                 const int64_t pix = (int64_t)(y0 + (tid >> 5)) * W + (tx_first + ts) * kGW + (tid & 31);
                 if (PACK) {
@@ -444,7 +449,11 @@ hipError_t launch_guidance_net(const float* aux, const void* w1, const void* w2,
                                const float* fill_planes, int sparse, float background, hipStream_t stream) {
     if (c1 != 32 || levels != 4 || in_mode < 0 || in_mode > 2) return hipErrorInvalidValue;  // the reference configuration (blender.txt:21-25)
     const int tiles_x = (W + kGW - 1) / kGW;
-    const dim3 grid((tiles_x + kStrip - 1) / kStrip, (H + kGH - 1) / kGH, n), block(256);
+    // strips of kStrip tiles when that still leaves every CU its workgroups (a batch of frames), shorter ones for a lone frame
+    const int tiles_y = (H + kGH - 1) / kGH;
+    int strip = kStrip;
+    while (strip > 1 && (int64_t)((tiles_x + strip - 1) / strip) * tiles_y * n < 2048) --strip;
+    const dim3 grid((tiles_x + strip - 1) / strip, tiles_y, n), block(256);
     const bool pack = guidance_out == nullptr;  // weight_out is then the packed fp16 buffer [n][H][W][8]
     NetCull cull;
     cull.mask = (pack ? fill_k != nullptr : fill_planes != nullptr) ? tile_mask : nullptr;
@@ -457,7 +466,7 @@ hipError_t launch_guidance_net(const float* aux, const void* w1, const void* w2,
     cull.bg = background;
 #define RTO_NET(IN, PK)                                                                                                   \
     hipLaunchKernelGGL((guidance_fused<32, 4, IN, PK>), grid, block, 0, stream, aux, (const _Float16*)w1, (const _Float16*)w2,     \
-                       b2, weight_out, guidance_out, H, W, cull)
+                       b2, weight_out, guidance_out, H, W, cull, strip)
     if (pack) {
         if (in_mode == 2) RTO_NET(2, true); else if (in_mode == 1) RTO_NET(1, true); else RTO_NET(0, true);
     } else {

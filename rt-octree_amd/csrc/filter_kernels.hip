@@ -679,38 +679,44 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
 #pragma unroll
         for (int r = 0; r < kFastRows; ++r) o[r][0] = o[r][1] = o[r][2] = 0.f;
 
-        auto level = [&](auto l_tag) {
-            constexpr int l = decltype(l_tag)::value;
-            // ---- tile maximum / minimum of g_l over the image pixels of the staged tile
-            float mx = -3.402823466e+38f, mn = 3.402823466e+38f;
-            float gv[PER];
+        // ---- ONE constant for all levels of the tile (round 6): c = the maximum of every level's g over the image pixels of the
+        // staged tile (any constant common to a window cancels; GuidanceNet's maps lie in [0, 6]), lo = the minimum -- one
+        // reduction and one barrier per tile where each level had its own.  A tile whose values spread over more than 80 takes
+        // the per-pixel-maximum route for all its levels.
+        float mx = -3.402823466e+38f, mn = 3.402823466e+38f;
 #pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                gv[i] = gval(l, i);
-                if (inimg[i]) {
-                    mx = fmaxf(mx, gv[i]);
-                    mn = fminf(mn, gv[i]);
+        for (int i = 0; i < PER; ++i) {
+            if (inimg[i]) {
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    mx = fmaxf(mx, gval(l, i));
+                    mn = fminf(mn, gval(l, i));
                 }
             }
+        }
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                mx = fmaxf(mx, __shfl_xor(mx, d, 64));
-                mn = fminf(mn, __shfl_xor(mn, d, 64));
-            }
-            if ((tid & 63) == 0) {
-                s_red[0][tid >> 6] = mx;
-                s_red[1][tid >> 6] = mn;
-            }
-            __syncthreads();  // also: the previous level's (or tile's) box reads of s_p are done
-            const float c = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
-            const float lo = fminf(fminf(s_red[1][0], s_red[1][1]), fminf(s_red[1][2], s_red[1][3]));
-            const bool wide = !(c - lo <= 80.f);  // workgroup-uniform (NaNs take the slow route too)
+        for (int d = 32; d >= 1; d >>= 1) {
+            mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+            mn = fminf(mn, __shfl_xor(mn, d, 64));
+        }
+        if ((tid & 63) == 0) {
+            s_red[0][tid >> 6] = mx;
+            s_red[1][tid >> 6] = mn;
+        }
+        __syncthreads();  // (s_red is next written a tile -- several barriers -- later)
+        const float c = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
+        const float lo = fminf(fminf(s_red[1][0], s_red[1][1]), fminf(s_red[1][2], s_red[1][3]));
+        const bool wide = !(c - lo <= 80.f);  // workgroup-uniform (NaNs take the slow route too)
+
+        auto level = [&](auto l_tag) {
+            constexpr int l = decltype(l_tag)::value;
+            // (s_p is free: every thread is past the barrier that ended the previous level's -- or tile's -- pass A, its last reader)
             if (!wide) {
 #pragma unroll
                 for (int i = 0; i < PER; ++i) {
                     const int e = tid + i * 256;
                     if (e < NE) {
-                        const float E = inimg[i] ? __builtin_amdgcn_exp2f((gv[i] - c) * 1.44269504088896340736f) : 0.f;
+                        const float E = inimg[i] ? __builtin_amdgcn_exp2f((gval(l, i) - c) * 1.44269504088896340736f) : 0.f;
                         int ty, tx;
                         bool in_tile;
                         const int sp = elem(i, ty, tx, in_tile);
@@ -723,7 +729,7 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
                     }
                 }
             }
-            __syncthreads();  // P_l complete (and s_red may be rewritten)
+            __syncthreads();  // P_l complete (and the previous level's pass B is done with s_hs)
             const float(&wl)[kFastRows] = wl_all[l];
             if (!wide) {
                 // The box filter in two passes (round 5): the kernel was LDS-bound -- 40 M wave-level LDS instructions per 100
@@ -766,28 +772,27 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
                     }
                 }
                 __syncthreads();  // the row sums are complete (and s_p may be rewritten by the next level)
-                float4 acc[kFastRows];
+                // (packed adds: the same sums as four scalar adds per value, half the instructions)
+                float2v acc01[kFastRows], acc23[kFastRows];
 #pragma unroll
-                for (int o = 0; o < kFastRows; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int o = 0; o < kFastRows; ++o) acc01[o] = acc23[o] = float2v{0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < 2 * S + kFastRows; ++j) {
                     const float4 t = s_hs[(ry * kFastRows + j) * SWP + (lx & 1) * HALF + (lx >> 1)];
 #pragma unroll
                     for (int o = 0; o < kFastRows; ++o) {
                         if (j - o >= 0 && j - o <= 2 * S) {
-                            acc[o].x += t.x;
-                            acc[o].y += t.y;
-                            acc[o].z += t.z;
-                            acc[o].w += t.w;
+                            acc01[o] += float2v{t.x, t.y};
+                            acc23[o] += float2v{t.z, t.w};
                         }
                     }
                 }
 #pragma unroll
                 for (int r = 0; r < kFastRows; ++r) {
-                    const float ww = wl[r] / acc[r].w;
-                    o[r][0] += acc[r].x * ww;
-                    o[r][1] += acc[r].y * ww;
-                    o[r][2] += acc[r].z * ww;
+                    const float ww = wl[r] * rcp_refined(acc23[r].y);  // (the tolerance route: reciprocal + one Newton step, not an IEEE division)
+                    o[r][0] += acc01[r].x * ww;
+                    o[r][1] += acc01[r].y * ww;
+                    o[r][2] += acc23[r].x * ww;
                 }
             } else {  // per-pixel maximum, taps from global memory
 #pragma unroll

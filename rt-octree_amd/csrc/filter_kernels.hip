@@ -211,6 +211,22 @@ __device__ __forceinline__ bool sees_only_background(const FilterCull& cull, int
     return !__syncthreads_or(any);
 }
 
+// The same test without a barrier: lane (threadIdx.x & 63) of EVERY wave looks at one render tile of the region (8 x 8 lanes cover
+// its <= 7 x 5 render tiles) and returns its mark (1 where the region is not interior: computed); the region sees only background
+// when no lane of the wave holds a mark -- __builtin_amdgcn_ballot_w64(mark != 0) == 0, the same verdict in every wave.
+template <int SW, int SH>
+__device__ __forceinline__ int neighbourhood_mark(const FilterCull& cull, int sx0, int sy0, int H, int W) {
+    constexpr int RW = SW + 2 * kMapHalo, RH = SH + 2 * kMapHalo;
+    static_assert((RW + 6) / 8 + 1 <= 8 && (RH + 6) / 8 + 1 <= 8, "8 x 8 lanes cover the region's render tiles");
+    const int rx0 = sx0 - kMapHalo, ry0 = sy0 - kMapHalo;
+    if (!(rx0 >= 0 && ry0 >= 0 && rx0 + RW <= W && ry0 + RH <= H)) return 1;  // (the zero padding is not background)
+    const uint32_t* fm = cull.mask + (size_t)blockIdx.z * cull.mask_words;
+    const int ln = (int)threadIdx.x & 63, tx = (rx0 >> 3) + (ln & 7), ty = (ry0 >> 3) + (ln >> 3);
+    if (tx > ((rx0 + RW - 1) >> 3) || ty > ((ry0 + RH - 1) >> 3)) return 0;
+    const uint32_t t = (uint32_t)(ty * cull.tiles_x + tx);
+    return (int)(((fm[t >> 5] >> (t & 31u)) | fm[cull.mask_words - 1]) & 1u);
+}
+
 // SAVE: the training forward (Filtering::forward with requires_grad, filtering.cu:596-665) -- the same
 // pass, also storing rgb_filtered [n][L][H][W] (float4), max_map and inv_kernel_sum [n][L][H][W]
 template <int L, bool SAVE>
@@ -495,9 +511,16 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
     // tiles of the strip that see only background: filled from the measured tile, not computed (bit ts; workgroup-uniform)
     uint32_t skip = 0;
     if (cull.mask) {
+        // (round 6: every wave tests all the strip's tiles for itself -- lane = one render tile of a tile's neighbourhood, the strip's
+        //  mark words requested together, the verdicts by ballot; the workgroup-wide form took a dependent load and a barrier per
+        //  tile, five in a row before a workgroup -- two thirds of them only fill -- had anything to do)
+        int marked[kFastStrip];
 #pragma unroll
         for (int ts = 0; ts < kFastStrip; ++ts)
-            if (ts < strip && tx_first + ts < tiles_x && sees_only_background<SW, SH>(cull, (tx_first + ts) * kFastW - L, y0, H, W)) skip |= 1u << ts;
+            marked[ts] = ts < strip && tx_first + ts < tiles_x ? neighbourhood_mark<SW, SH>(cull, (tx_first + ts) * kFastW - L, y0, H, W) : 1;
+#pragma unroll
+        for (int ts = 0; ts < kFastStrip; ++ts)
+            if (__builtin_amdgcn_ballot_w64(marked[ts] != 0) == 0ull) skip |= 1u << ts;
         for (int ts = 0; ts < strip && tx_first + ts < tiles_x; ++ts)
             if ((skip >> ts) & 1u) {
 #pragma unroll

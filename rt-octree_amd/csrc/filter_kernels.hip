@@ -175,20 +175,6 @@ struct FilterCull {
     uint4 fill_maps;
 };
 
-// guidance_fused's decision to skip a 32 x 8 output tile (guidance_kernels.hip: its 36 x 12 input region lies inside the image
-// and in unmarked render tiles), restated for the filter that has to know which map pixels were never stored
-__device__ __forceinline__ bool net_tile_was_skipped(const uint32_t* fm, int mask_words, int tiles_x8, int H, int W, int ntx, int nty) {
-    const int x0 = ntx * 32 - 2, y0 = nty * 8 - 2;
-    if (ntx < 0 || nty < 0 || ntx * 32 >= W || nty * 8 >= H) return false;
-    if (x0 < 0 || y0 < 0 || x0 + 36 > W || y0 + 12 > H) return false;  // (its zero padding is not background: computed)
-    if (fm[mask_words - 1] & 1u) return false;                           // keep-all frame
-    for (int ty = y0 >> 3; ty <= (y0 + 11) >> 3; ++ty)
-        for (int tx = x0 >> 3; tx <= (x0 + 35) >> 3; ++tx) {
-            const uint32_t t = (uint32_t)(ty * tiles_x8 + tx);
-            if ((fm[t >> 5] >> (t & 31u)) & 1u) return false;
-        }
-    return true;
-}
 constexpr int kMapHalo = 2;  // a GuidanceNet map value depends on the 5x5 aux pixels around it (two 3x3 convolutions)
 
 // A workgroup whose staged region (outputs + halo, RW x RH pixels from (rx0, ry0)), grown by the network's receptive field,
@@ -209,22 +195,6 @@ __device__ __forceinline__ bool sees_only_background(const FilterCull& cull, int
         any = (int)(((fm[t >> 5] >> (t & 31u)) | fm[cull.mask_words - 1]) & 1u);
     }
     return !__syncthreads_or(any);
-}
-
-// The same test without a barrier: lane (threadIdx.x & 63) of EVERY wave looks at one render tile of the region (8 x 8 lanes cover
-// its <= 7 x 5 render tiles) and returns its mark (1 where the region is not interior: computed); the region sees only background
-// when no lane of the wave holds a mark -- __builtin_amdgcn_ballot_w64(mark != 0) == 0, the same verdict in every wave.
-template <int SW, int SH>
-__device__ __forceinline__ int neighbourhood_mark(const FilterCull& cull, int sx0, int sy0, int H, int W) {
-    constexpr int RW = SW + 2 * kMapHalo, RH = SH + 2 * kMapHalo;
-    static_assert((RW + 6) / 8 + 1 <= 8 && (RH + 6) / 8 + 1 <= 8, "8 x 8 lanes cover the region's render tiles");
-    const int rx0 = sx0 - kMapHalo, ry0 = sy0 - kMapHalo;
-    if (!(rx0 >= 0 && ry0 >= 0 && rx0 + RW <= W && ry0 + RH <= H)) return 1;  // (the zero padding is not background)
-    const uint32_t* fm = cull.mask + (size_t)blockIdx.z * cull.mask_words;
-    const int ln = (int)threadIdx.x & 63, tx = (rx0 >> 3) + (ln & 7), ty = (ry0 >> 3) + (ln >> 3);
-    if (tx > ((rx0 + RW - 1) >> 3) || ty > ((ry0 + RH - 1) >> 3)) return 0;
-    const uint32_t t = (uint32_t)(ty * cull.tiles_x + tx);
-    return (int)(((fm[t >> 5] >> (t & 31u)) | fm[cull.mask_words - 1]) & 1u);
 }
 
 // SAVE: the training forward (Filtering::forward with requires_grad, filtering.cu:596-665) -- the same
@@ -502,71 +472,85 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
     guidance += (int64_t)blockIdx.z * L * HW;
     img_in += (int64_t)blockIdx.z * HW;
     img_out += (int64_t)blockIdx.z * HW;
-    typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
     typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
     const _Float16* packed = reinterpret_cast<const _Float16*>(weight);
     const int lx = tid & (kFastW - 1), ry = tid / kFastW;  // column, row group
     const int py0 = blockIdx.y * kFastH + ry * kFastRows;
 
-    // tiles of the strip that see only background: filled from the measured tile, not computed (bit ts; workgroup-uniform)
-    uint32_t skip = 0;
+    // Everything the culling needs -- which tiles of the strip see only background (filled from the measured tile, not computed:
+    // bit ts of `skip`), and for sparse frames which network tiles under the staged region stored no maps (`nskip`) and which
+    // render tiles stored their pixels (`rm`) -- follows from ONE bitmap of render-tile marks: 6 tile rows from R0 = (y0 >> 3) - 1,
+    // 32 columns from C0 = 4 tx_first - 5, bit c of rm[r].  Every wave builds it for itself (round 6): lane = one render tile,
+    // three independent mark words per lane requested together, the rows by ballot -- no LDS, no barrier, one memory round trip.
+    // (Before: a dependent load + barrier per strip tile, then up to ten dependent mark loads per network tile -- 8-25 k clocks of
+    //  a computing workgroup's ~90 k went by before its first pixel load, profiles/r6_p_filter_stamps.txt.)
+    uint32_t skip = 0, nskip = 0, rm[6] = {0, 0, 0, 0, 0, 0};
+    const int R0 = (y0 >> 3) - 1, C0 = 4 * tx_first - 5;
+    const int ntx0 = (tx_first * kFastW - L) >> 5, nty0 = y0 >> 3;  // first network tile (32 x 8) under the staged region
+    static_assert(kFastW == 32 && kFastH == 16 && L <= 6 && kFastStrip <= 5, "6 rows x 32 columns of render tiles cover a strip's neighbourhoods");
     if (cull.mask) {
-        // (round 6: every wave tests all the strip's tiles for itself -- lane = one render tile of a tile's neighbourhood, the strip's
-        //  mark words requested together, the verdicts by ballot; the workgroup-wide form took a dependent load and a barrier per
-        //  tile, five in a row before a workgroup -- two thirds of them only fill -- had anything to do)
-        int marked[kFastStrip];
+        const uint32_t* const fm = cull.mask + (size_t)blockIdx.z * cull.mask_words;
+        const int ln = tid & 63;
+        const uint32_t keep_all = fm[cull.mask_words - 1] & 1u;
+        uint32_t word[3];
+        bool inside[3];
 #pragma unroll
-        for (int ts = 0; ts < kFastStrip; ++ts)
-            marked[ts] = ts < strip && tx_first + ts < tiles_x ? neighbourhood_mark<SW, SH>(cull, (tx_first + ts) * kFastW - L, y0, H, W) : 1;
+        for (int k = 0; k < 3; ++k) {  // render tile (row R0 + 2 k + (lane >> 5), column C0 + (lane & 31))
+            const int ty = R0 + 2 * k + (ln >> 5), tx = C0 + (ln & 31);
+            inside[k] = tx >= 0 && ty >= 0 && tx < cull.tiles_x && ty * 8 < H;
+            const uint32_t t = inside[k] ? (uint32_t)(ty * cull.tiles_x + tx) : 0u;
+            word[k] = fm[t >> 5] >> (t & 31u);
+        }
 #pragma unroll
-        for (int ts = 0; ts < kFastStrip; ++ts)
-            if (__builtin_amdgcn_ballot_w64(marked[ts] != 0) == 0ull) skip |= 1u << ts;
+        for (int k = 0; k < 3; ++k) {
+            const unsigned long long b = __builtin_amdgcn_ballot_w64(inside[k] && ((word[k] | keep_all) & 1u) != 0u);
+            rm[2 * k] = (uint32_t)b;
+            rm[2 * k + 1] = (uint32_t)(b >> 32);
+        }
+        // a tile sees only background when its staged region, grown by the network's receptive field, lies inside the image and in
+        // unmarked render tiles (sees_only_background above, from the bitmap; all scalar)
+#pragma unroll
+        for (int ts = 0; ts < kFastStrip; ++ts) {
+            constexpr int RW = SW + 2 * kMapHalo, RH = SH + 2 * kMapHalo;
+            const int rx0 = (tx_first + ts) * kFastW - L - kMapHalo, ry0 = y0 - kMapHalo;
+            if (ts < strip && tx_first + ts < tiles_x && rx0 >= 0 && ry0 >= 0 && rx0 + RW <= W && ry0 + RH <= H) {
+                uint32_t m = 0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+                    if (R0 + r >= (ry0 >> 3) && R0 + r <= ((ry0 + RH - 1) >> 3)) m |= rm[r];
+                const int lo = (rx0 >> 3) - C0, n = ((rx0 + RW - 1) >> 3) - (rx0 >> 3) + 1;  // 0 <= lo, lo + n <= 32
+                if (((m >> lo) & ((1u << n) - 1u)) == 0u) skip |= 1u << ts;
+            }
+        }
         for (int ts = 0; ts < strip && tx_first + ts < tiles_x; ++ts)
             if ((skip >> ts) & 1u) {
 #pragma unroll
                 for (int r = 0; r < kFastRows; ++r)
                     img_out[(int64_t)(py0 + r) * W + (tx_first + ts) * kFastW + lx] = cull.fill[(ry * kFastRows + r) * kFastW + lx];
             }
+        // sparse frames: guidance_fused's decision to skip a 32 x 8 output tile (its 36 x 12 input region inside the image and in
+        // unmarked render tiles -- guidance_kernels.hip `skip_tiles`), restated for the network tile (ntx0 + (lane & 7), nty0 + (lane >> 3)) -- bit
+        // lane of `nskip`; the staged region spans at most strip + 2 <= 7 columns and 4 rows of them
+        if (PACKED && cull.sparse) {
+            const int c = ln & 7, r = (ln >> 3) & 3, ntx = ntx0 + c, nty = nty0 + r;
+            const int nx0 = ntx * 32 - 2, ny0 = nty * 8 - 2;
+            // (its render-tile rows nty - 1 .. nty + 1 are rows r .. r + 2 of the bitmap, its columns 4 ntx - 1 .. 4 ntx + 4 bits 4 c ..)
+            const uint32_t m0 = rm[0] | rm[1] | rm[2], m1 = rm[1] | rm[2] | rm[3], m2 = rm[2] | rm[3] | rm[4], m3 = rm[3] | rm[4] | rm[5];
+            const uint32_t m = r == 0 ? m0 : r == 1 ? m1 : r == 2 ? m2 : m3;
+            const bool sk = ln < 32 && c <= kFastStrip + 1 && ntx >= 0 && nty >= 0 && ntx * 32 < W && nty * 8 < H && nx0 >= 0 && ny0 >= 0 &&
+                            nx0 + 36 <= W && ny0 + 12 <= H && ((m >> (4 * c)) & 0x3fu) == 0u;
+            nskip = (uint32_t)__builtin_amdgcn_ballot_w64(sk);
+        }
     }
     auto next_live = [&](int ts) {  // first tile >= ts of the strip that has to be computed (kFastStrip: none)
         while (ts < strip && tx_first + ts < tiles_x && ((skip >> ts) & 1u)) ++ts;
         return (ts < strip && tx_first + ts < tiles_x) ? ts : kFastStrip;
     };
-    // sparse frames: the network tiles under this strip's staged region whose maps were never stored -- bit (row - nty0) * 8 +
-    // (column - ntx0) of `nskip`; the region spans at most strip + 2 <= 7 columns and 4 rows of 32 x 8 tiles
-    const uint32_t* const fmask = cull.mask ? cull.mask + (size_t)blockIdx.z * cull.mask_words : nullptr;
-    const int ntx0 = (tx_first * kFastW - L) >> 5, nty0 = y0 >> 3;
-    // ... and the marks of the render tiles (8 x 8) under it, one word per tile row: bit (column - rtx0) of rmark[row - nty0]
-    // (at most (strip * 32 + 2 L + 7) / 8 + 1 <= 22 columns, 4 rows); wave-uniform values in SGPRs: a staged element's test is
-    // shifts and selects, no load, no division
-    const int rtx0 = (tx_first * kFastW - L) >> 3;
-    uint32_t nskip = 0, rmark[4] = {0, 0, 0, 0};
-    if (PACKED && cull.sparse && next_live(0) < kFastStrip) {  // (a strip without a computed tile stages nothing)
-        static_assert(!PACKED || (kFastStrip + 2 <= 8 && (kFastH + 2 * L + 7) / 8 + 1 <= 4 && (kFastStrip * kFastW + 2 * L + 7) / 8 + 1 <= 32),
-                      "bit budget of the skipped-network-tile mask and of the render-tile rows");
-        // (every wave evaluates all of it for itself -- 32 + 128 predicates, a few cached mask words each -- and takes the bits by
-        //  ballot: no LDS, no barrier, and the loads go out with the kernel's first ones)
-        const int ln = tid & 63;
-        const bool sk = ln < 32 && net_tile_was_skipped(fmask, cull.mask_words, cull.tiles_x, H, W, ntx0 + (ln & 7), nty0 + (ln >> 3));
-        nskip = (uint32_t)__builtin_amdgcn_ballot_w64(sk);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {  // render tile (row 2 * half + (lane >> 5), column lane & 31) of the region
-            const int ty = nty0 + 2 * half + (ln >> 5), tx = rtx0 + (ln & 31);
-            bool marked = false;
-            if (tx >= 0 && ty >= 0 && tx < cull.tiles_x && ty * 8 < H) {
-                const uint32_t t = (uint32_t)(ty * cull.tiles_x + tx);
-                marked = (((fmask[t >> 5] >> (t & 31u)) | fmask[cull.mask_words - 1]) & 1u) != 0u;
-            }
-            const unsigned long long b = __builtin_amdgcn_ballot_w64(marked);
-            rmark[2 * half] = (uint32_t)b;
-            rmark[2 * half + 1] = (uint32_t)(b >> 32);
-        }
-    }
     auto maps_stored = [&](int gx, int gy) { return ((nskip >> ((((gy >> 3) - nty0) << 3) + ((gx >> 5) - ntx0))) & 1u) == 0u; };
-    auto pixel_stored = [&](int gx, int gy) {  // its render tile is marked: the shading kernel wrote it
+    auto pixel_stored = [&](int gx, int gy) {  // its render tile is marked: the shading kernel wrote it (staged rows: bitmap rows 1..4)
         const int r = (gy >> 3) - nty0;
-        const uint32_t w = r == 0 ? rmark[0] : r == 1 ? rmark[1] : r == 2 ? rmark[2] : rmark[3];
-        return ((w >> ((gx >> 3) - rtx0)) & 1u) != 0u;
+        const uint32_t w = r == 0 ? rm[1] : r == 1 ? rm[2] : r == 2 ? rm[3] : rm[4];
+        return ((w >> ((gx >> 3) - C0)) & 1u) != 0u;
     };
 
     // what a tile's computation needs from memory, as it arrives: the staged noisy pixels, the guidance values of the staged

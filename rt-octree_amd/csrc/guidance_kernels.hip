@@ -133,48 +133,46 @@ __global__ void __launch_bounds__(256, IN ? 4 : RTO_NET_SQ0_WG) guidance_fused(c
 
     // Tiles of the strip whose input region (tile + halo 2) lies inside the image and in culled render tiles read nothing
     // but background: every output pixel is cull.fill.  Bit ts of `skip_tiles`; workgroup-uniform.
+    // Round 6: every wave builds the marks of the render tiles under the strip's input regions for itself -- 3 tile rows from
+    // (y0 - 2) >> 3, 64 columns from 4 tx_first - 1 (a tile's region spans 6 of them from bit 4 ts), lane = column, the three mark
+    // words of a lane requested together, the rows by ballot: one memory round trip, no LDS, no barrier (the first form tested one
+    // (tile, render tile) per thread into LDS words under two barriers).  A workgroup with nothing to compute leaves before it
+    // has requested a single weight.
     uint32_t skip_tiles = 0;
     constexpr int RX = (IW + 7) / 8 + 1, RY = (IH + 7) / 8 + 1;  // render tiles an input region can touch, per axis
-    __shared__ uint32_t s_rtm[kStrip];  // sparse input: bit sy * RX + sx = render tile (sx, sy) of strip tile ts's input region is marked
+    static_assert(RX == 6 && RY == 3 && 4 * (kStrip - 1) + RX <= 64, "64 columns x 3 rows of render tiles cover a strip's input regions");
+    unsigned long long rmk[RY] = {0ull, 0ull, 0ull};  // bit c of rmk[r]: render tile (4 tx_first - 1 + c, ((y0 - 2) >> 3) + r) is marked
     if (cull.mask) {
-        __shared__ uint32_t s_live;
-        if (tid == 0) s_live = 0;
-        if (tid < kStrip) s_rtm[tid] = 0;
-        __syncthreads();
-        static_assert(kStrip * RX * RY <= 256 && RX * RY <= 32, "one thread per (strip tile, render tile)");
-        if (tid < strip * RX * RY) {
-            const int ts = tid / (RX * RY), sub = tid - ts * (RX * RY), sy = sub / RX, sx = sub - sy * RX;
-            const int x0 = (tx_first + ts) * kGW - 2, ry0 = y0 - 2;
-            bool live = false;
-            if (cull.sparse && tx_first + ts < tiles_x) {  // (also for regions that reach over the frame: their in-frame pixels may be unstored)
-                const int tx = (x0 >> 3) + sx, ty = (ry0 >> 3) + sy;
-                if (tx >= 0 && ty >= 0 && tx < cull.tiles_x && ty * 8 < H) {
-                    const uint32_t* fm = cull.mask + (size_t)blockIdx.z * cull.mask_words;
-                    const uint32_t t = (uint32_t)(ty * cull.tiles_x + tx);
-                    if (((fm[t >> 5] >> (t & 31u)) | fm[cull.mask_words - 1]) & 1u) atomicOr(&s_rtm[ts], 1u << sub);
-                }
-            }
-            if (tx_first + ts < tiles_x) {
-                if (x0 < 0 || ry0 < 0 || x0 + IW > W || ry0 + IH > H) {
-                    live = true;  // the zero padding is not background
-                } else {
-                    const int tx = (x0 >> 3) + sx, ty = (ry0 >> 3) + sy;
-                    if (tx <= ((x0 + IW - 1) >> 3) && ty <= ((ry0 + IH - 1) >> 3)) {
-                        const uint32_t* fm = cull.mask + (size_t)blockIdx.z * cull.mask_words;
-                        const uint32_t t = (uint32_t)(ty * cull.tiles_x + tx);
-                        live = (((fm[t >> 5] >> (t & 31u)) | fm[cull.mask_words - 1]) & 1u) != 0;
-                    }
-                }
-            }
-            if (live) atomicOr(&s_live, 1u << ts);
+        const uint32_t* const fm = cull.mask + (size_t)blockIdx.z * cull.mask_words;
+        const uint32_t keep_all = fm[cull.mask_words - 1] & 1u;
+        uint32_t word[RY];
+        bool inside[RY];
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            const int tx = 4 * tx_first - 1 + lane, ty = ((y0 - 2) >> 3) + r;
+            inside[r] = tx >= 0 && ty >= 0 && tx < cull.tiles_x && ty * 8 < H;
+            const uint32_t t = inside[r] ? (uint32_t)(ty * cull.tiles_x + tx) : 0u;
+            word[r] = fm[t >> 5] >> (t & 31u);
         }
-        __syncthreads();
-        skip_tiles = (uint32_t)__builtin_amdgcn_readfirstlane((int)~s_live);
+#pragma unroll
+        for (int r = 0; r < RY; ++r) rmk[r] = __builtin_amdgcn_ballot_w64(inside[r] && ((word[r] | keep_all) & 1u) != 0u);
+        const unsigned long long any_row = rmk[0] | rmk[1] | rmk[2];
+        for (int ts = 0; ts < strip && tx_first + ts < tiles_x; ++ts) {
+            const int x0 = (tx_first + ts) * kGW - 2, ry0 = y0 - 2;
+            // (outside the image the zero padding is not background: computed)
+            if (x0 >= 0 && ry0 >= 0 && x0 + IW <= W && ry0 + IH <= H && ((any_row >> (4 * ts)) & 0x3full) == 0ull) skip_tiles |= 1u << ts;
+        }
     }
+    // sparse input: bit sy * RX + sx = render tile (sx, sy) of strip tile ts's input region is marked (its pixels were stored)
+    auto region_marks = [&](int ts) {
+        return (uint32_t)((rmk[0] >> (4 * ts)) & 0x3full) | (uint32_t)((rmk[1] >> (4 * ts)) & 0x3full) << RX |
+               (uint32_t)((rmk[2] >> (4 * ts)) & 0x3full) << (2 * RX);
+    };
     auto next_live = [&](int ts) {  // first tile >= ts of the strip that has to be computed (kStrip: none)
         while (ts < strip && tx_first + ts < tiles_x && ((skip_tiles >> ts) & 1u)) ++ts;
         return (ts < strip && tx_first + ts < tiles_x) ? ts : kStrip;
     };
+    if (PACK && cull.sparse && next_live(0) == kStrip) return;  // (sparse maps: nothing is stored for a skipped tile either)
 
     // Weights first: their loads overlap stage A instead of stalling the first MFMAs of each layer.
     half8 wa[NT1][3];
@@ -200,7 +198,7 @@ __global__ void __launch_bounds__(256, IN ? 4 : RTO_NET_SQ0_WG) guidance_fused(c
     auto fetch = [&](int x0) {  // issue the loads of the tile whose first output column is x0
         // (sparse: the marks of the render tiles under this tile's input region, in an SGPR -- whether a pixel was stored is known
         //  before its load is issued, which is then simply not issued: no dependent mask load, no select that waits for the pixel)
-        const uint32_t rtm = cull.sparse ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rtm[x0 / kGW - tx_first]) : 0u;
+        const uint32_t rtm = cull.sparse ? region_marks(x0 / kGW - tx_first) : 0u;
         const int rtx0 = (x0 - 2) >> 3, rty0 = (y0 - 2) >> 3;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {

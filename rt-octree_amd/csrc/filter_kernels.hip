@@ -546,13 +546,6 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
         while (ts < strip && tx_first + ts < tiles_x && ((skip >> ts) & 1u)) ++ts;
         return (ts < strip && tx_first + ts < tiles_x) ? ts : kFastStrip;
     };
-    auto maps_stored = [&](int gx, int gy) { return ((nskip >> ((((gy >> 3) - nty0) << 3) + ((gx >> 5) - ntx0))) & 1u) == 0u; };
-    auto pixel_stored = [&](int gx, int gy) {  // its render tile is marked: the shading kernel wrote it (staged rows: bitmap rows 1..4)
-        const int r = (gy >> 3) - nty0;
-        const uint32_t w = r == 0 ? rm[1] : r == 1 ? rm[2] : r == 2 ? rm[3] : rm[4];
-        return ((w >> ((gx >> 3) - C0)) & 1u) != 0u;
-    };
-
     // what a tile's computation needs from memory, as it arrives: the staged noisy pixels, the guidance values of the staged
     // elements and the weights of this thread's outputs (packed: raw fp16 maps, converted when the tile's turn comes)
     // (packed: raw fp16 values -- of a staged element only its 4 guidance values, 8 bytes -- converted where they are used)
@@ -595,35 +588,82 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
         int gx, gy;
         return gindex_xy(x0, i, gx, gy);
     };
+    // Packed form, round 6: what decides a staged element's loads -- is it inside the image, was its pixel stored, were its maps
+    // stored -- depends on the tile only through the tile's position in the strip, so it is worked out ONCE per strip into three
+    // registers: bit 4 ts + i of `imgbits` = element i is inside the image when strip tile ts is staged, the same bit of `pixbits` =
+    // its pixel is in memory, bit 8 i + ts of `mapbits` = its maps are.  A tile's fetch then tests bits.  (The first form re-derived
+    // all of it per tile and element: ~280 of a tile's ~1080 vector instructions and a dozen branches per element.)
+    uint32_t imgbits = 0, pixbits = 0, mapbits = 0;
+    if constexpr (PACKED) {
+        if (next_live(0) < kFastStrip) {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                int ty, tx;
+                bool in_tile;
+                elem(i, ty, tx, in_tile);
+                const int gy = y0 + ty, rr = (gy >> 3) - R0;  // (staged rows: bitmap rows 1..4)
+                const bool yok = in_tile && gy >= 0 && gy < H;
+                const uint32_t roww = rr == 1 ? rm[1] : rr == 2 ? rm[2] : rr == 3 ? rm[3] : rm[4];
+                const int kc = ((tx - L) >> 3) + 5;  // bitmap column of this element in the strip's first tile; + 4 per tile
+                const int kn = ((tx - L) >> 5) + 1;  // network-tile column of it there, from ntx0; + 1 per tile
+                const uint32_t pb = cull.sparse ? (roww >> kc) & 0x11111u : 0x11111u;           // bits 4 ts
+                const uint32_t nb = cull.sparse ? ~(nskip >> (8 * (rr - 1) + kn)) & 0x1fu : 0x1fu;  // bits ts
+                uint32_t xs = 0, xb = 0;  // its column is inside the image: bits 4 ts / bits ts
+#pragma unroll
+                for (int ts = 0; ts < kFastStrip; ++ts) {
+                    const int gx = (tx_first + ts) * kFastW - L + tx;
+                    const uint32_t ok = yok && gx >= 0 && gx < W ? 1u : 0u;
+                    xs |= ok << (4 * ts);
+                    xb |= ok << ts;
+                }
+                imgbits |= xs << i;
+                pixbits |= (pb & xs) << i;
+                mapbits |= (nb & xb) << (8 * i);
+            }
+        }
+    }
+    static_assert(!PACKED || (PER <= 4 && kFastStrip <= 5), "bit budget of imgbits / pixbits / mapbits");
+    // this thread's outputs sit in network-tile row (wave >> 1) + 1 of the region (kFastRows = 2 rows of one 8-row tile), column ts + 1
+    const uint32_t outbits = (uint32_t)__builtin_amdgcn_readfirstlane((int)(~(nskip >> (8 * ((ry >> 2) + 1) + 1)) & 0x1fu));
+    static_assert(kFastRows == 2 && kFastH == 16, "a thread's two output rows share a network tile; row = wave >> 1");
     auto fetch = [&](int tile, Fetched& f) {
         const int x0 = tile * kFastW - L, px = tile * kFastW + lx;
+        if constexpr (PACKED) {
+            // (sparse: whether a value exists in memory is known from registers BEFORE its load is issued, so the load is simply not
+            //  issued for the lanes that take the constant -- a select on the loaded value would make this prefetch wait for it)
+            const int ts = tile - tx_first;
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            int gx, gy;
-            const int gi = gindex_xy(x0, i, gx, gy);
-            if constexpr (PACKED) {
-                // (sparse: whether a value exists in memory is known from registers BEFORE its load is issued, so the load is simply
-                //  not issued for the lanes that take the constant -- a select on the loaded value would make this prefetch wait for it)
-                const bool ld_rgb = gi >= 0 && (!cull.sparse || pixel_stored(gx, gy));
-                const bool ld_map = gi >= 0 && (!cull.sparse || maps_stored(gx, gy));
-                const float bgv = gi >= 0 ? cull.bg : 0.f;  // (only ever used when sparse)
+            for (int i = 0; i < PER; ++i) {
+                int ty, tx;
+                bool in_tile;
+                elem(i, ty, tx, in_tile);
+                const int gi = (y0 + ty) * W + x0 + tx;  // (used only where the bits say it is inside; a frame has < 2^31 pixels)
+                const bool in = ((imgbits >> (4 * ts + i)) & 1u) != 0u;
+                const bool ld_rgb = ((pixbits >> (4 * ts + i)) & 1u) != 0u, ld_map = ((mapbits >> (8 * i + ts)) & 1u) != 0u;
+                const float bgv = in ? cull.bg : 0.f;  // (only ever used when sparse)
                 f.rgb[i] = make_float4(bgv, bgv, bgv, 0.f);
                 if (ld_rgb) f.rgb[i] = img_in[gi];
-                f.hg[i] = gi >= 0 ? __builtin_bit_cast(half4_t, make_uint2(cull.fill_maps.z, cull.fill_maps.w)) : half4_t{0, 0, 0, 0};
+                f.hg[i] = in ? __builtin_bit_cast(half4_t, make_uint2(cull.fill_maps.z, cull.fill_maps.w)) : half4_t{0, 0, 0, 0};
                 if (ld_map) f.hg[i] = *reinterpret_cast<const half4_t*>(packed + (int64_t)gi * 8 + 4);
-            } else {
+            }
+            const bool out_stored = !cull.sparse || ((outbits >> ts) & 1u) != 0u;  // (wave-uniform)
+#pragma unroll
+            for (int r = 0; r < kFastRows; ++r) {
+                const bool in = px < W && py0 + r < H;
+                f.hw[r] = in ? __builtin_bit_cast(half4_t, make_uint2(cull.fill_maps.x, cull.fill_maps.y)) : half4_t{0, 0, 0, 0};
+                if (in && out_stored) f.hw[r] = *reinterpret_cast<const half4_t*>(packed + ((int64_t)(py0 + r) * W + px) * 8);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int gi = gindex(x0, i);
                 if (tid + i * 256 < NE) s_rgb[tid + i * 256] = gi >= 0 ? img_in[gi] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int l = 0; l < L; ++l) f.gv[l][i] = gi >= 0 ? guidance[l * HW + gi] : 0.f;
             }
-        }
 #pragma unroll
-        for (int r = 0; r < kFastRows; ++r) {
-            const bool in = px < W && py0 + r < H;
-            if constexpr (PACKED) {
-                f.hw[r] = in ? __builtin_bit_cast(half4_t, make_uint2(cull.fill_maps.x, cull.fill_maps.y)) : half4_t{0, 0, 0, 0};
-                if (in && (!cull.sparse || maps_stored(px, py0 + r))) f.hw[r] = *reinterpret_cast<const half4_t*>(packed + ((int64_t)(py0 + r) * W + px) * 8);
-            } else {
+            for (int r = 0; r < kFastRows; ++r) {
+                const bool in = px < W && py0 + r < H;
 #pragma unroll
                 for (int l = 0; l < L; ++l) f.wl[l][r] = in ? weight[l * HW + (int64_t)(py0 + r) * W + px] : 0.f;
             }
@@ -655,7 +695,7 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
         }
         bool inimg[PER];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) inimg[i] = gindex(x0, i) >= 0;
+        for (int i = 0; i < PER; ++i) inimg[i] = PACKED ? ((imgbits >> (4 * (tile - tx_first) + i)) & 1u) != 0u : gindex(x0, i) >= 0;
         auto gval = [&](int l, int i) -> float {
             if constexpr (PACKED)
                 return (float)cur.hg[i][l];

@@ -452,7 +452,11 @@ int rto_probe_math(int fn, uint32_t first_bits, uint32_t stride, uint32_t count,
  * that must return the float of the plain statement for every argument.  mode 0: the short sigmoid against the plain one
  * for the floats t with bit patterns first_bits + i, i < count (<= 2^32), times every sample count cnt_lo .. cnt_hi
  * (1 .. 32); mode 1: the short division cnt / d alone, for d = those floats (callers pass [1, 2^126)).  Both sides run on
- * the device.  out3[0] = pairs that differ, out3[1] = the first of them (bits << 8 | cnt; ~0 if none), out3[2] = pairs compared. */
+ * the device.  out3[0] = pairs that differ, out3[1] = the first of them (bits << 8 | cnt; ~0 if none), out3[2] = pairs compared.
+ * Modes 2 / 3: the shading kernels' one-instruction `(float)half * b` (v_fma_mix_f32 with a -0.0 addend; rt_core.cuh:286-312's
+ * 48 products per hit entry) against convert-then-multiply, for the floats b = first_bits + i (mode 2; times the 16 special
+ * halves selected by cnt 1 .. 16) or first_bits + 4099 i (mode 3; times halves 2048 (cnt - 1) .. 2048 cnt - 1: all 65536 over
+ * cnt 1 .. 32), in both packed positions. */
 int rto_probe_sigmoid(int mode, uint32_t first_bits, uint64_t count, int cnt_lo, int cnt_hi, uint64_t* out3);
 
 #ifdef __cplusplus

@@ -199,17 +199,34 @@ extern "C" int rto_probe_math(int fn, uint32_t first_bits, uint32_t stride, uint
 // plain statement's det_expf is the function the sweep above pins to the oracle).  mode 0: sigmoid_cnt3 for the floats t with
 // bit patterns first_bits + i, i < count, as each of the three channels in turn, times every sample count cnt_lo .. cnt_hi;
 // mode 1: div_small_by_ge1(cnt, d) against cnt / d for the floats d (callers pass bit patterns of [1, 2^126)).
+// modes 2 / 3: mul_half_lo / _hi (one v_fma_mix_f32) against convert + multiply, see the kernel.
 // out[0] = mismatching (value, cnt) pairs, out[1] = the first one found (bits << 8 | cnt), out[2] = pairs compared.
+// halves a rounding or denormal shortcut would show on: zeros, the denormal range's ends, the normal range's ends, infinities, odd mantissas
+__constant__ uint32_t kSpecialHalves[16] = {0x0000u, 0x8000u, 0x0001u, 0x8001u, 0x03ffu, 0x83ffu, 0x0400u, 0x7bffu,
+                                            0xfbffu, 0x3c00u, 0xbc01u, 0x3555u, 0x7c00u, 0xfc00u, 0x0155u, 0x6aabu};
 __global__ void __launch_bounds__(256) sigmoid_probe_kernel(int mode, uint32_t first_bits, uint64_t count, int cnt_lo, int cnt_hi,
                                                             unsigned long long* __restrict__ out) {
     unsigned long long bad = 0, first_bad = ~0ULL, done = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256u) {
-        const uint32_t bits = first_bits + (uint32_t)i;
+        const uint32_t bits = mode == 3 ? first_bits + (uint32_t)i * 4099u : first_bits + (uint32_t)i;  // (mode 3: a stride over the whole range)
         const float v = __uint_as_float(bits);
         for (int c = cnt_lo; c <= cnt_hi; ++c) {
             const float cnt = (float)c;
             bool differ;
-            if (mode == 0) {
+            if (mode >= 2) {
+                // the one-instruction multiply by a widened half (mul_half_lo / _hi) against convert + multiply: v = the float
+                // operand; mode 2: 16 special halves per float (index c - 1 < 16), mode 3: 2048 halves per float and loop step c
+                // (all 65536 over c = 1 .. 32)
+                differ = false;
+                const int nh = mode == 2 ? 1 : 2048;
+                for (int k = 0; k < nh && !differ; ++k) {
+                    const uint32_t hb = mode == 2 ? kSpecialHalves[(c - 1) & 15] : (uint32_t)((c - 1) * 2048 + k);
+                    const float want = rto::half_bits_to_float((uint16_t)hb) * v;
+                    const float lo = rto::mul_half_lo(hb | 0xabcd0000u, v), hi = rto::mul_half_hi((hb << 16) | 0x1234u, v);
+                    const uint32_t w = __float_as_uint(want);
+                    differ = (__float_as_uint(lo) != w && !(lo != lo && want != want)) || (__float_as_uint(hi) != w && !(hi != hi && want != want));
+                }
+            } else if (mode == 0) {
                 const float want = cnt / (1.f + rto::det_expf(-v));
                 // the value in one channel, harmless neighbours in the other two (and once with itself everywhere)
                 const float t[3] = {v, (i & 1) ? v : 0.25f, (i & 2) ? -3.5f : v};
@@ -238,7 +255,7 @@ __global__ void __launch_bounds__(256) sigmoid_probe_kernel(int mode, uint32_t f
 }
 
 extern "C" int rto_probe_sigmoid(int mode, uint32_t first_bits, uint64_t count, int cnt_lo, int cnt_hi, uint64_t* out3) {
-    if (!out3 || count == 0 || count > (1ull << 32) || mode < 0 || mode > 1 || cnt_lo < 1 || cnt_hi > 32 || cnt_lo > cnt_hi) return RTO_E_INVALID;
+    if (!out3 || count == 0 || count > (1ull << 32) || mode < 0 || mode > 3 || cnt_lo < 1 || cnt_hi > 32 || cnt_lo > cnt_hi) return RTO_E_INVALID;
     unsigned long long* d = nullptr;
     if (hipMalloc((void**)&d, 24) != hipSuccess) return RTO_E_HIP;
     const unsigned long long init[3] = {0ULL, ~0ULL, 0ULL};
@@ -344,6 +361,16 @@ constexpr int kBlk = 32;
 #define OP_PKFMA(i) "v_pk_fma_f32 %" #i ", %" #i ", %8, %9\n"
 #define OP_PKMUL(i) "v_pk_mul_f32 %" #i ", %" #i ", %8\n"
 #define OP_FMA64(i) "v_fma_f64 %" #i ", %" #i ", %8, %9\n"
+// (round 6: what the shading kernel's sigmoid and SH basis are made of)
+#define OP_MUL64(i) "v_mul_f64 %" #i ", %" #i ", %8\n"
+#define OP_ADD64(i) "v_add_f64 %" #i ", %" #i ", %8\n"
+#define OP_RNDNE64(i) "v_rndne_f64 %" #i ", %" #i "\n"
+#define OP_LDEXP64(i) "v_ldexp_f64 %" #i ", %" #i ", 1\n"
+#define OP_CVT64_32(i) "v_cvt_f64_f32 %" #i ", %10\n"
+#define OP_CVT32_64(i) "v_cvt_f32_f64 %" #i ", %8\n"
+#define OP_CVTI_64(i) "v_cvt_i32_f64 %" #i ", %8\n"
+#define OP_FMAMIX(i) "v_fma_mix_f32 %" #i ", %" #i ", %16, neg(0) op_sel_hi:[1,0,0]\n"
+#define RTO_REGS8F "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
 
 template <int KIND>
 __global__ void __launch_bounds__(256) valu_probe_kernel(int iters, float k0, float k1, float* __restrict__ sink,
@@ -449,6 +476,14 @@ __global__ void __launch_bounds__(256) valu_probe_kernel(int iters, float k0, fl
         if constexpr (BK == 76) asm volatile(RTO_R16(OP_CND_S) RTO_R16(OP_CND_S) : RTO_REGS16 : "v"(k1), "v"(k0) : "s20", "s21");
         if constexpr (BK == 77) asm volatile(RTO_R16(OP_CND_FMA) : RTO_REGS16 : "v"(k1), "v"(k0) : "vcc");
         if constexpr (BK == 78) asm volatile(RTO_R8(OP_CMP_3CND) : RTO_REGS16 : "v"(k1), "v"(k0) : "vcc");
+        if constexpr (BK == 79) asm volatile(RTO_R16(OP_FMAMIX) RTO_R16(OP_FMAMIX) : RTO_REGS16 : "v"(k1), "v"(k0));
+        if constexpr (BK == 80) asm volatile(RTO_R8(OP_MUL64) RTO_R8(OP_MUL64) RTO_R8(OP_MUL64) RTO_R8(OP_MUL64) : RTO_REGS8 : "v"(dk1), "v"(dk0));
+        if constexpr (BK == 81) asm volatile(RTO_R8(OP_ADD64) RTO_R8(OP_ADD64) RTO_R8(OP_ADD64) RTO_R8(OP_ADD64) : RTO_REGS8 : "v"(dk1), "v"(dk0));
+        if constexpr (BK == 82) asm volatile(RTO_R8(OP_RNDNE64) RTO_R8(OP_RNDNE64) RTO_R8(OP_RNDNE64) RTO_R8(OP_RNDNE64) : RTO_REGS8 : "v"(dk1), "v"(dk0));
+        if constexpr (BK == 83) asm volatile(RTO_R8(OP_LDEXP64) RTO_R8(OP_LDEXP64) RTO_R8(OP_LDEXP64) RTO_R8(OP_LDEXP64) : RTO_REGS8 : "v"(dk1), "v"(dk0));
+        if constexpr (BK == 84) asm volatile(RTO_R8(OP_CVT64_32) RTO_R8(OP_CVT64_32) RTO_R8(OP_CVT64_32) RTO_R8(OP_CVT64_32) : RTO_REGS8 : "v"(dk1), "v"(dk0), "v"(k1));
+        if constexpr (BK == 85) asm volatile(RTO_R8(OP_CVT32_64) RTO_R8(OP_CVT32_64) RTO_R8(OP_CVT32_64) RTO_R8(OP_CVT32_64) : RTO_REGS8F : "v"(dk1));
+        if constexpr (BK == 86) asm volatile(RTO_R8(OP_CVTI_64) RTO_R8(OP_CVTI_64) RTO_R8(OP_CVTI_64) RTO_R8(OP_CVTI_64) : RTO_REGS8F : "v"(dk1));
         if constexpr (BK == 66) {
             asm volatile(RTO_R16(OP_LDSR) RTO_R16(OP_LDSR) "s_waitcnt lgkmcnt(0)\n" : RTO_REGS16 : "v"(k1), "v"(k0), "v"(lds_addr) : "memory");
         }
@@ -556,6 +591,14 @@ const ValuKind kValuKinds[] = {
     {"v_cndmask_b32_e64, condition in an SGPR pair", 32, valu_probe_kernel<76>},
     {"v_cndmask_b32 (vcc) alternating with v_fma_f32", 32, valu_probe_kernel<77>},
     {"v_cmp_lt_f32 -> vcc + three v_cndmask_b32", 32, valu_probe_kernel<78>},
+    {"v_fma_mix_f32 (f16 x f32 - 0)", kBlk, valu_probe_kernel<79>},
+    {"v_mul_f64", kBlk, valu_probe_kernel<80>},
+    {"v_add_f64", kBlk, valu_probe_kernel<81>},
+    {"v_rndne_f64", kBlk, valu_probe_kernel<82>},
+    {"v_ldexp_f64", kBlk, valu_probe_kernel<83>},
+    {"v_cvt_f64_f32", kBlk, valu_probe_kernel<84>},
+    {"v_cvt_f32_f64", kBlk, valu_probe_kernel<85>},
+    {"v_cvt_i32_f64", kBlk, valu_probe_kernel<86>},
 };
 constexpr int kNumValuKinds = (int)(sizeof(kValuKinds) / sizeof(kValuKinds[0]));
 

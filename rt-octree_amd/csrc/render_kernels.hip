@@ -512,6 +512,39 @@ RTO_DEV uint32_t hit_slot(uint32_t h) { return h & ((1u << hit_slot_bits(SPP)) -
 template <int SPP>
 RTO_DEV uint32_t hit_count(uint32_t h) { return ((h & ~kHitValid) >> hit_slot_bits(SPP)) + 1u; }
 
+// The record's DD - 1 coefficients as packed halves al[k >> 1] (half k at its packed position) -> the leaf's contribution.
+template <int DD>
+RTO_DEV void shade_leaf_words(const uint32_t* al, const float* basis_fn, float cnt, float* out) {
+    constexpr int B = (DD - 1) / 3;
+    // basis_fn[j] * (float)coefficient k, the half widened by the multiply itself (mul_half_lo / _hi: one instruction, same float)
+    auto bc = [&](int j, int k) -> float { return (k & 1) ? mul_half_hi(al[k >> 1], basis_fn[j]) : mul_half_lo(al[k >> 1], basis_fn[j]); };
+    float t3[3], o3[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int off = c * B;
+        float tmp = bc(0, off);
+        if constexpr (B >= 25) {
+            tmp += bc(16, off + 16) + bc(17, off + 17) + bc(18, off + 18) + bc(19, off + 19) + bc(20, off + 20) + bc(21, off + 21) +
+                   bc(22, off + 22) + bc(23, off + 23) + bc(24, off + 24);
+        }
+        if constexpr (B >= 16) {
+            tmp += bc(9, off + 9) + bc(10, off + 10) + bc(11, off + 11) + bc(12, off + 12) + bc(13, off + 13) + bc(14, off + 14) +
+                   bc(15, off + 15);
+        }
+        if constexpr (B >= 9) {
+            tmp += bc(4, off + 4) + bc(5, off + 5) + bc(6, off + 6) + bc(7, off + 7) + bc(8, off + 8);
+        }
+        if constexpr (B >= 4) {
+            tmp += bc(1, off + 1) + bc(2, off + 2) + bc(3, off + 3);
+        }
+        t3[c] = tmp;
+    }
+    sigmoid_cnt3(t3, cnt, o3);  // out[c] += cnt / (1.f + det_expf(-tmp)), rt_core.cuh:314-318
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] += o3[c];
+    out[3] += cnt;
+}
+
 // Loads the `DD` fp16 values of one leaf record with aligned dword loads and shades it.
 // DD = data_dim (28 for SH9, 49 for SH16); the record starts at a 2-byte aligned address.
 // halves per record of the aligned SH-coefficient copy (TreeDev::shrec): the 3 B coefficients in a power-of-two stride,
@@ -554,37 +587,7 @@ RTO_DEV void shade_leaf_packed(const TreeDev& tree, uint32_t slot, const float* 
 #pragma unroll
         for (int i = 0; i < NAL; ++i) al[i] = __builtin_amdgcn_alignbit(i + 1 < NDW ? dw[i + 1] : 0u, dw[i], sh);
     }
-    auto coef = [&](int k) -> float {
-        return half_bits_to_float((uint16_t)((k & 1) ? (al[k >> 1] >> 16) : (al[k >> 1] & 0xffffu)));
-    };
-    float t3[3], o3[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const int off = c * B;
-        float tmp = basis_fn[0] * coef(off);
-        if constexpr (B >= 25) {
-            tmp += basis_fn[16] * coef(off + 16) + basis_fn[17] * coef(off + 17) + basis_fn[18] * coef(off + 18) +
-                   basis_fn[19] * coef(off + 19) + basis_fn[20] * coef(off + 20) + basis_fn[21] * coef(off + 21) +
-                   basis_fn[22] * coef(off + 22) + basis_fn[23] * coef(off + 23) + basis_fn[24] * coef(off + 24);
-        }
-        if constexpr (B >= 16) {
-            tmp += basis_fn[9] * coef(off + 9) + basis_fn[10] * coef(off + 10) + basis_fn[11] * coef(off + 11) +
-                   basis_fn[12] * coef(off + 12) + basis_fn[13] * coef(off + 13) + basis_fn[14] * coef(off + 14) +
-                   basis_fn[15] * coef(off + 15);
-        }
-        if constexpr (B >= 9) {
-            tmp += basis_fn[4] * coef(off + 4) + basis_fn[5] * coef(off + 5) + basis_fn[6] * coef(off + 6) +
-                   basis_fn[7] * coef(off + 7) + basis_fn[8] * coef(off + 8);
-        }
-        if constexpr (B >= 4) {
-            tmp += basis_fn[1] * coef(off + 1) + basis_fn[2] * coef(off + 2) + basis_fn[3] * coef(off + 3);
-        }
-        t3[c] = tmp;
-    }
-    sigmoid_cnt3(t3, cnt, o3);  // out[c] += cnt / (1.f + det_expf(-tmp)), rt_core.cuh:314-318
-#pragma unroll
-    for (int c = 0; c < 3; ++c) out[c] += o3[c];
-    out[3] += cnt;
+    shade_leaf_words<DD>(al, basis_fn, cnt, out);
 }
 
 // hit index of the wide image (= the index of the leaf's entry) -> the leaf's slot in data[] / shrec[] (what a hit entry

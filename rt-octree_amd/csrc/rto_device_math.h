@@ -73,6 +73,25 @@ RTO_DEV void pcg_advance_tab(Pcg32& r, uint32_t delta, const PcgJumpEntry* __res
 // ---- fp16 -> fp32 (exact) ----
 RTO_DEV float half_bits_to_float(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 
+// (float)h * b for the fp16 value h in the low / high half of `packed`, in ONE instruction: v_fma_mix_f32 widens the half
+// operand itself, and a * b + (-0.0) is a * b for every a, b (same rounding, same sign of zero, same infinities) -- the
+// conversion v_cvt_f32_f16 is exact, so this is the float of half_bits_to_float(h) * b.  The shading kernels multiply 48
+// coefficients per hit entry (rt_core.cuh:286-312): 48 of ~530 vector instructions per 64 entries saved (SQ_INSTS_VALU -8 %); the
+// kernel's time did not move (1.333 -> 1.330 ms per 100 C2 frames, profiles/r6_t_ab_shade_mix.txt): v_fma_mix_f32 issues at half
+// rate like the conversion it replaces (profiles/r6_v_probe_f64.txt), and the kernel is not bound by issue.  Compared on the device with
+// the two-instruction form for every half (denormals, infinities) against 2^20 floats and for 16 special halves against all 2^32
+// floats (rto_probe_sigmoid modes 2 / 3, tests/test_render_parity.py).
+RTO_DEV float mul_half_lo(uint32_t packed, float b) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, neg(0) op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(b));
+    return r;
+}
+RTO_DEV float mul_half_hi(uint32_t packed, float b) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, neg(0) op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(b));
+    return r;
+}
+
 // ---- deterministic logf / expf: constants and operation order identical to
 //      oracle/rto_oracle.c orc_det_logf / orc_det_expf ----
 // the reduction + series of det_logf for a POSITIVE NORMAL finite x (exponent e, mantissa bits man)

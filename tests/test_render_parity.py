@@ -637,6 +637,25 @@ def test_short_sigmoid_equals_the_plain_statement_for_every_float_and_sample_cou
     assert out[2] == 32 * (hi - lo)
 
 
+def test_one_instruction_half_multiply_equals_convert_then_multiply():
+    """round 6: shade_leaf_packed multiplies a basis value by an fp16 coefficient with ONE v_fma_mix_f32 (the half widened by the
+    instruction, addend -0.0) instead of v_cvt_f32_f16 + v_mul_f32 -- 48 products per hit entry (rt_core.cuh:286-312).  Same
+    float, checked on the device in both packed positions: every half (denormals, infinities, NaNs as NaN) against 2^20 floats
+    spread over the whole range, and 16 special halves against ALL 2^32 floats."""
+    import ctypes as C
+
+    from rt_octree_amd._lib import check, lib
+    out = (C.c_uint64 * 3)()
+    check(lib().rto_probe_sigmoid(3, 0x00000123, 1 << 20, 1, 32, out))
+    assert out[0] == 0, "mul_half differs for %d (float, half block) pairs, first at b bits 0x%08x block %d" % (out[0], out[1] >> 8, out[1] & 255)
+    assert out[2] == 32 << 20
+    for chunk in range(4):
+        check(lib().rto_probe_sigmoid(2, chunk << 30, 1 << 30, 1, 16, out))
+        assert out[0] == 0, "mul_half differs for %d (float, special half) pairs, first at b bits 0x%08x half #%d" % (
+            out[0], out[1] >> 8, out[1] & 255)
+        assert out[2] == 16 << 30
+
+
 @pytest.mark.parametrize("fn,name", [(0, "det_logf"), (1, "det_expf"), (2, "fexp_f32")])
 def test_device_math_equals_the_oracle_across_the_float_range(fn, name):
     """det_logf / det_expf / fexp_f32 stand in for the reference's `__logf` / `__expf` (DESIGN.md "Math"); device and

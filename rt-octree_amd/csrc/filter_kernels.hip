@@ -836,7 +836,7 @@ __global__ void __launch_bounds__(256, (PACKED || L <= 4) ? RTO_FAST_WGS : 3) fi
                 }
 #pragma unroll
                 for (int r = 0; r < kFastRows; ++r) {
-                    const float ww = wl[r] * rcp_refined(acc23[r].y);  // (the tolerance route: reciprocal + one Newton step, not an IEEE division)
+                    const float ww = div_refined(wl[r], acc23[r].y);  // (the tolerance route: reciprocal + one residual correction, not an IEEE division)
                     o[r][0] += acc01[r].x * ww;
                     o[r][1] += acc01[r].y * ww;
                     o[r][2] += acc23[r].x * ww;

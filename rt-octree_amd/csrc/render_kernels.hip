@@ -1219,13 +1219,20 @@ __global__ void __launch_bounds__(kQueueChunk) queue_write_kernel(const FrameBat
 // sample_dst (rt_core.cuh:67-193) for every pixel of the batch, at full lane utilisation: the RNG
 // jump (volrend.cu:157), SPP draws of -log(1-u) and their sort.  The thresholds go to the hand-off
 // buffer slots [i][pixel] that the traversal later overwrites with the pixel's hit list.
+// Tiles (waves) per workgroup: ONE, as in the shading kernel and for the same reason -- two thirds of the waves find their tile
+// unmarked and leave after one load, the others draw for ~400 instructions, and a workgroup frees its slots when its last wave ends
+// (4 waves: 0.438 ms per 100 C2 frames for marks + lists + thresholds, 2: 0.436, 1: 0.427; profiles/r6_w_ab_sample_waves.txt)
+#ifndef RTO_SAMPLE_WG_WAVES
+#define RTO_SAMPLE_WG_WAVES 1
+#endif
+constexpr int kSampleWaves = RTO_SAMPLE_WG_WAVES;
 template <int SPP>
-__global__ void __launch_bounds__(256) sample_kernel(const FrameBatch fb, const PcgJumpEntry* __restrict__ jump) {
-    // one wave = one 8x8 tile (row-major tiles, 4 per workgroup): a culled tile's wave writes 64 empty lists and is gone --
+__global__ void __launch_bounds__(64 * kSampleWaves) sample_kernel(const FrameBatch fb, const PcgJumpEntry* __restrict__ jump) {
+    // one wave = one 8x8 tile (row-major tiles): a culled tile's wave is gone after its mark load --
     // with one thread per pixel of a scanline nearly every wave held some marched pixel and paid for all the draws
     const uint32_t SIZE = (uint32_t)fb.width * (uint32_t)fb.height;
     const uint32_t tiles_x = (uint32_t)(fb.width + 7) >> 3, tiles_y = (uint32_t)(fb.height + 7) >> 3;
-    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
+    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (uint32_t)kSampleWaves + (threadIdx.x >> 6)));
     if (tile >= tiles_x * tiles_y) return;
     const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x, lane = threadIdx.x & 63u;
     const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
@@ -2223,7 +2230,7 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
     hipLaunchKernelGGL(queue_count_kernel, dim3(n_chunks), dim3(kQueueChunk), 0, stream, fb);
     hipLaunchKernelGGL(queue_scan_kernel, dim3(1), dim3(256), 0, stream, fb);
     hipLaunchKernelGGL(queue_write_kernel, dim3(n_chunks), dim3(kQueueChunk), 0, stream, fb);
-    hipLaunchKernelGGL(sample_kernel<SPP>, dim3((unsigned)((tiles / fb.n + 3) / 4), fb.n), dim3(256), 0, stream, fb, jump);
+    hipLaunchKernelGGL(sample_kernel<SPP>, dim3((unsigned)((tiles / fb.n + kSampleWaves - 1) / kSampleWaves), fb.n), dim3(64 * kSampleWaves), 0, stream, fb, jump);
     // arm the ray queues on the launch stream (576 B): a launch never depends on how the previous one on
     // this context ended
     if (hipMemsetAsync(queue, 0, kQueueWords * sizeof(unsigned long long), stream) != hipSuccess) return hipErrorLaunchFailure;

@@ -331,6 +331,12 @@ RTO_DEV float rcp_refined(float x) {
     const float r = __builtin_amdgcn_rcpf(x);
     return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
 }
+// n / d as n * rcp(d) with one exact-residual correction: the correctly rounded quotient except for rare last-bit cases, in 4
+// instructions (v_rcp_f32, multiply, two FMAs) -- for the tolerance routes; d normal, not 0, the quotient far from the range's ends.
+RTO_DEV float div_refined(float n, float d) {
+    const float r = __builtin_amdgcn_rcpf(d), q = n * r;
+    return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+}
 
 // weight = softmax(x[:, :4]) (network.py:113-114) in fp32 over the four fp16-valued logits; one definition for
 // the GuidanceNet kernel's epilogue and for the filter that consumes packed logits, so both give the same bits

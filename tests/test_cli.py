@@ -183,7 +183,8 @@ def test_cli_fast_filter_route(tmp_path):
         assert np.abs(outs["fast"][i] - outs["exact"][i]).max() <= 1, i
         assert np.array_equal(outs["fast"][i], outs["fast1"][i]), i
         changed += int((outs["fast"][i] != outs["exact"][i]).sum())
-    assert changed < 0.002 * 3 * 96 * 72 * 4  # a handful of LSB flips at most
+    print("fast vs exact route: %d of %d PNG bytes differ by one code value" % (changed, 3 * 96 * 72 * 4))
+    assert changed < 0.002 * 3 * 96 * 72 * 4, changed  # a handful of LSB flips at most
 
 
 @pytest.mark.gpu

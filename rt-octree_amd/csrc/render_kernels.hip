@@ -1801,6 +1801,13 @@ __device__ unsigned long long g_shade_phase[kShadeStampWaves * 8];
 #define RTO_SHADE_WG_WAVES 1
 #endif
 constexpr int kShadeWaves = RTO_SHADE_WG_WAVES;
+#ifndef RTO_SHADE_BAND_ROWS
+#define RTO_SHADE_BAND_ROWS 8
+#endif
+// pixel blocks (of block_px consecutive pixels, scanline order) per band of RTO_SHADE_BAND_ROWS rows
+__host__ __device__ constexpr uint32_t shade_blocks_per_band(int W, int block_px) {
+    return (uint32_t)((RTO_SHADE_BAND_ROWS > 0 ? RTO_SHADE_BAND_ROWS : 1) * W + block_px - 1) / (uint32_t)block_px;
+}
 template <int SPP, int P, int MODE>
 __global__ void __launch_bounds__(64 * kShadeWaves, shade_wps(MODE)) shade_kernel(const TreeDev tree, const OptDev opt, const FrameBatch fb,
                                                                               const uint32_t* __restrict__ hits0) {
@@ -1815,14 +1822,23 @@ __global__ void __launch_bounds__(64 * kShadeWaves, shade_wps(MODE)) shade_kerne
     for (int i = 0; i < 8; ++i) ph[i] = 0;
     RTO_SHADE_STAMP(0)
 #endif
-    // Workgroup -> (pixel block, frame), XCD-aware: workgroups go round-robin over the 8 XCDs, so id & 7
-    // picks the XCD; the same pixel block of ALL frames of the batch lands on one XCD, frame after frame.
-    // Neighbouring poses hit the same leaves there, so a leaf's SH record is fetched from HBM once per
-    // batch instead of once per frame (frame-major order streams ~70 MB of records per frame through a
-    // 4 MB L2: hit rate 16 %).
+    // Workgroup -> (pixel block, frame), XCD-aware: workgroups go round-robin over the 8 XCDs, so id & 7 picks the XCD, and the L2 is
+    // per XCD.  Rounds 2-5 put the same 128-pixel block of ALL frames of the batch on one XCD, frame after frame, hoping that
+    // neighbouring poses hit the same leaves there; the counters never agreed (L2 hit 15 %, as with frame-major order): an orbiting
+    // camera moves a leaf SIDEWAYS by ten or twenty pixels per frame -- out of its block after a few frames, but not out of its rows.
+    // Round 6: BANDS of 8 rows.  Band b of all frames runs on XCD b & 7, frame after frame, a band's blocks side by side: L2 hit
+    // 0.15 -> 0.28, FETCH 4.25 -> 3.56 GB per 100 C2 frames, 1.335 -> 1.298 ms (C4 6.75 -> 6.23, C5 0.985 -> 0.936); bands of 4 / 16 /
+    // 32 rows: 1.306 / 1.315 / 1.43 (profiles/r6_y_ab_shade_bands*.txt, r6_y_pmc_shade_bands.txt).  RTO_SHADE_BAND_ROWS=0: the old order.
     const uint32_t bid = blockIdx.x, q = bid >> 3;
+#if RTO_SHADE_BAND_ROWS > 0
+    const uint32_t cpb = shade_blocks_per_band(W, 64 * kShadeWaves * P), per_band = cpb * (uint32_t)fb.n;
+    const uint32_t bi = q / per_band, rem = q - bi * per_band;
+    const uint32_t frame = rem / cpb;
+    const uint32_t pblock = (bi * 8u + (bid & 7u)) * cpb + (rem - frame * cpb);
+#else
     const uint32_t frame = q % (uint32_t)fb.n;
     const uint32_t pblock = (q / (uint32_t)fb.n) * 8u + (bid & 7u);
+#endif
     const int64_t wave_px0 = ((int64_t)pblock * kShadeWaves + wv) * (64 * P);
     if (wave_px0 >= SIZE) return;  // wave-uniform
     const FrameDesc& fd = fb.f[frame];  // block-uniform index: scalar loads
@@ -2243,7 +2259,12 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
 #endif
     constexpr int SP = SPP <= 8 ? RTO_SHADE_P : 1;  // pixels per lane of the shading kernel (its hit lists live in registers)
     const unsigned pblocks = (unsigned)((size + 64 * kShadeWaves * SP - 1) / (64 * kShadeWaves * SP));
+#if RTO_SHADE_BAND_ROWS > 0
+    const unsigned cpb = shade_blocks_per_band(fb.width, 64 * kShadeWaves * SP), bands = (pblocks + cpb - 1u) / cpb;
+    const dim3 sgrid(((bands + 7u) / 8u) * 8u * cpb * (unsigned)fb.n);  // see shade_kernel: (band, frame, pixel block of the band) <- block id
+#else
     const dim3 sgrid(((pblocks + 7u) / 8u) * 8u * (unsigned)fb.n);  // see shade_kernel: (pixel block, frame) <- block id
+#endif
 #define RTO_SHADE(M) hipLaunchKernelGGL((shade_kernel<SPP, SP, M>), sgrid, dim3(64 * kShadeWaves), 0, stream, tree, opt, fb, (const uint32_t*)hits)
     if (tree.qrec) {  // (the host admits SH4/9/16/25 only)
         if (tree.basis_dim == 4)

@@ -202,8 +202,9 @@ void rto_ctx_rng_get(const rto_ctx* c, uint64_t* state, uint64_t* inc);
 int rto_ctx_set_kernel(rto_ctx* c, int kernel);
 /* Performance knobs; never change results.  key: "strip_rows" (single-frame kernel: tile rows per XCD
  * strip, >= 1); batched kernel: "refill" (0 = default; 100 * waves/SIMD + idle-lane threshold selects one of the A/B instantiations), "tile_order"
- * (0 = row-major tiles, 1 = centre-out), "xcd_queues" (1 = one ray queue per XCD over an image wedge
- * each, with stealing; 0 = a single queue), "tile_major" / "tile_block" (queue order), "cull" (1 = skip the tiles whose rays provably meet no density, the default; 0 = march every ray), "blocks_per_cu" (0 = as many
+ * (0 = row-major tiles, 1 = centre-out), "xcd_queues" (1 = one ray queue per XCD over its share of the image,
+ * with stealing; 0 = a single queue), "tile_major" / "tile_block" (queue order), "queue_bands" (the XCD queues take bands of this many
+ * 8-pixel tile rows, band j -> queue j % 8; 0 = angular wedges around the image centre; default 3), "cull" (1 = skip the tiles whose rays provably meet no density, the default; 0 = march every ray), "blocks_per_cu" (0 = as many
  * workgroups of the persistent traversal kernel per CU as fit, else a cap 1..8: the kernel's true occupancy knob --
  * `refill`'s waves/SIMD only sets the register budget). */
 int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value);

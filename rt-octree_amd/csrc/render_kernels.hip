@@ -975,7 +975,7 @@ __global__ void __launch_bounds__(256, SPP <= 8 ? RTO_FAST_WPS : 4) render_fast(
 //     idles only until the wave has REFILL such lanes; then a ballot / mbcnt prefix sum hands each
 //     idle lane the next ray of the wave's reservoir (one atomicAdd per 64-256 rays);
 //   * rays are queued in 8x8-pixel tile order, so a wave's 64 rays stay spatially coherent; one
-//     queue per XCD over an image wedge each, tile-major across the frames (FrameBatch::qstart);
+//     queue per XCD over interleaved bands of tile rows (rounds 3-5: an angular image wedge each), tile-major across the frames (FrameBatch::qstart);
 //   * the end-of-queue drain happens once per batch instead of once per frame.
 // Per-ray arithmetic is exactly render_fast's; results are bit-identical.
 

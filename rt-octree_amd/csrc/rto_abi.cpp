@@ -111,6 +111,12 @@ struct rto_tree {
     std::mutex rebuild_mutex;
 };
 
+// tile rows per band of the XCD ray queues (build_tile_tables; 0: angular wedges, rounds 3-5).  Per 100 C2 frames: wedges 3.84 ms,
+// bands of 1 / 2 / 4 / 8 tile rows 3.73 / 3.70 / 3.72 / 3.75; through bench.py 3.92 -> 3.78 (2) / 3.75 (3); C5 2.48 -> 2.37, C3 shape
+// 3.30 -> 3.15, C4 unchanged (profiles/r6_y_ab_queue_bands*.txt)
+#ifndef RTO_QUEUE_BANDS_DEFAULT
+#define RTO_QUEUE_BANDS_DEFAULT 3
+#endif
 struct rto_ctx {
     int device = 0;
     int width = 0, height = 0;
@@ -126,6 +132,7 @@ struct rto_ctx {
     bool xcd_queues = true;
     bool tile_major = true;
     int tile_block = 4;  // tiles per side of the blocks the wedge queues are ordered by
+    int queue_bands = RTO_QUEUE_BANDS_DEFAULT;  // > 0: the XCD queues take BANDS of this many tile rows (band j -> queue j % 8) instead of angular wedges
     uint32_t* hits = nullptr;             // [frames][hits_spp][H*W] traversal -> shading hand-off
     int hits_spp = 0;
     // empty-space culling + ray-queue lists of the batched path (allocated with the first batch)
@@ -1119,11 +1126,12 @@ int rto_ctx_create(int width, int height, int device, rto_ctx** out) {
 //  * tile_order: rings around the image centre, innermost first, each ring walked by angle -- the
 //    frame's long rays (the object) start early, the queue ends on cheap border tiles, consecutive
 //    tiles stay neighbours;
-//  * wedge_order: the image cut into 8 angular wedges around the centre (one ray queue per XCD):
-//    every wedge gets its share of the expensive centre and of the cheap border and covers one
-//    contiguous slice of the view frustum, i.e. of the tree -- which is what the XCD's L2 then holds.
-//    Inside a wedge, blocks of tile_block x tile_block tiles go centre-out and the tiles of a block
-//    in Morton order, so the rays in flight at any time cover a compact patch, not a thin arc.
+//  * wedge_order: the tiles of the 8 XCD ray queues.  Rounds 3-5: the image cut into 8 angular wedges around the centre, blocks of
+//    tile_block x tile_block tiles centre-out, Morton order inside a block.  Round 6 (queue_bands > 0, the default): BANDS of
+//    queue_bands tile rows, band j -> queue j % 8, centre bands first, a band's tiles centre-out.  Every queue still gets its share
+//    of the expensive centre and of the cheap border (the bands interleave), but what its XCD's L2 has to hold is a few horizontal
+//    slabs of the tree: a camera that orbits the scene's vertical axis keeps a leaf in its rows from frame to frame, while an
+//    angular wedge of the image sees the whole scene turn past it over the batch.
 static int build_tile_tables(rto_ctx* c) {
     const int tx8 = (c->width + 7) / 8, ty8 = (c->height + 7) / 8;
     const int B = c->tile_block < 1 ? 1 : c->tile_block;
@@ -1156,6 +1164,18 @@ static int build_tile_tables(rto_ctx* c) {
             polar(bx * B + 0.5 * (B - 1), by * B + 0.5 * (B - 1), bring, bang);
             int wedge = (int)(bang / (2.0 * pi) * rto::kMaxQueues);
             if (wedge >= rto::kMaxQueues) wedge = rto::kMaxQueues - 1;
+            if (c->queue_bands > 0) {
+                // BANDS (round 6): band j of queue_bands tile rows -> queue j % 8.  A camera that orbits the scene's vertical axis keeps
+                // a leaf in its rows from frame to frame, so a queue's rays -- the same tiles of all frames of the batch in turn --
+                // stay inside a few horizontal slabs of the tree, which is what that XCD's L2 then has to hold; an angular wedge of
+                // the image sees the whole scene turn past it.  Centre bands first, a band's tiles centre-out.
+                const int band = ty / c->queue_bands;
+                wedge = band % rto::kMaxQueues;
+                bring = std::fabs((band + 0.5) * c->queue_bands - 0.5 - cy);
+                bang = std::fabs(tx - cx) / (tx8 + 1.0);  // (< 1: orders inside a band; ring * 16 + ang stays monotone in the band)
+                keyed.push_back({wedge, bring, bang, (uint32_t)(ty % c->queue_bands), code});
+                continue;
+            }
             keyed.push_back({wedge, bring, bang, spread((uint32_t)(tx % B)) | (spread((uint32_t)(ty % B)) << 1), code});
         }
     std::stable_sort(plain.begin(), plain.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
@@ -1395,6 +1415,12 @@ int rto_ctx_set_tuning(rto_ctx* c, const char* key, int value) {
     } else if (k == "tile_block") {
         if (value < 1 || value > 64) return set_err(RTO_E_INVALID, "tile_block must be 1..64");
         c->tile_block = value;
+        DeviceGuard guard(c->device);
+        if (hipDeviceSynchronize() != hipSuccess) return set_err(RTO_E_HIP, "hipDeviceSynchronize failed");
+        return build_tile_tables(c);
+    } else if (k == "queue_bands") {  // XCD queues by bands of `value` tile rows (0: angular wedges); same pixels
+        if (value < 0 || value > 64) return set_err(RTO_E_INVALID, "queue_bands must be 0..64");
+        c->queue_bands = value;
         DeviceGuard guard(c->device);
         if (hipDeviceSynchronize() != hipSuccess) return set_err(RTO_E_HIP, "hipDeviceSynchronize failed");
         return build_tile_tables(c);

@@ -512,7 +512,7 @@ def test_batched_kernel_full_size_matches_fast(small_tree_sh9):
 
 def test_queue_tuning_never_changes_results(small_tree_sh16):
     """rto_ctx_set_tuning: single queue / one queue per XCD, frame- / tile-major order, row-major /
-    centre-out / wedge tile tables of any block size, refill thresholds -- which wave renders which ray
+    centre-out / wedge / band tile tables of any block size, refill thresholds -- which wave renders which ray
     when is free, the pixels are not."""
     ht, dt = make_pair(small_tree_sh16)
     W, H = 132, 76  # ragged vs the 8x8 ray tiles and vs the 4x4-tile blocks
@@ -524,7 +524,8 @@ def test_queue_tuning_never_changes_results(small_tree_sh16):
     ctx = R.RenderContext(W, H, frames=3)
     settings = [{"xcd_queues": 0, "tile_order": 0}, {"xcd_queues": 0, "tile_order": 1, "tile_major": 0},
                 {"xcd_queues": 1, "tile_major": 1, "tile_block": 1}, {"tile_block": 3}, {"tile_block": 64},
-                {"tile_block": 4, "refill": 808}, {"refill": 816}, {"refill": 432}, {"refill": 0}]
+                {"tile_block": 4, "refill": 808}, {"refill": 816}, {"refill": 432}, {"refill": 0},
+                {"queue_bands": 0}, {"queue_bands": 1}, {"queue_bands": 3}, {"queue_bands": 64}]  # angular wedges / bands of tile rows per XCD queue
     for kv in settings:
         for k, v in kv.items():
             ctx.set_tuning(k, v)
@@ -535,6 +536,8 @@ def test_queue_tuning_never_changes_results(small_tree_sh16):
             assert_bits_equal(ctx.download_aux(), want[f], "%s frame %d" % (kv, f))
     with pytest.raises(R.RtoError):
         ctx.set_tuning("tile_block", 0)
+    with pytest.raises(R.RtoError):
+        ctx.set_tuning("queue_bands", 65)
     with pytest.raises(R.RtoError):
         ctx.set_tuning("no_such_knob", 1)
 

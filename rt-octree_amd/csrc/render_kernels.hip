@@ -1226,46 +1226,62 @@ __global__ void __launch_bounds__(kQueueChunk) queue_write_kernel(const FrameBat
 #define RTO_SAMPLE_WG_WAVES 1
 #endif
 constexpr int kSampleWaves = RTO_SAMPLE_WG_WAVES;
+// tiles per wave of sample_kernel (round 6): with one 8x8 tile per single-wave workgroup a 100-frame launch is a million
+// workgroups, two thirds of which leave after their mark load -- the kernel then runs at the rate workgroups are DISPATCHED
+// (~2 per clock chip-wide: 0.24 ms before a single draw), not at any arithmetic rate.  A wave takes a strip of consecutive
+// tiles, reads their marks in one round trip (lane i: tile i of the strip, ballot) and walks the marked ones.
+#ifndef RTO_SAMPLE_TILES
+#define RTO_SAMPLE_TILES 8
+#endif
+constexpr int kSampleTiles = RTO_SAMPLE_TILES;
+static_assert(kSampleTiles >= 1 && kSampleTiles <= 64, "a strip's marks come from one ballot");
 template <int SPP>
 __global__ void __launch_bounds__(64 * kSampleWaves) sample_kernel(const FrameBatch fb, const PcgJumpEntry* __restrict__ jump) {
-    // one wave = one 8x8 tile (row-major tiles): a culled tile's wave is gone after its mark load --
+    // one wave = a strip of 8x8 tiles (row-major tiles): a culled tile costs its wave one bit of a ballot --
     // with one thread per pixel of a scanline nearly every wave held some marched pixel and paid for all the draws
     const uint32_t SIZE = (uint32_t)fb.width * (uint32_t)fb.height;
-    const uint32_t tiles_x = (uint32_t)(fb.width + 7) >> 3, tiles_y = (uint32_t)(fb.height + 7) >> 3;
-    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (uint32_t)kSampleWaves + (threadIdx.x >> 6)));
-    if (tile >= tiles_x * tiles_y) return;
-    const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x, lane = threadIdx.x & 63u;
-    const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
-    if (x >= (uint32_t)fb.width || y >= (uint32_t)fb.height) return;
-    const uint32_t idx = y * (uint32_t)fb.width + x;
+    const uint32_t tiles_x = (uint32_t)(fb.width + 7) >> 3, tiles_y = (uint32_t)(fb.height + 7) >> 3, n_tiles = tiles_x * tiles_y;
+    const uint32_t tile0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * (uint32_t)kSampleWaves + (threadIdx.x >> 6)) * (uint32_t)kSampleTiles));
+    if (tile0 >= n_tiles) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    // a pixel of a culled tile: an empty hit list, no draws (its RNG stream is its own: nobody observes the skipped ones;
+    // shade_kernel reads the marks, not a list)
+    bool marked = lane < (uint32_t)kSampleTiles && tile0 + lane < n_tiles;
+    if (marked && fb.tile_mask) marked = tile_marked(fb, (int)blockIdx.y, tile0 + lane);
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(marked);
+    if (todo == 0ULL) return;
     const FrameDesc& fd = fb.f[blockIdx.y];
-    // a pixel of a culled tile: an empty hit list, no draws (its RNG stream is its own: nobody observes the skipped ones)
-    if (fb.tile_mask && !tile_marked(fb, (int)blockIdx.y, tile)) {  // (shade_kernel reads the marks, not a list)
-        return;
-    }
-    Pcg32 rng;
-    rng.state = fd.rng_state;
-    rng.inc = fd.rng_inc;
-    pcg_advance_tab(rng, idx * (uint32_t)SPP, jump);
-    float dst[SPP];
-#pragma unroll
-    for (int n = 0; n < SPP; ++n) {
-        float tv = -det_log_one_minus(pcg_next_float(rng));
-#pragma unroll
-        for (int i = 0; i < n; ++i) {  // static-index insertion: same sorted array
-            // (v_min_f32 / v_max_f32: the draws are never NaN, and the only zero a draw can be is -0.0 = -log(1 - 0), so
-            //  these return what the reference's `a < b ? a : b` forms do -- in half the instructions)
-            const float lo = __builtin_fminf(dst[i], tv), hi = __builtin_fmaxf(dst[i], tv);
-            dst[i] = lo;
-            tv = hi;
-        }
-        dst[n] = tv;
-    }
-    // (-log(1 - 0) = -0.0: the thresholds are only ever compared, so +0.0 serves; its clear top bit is what the
-    //  shading kernel ends a hit list on)
     RTO_GLOBAL uint32_t* const fhits = as_global(fd.hits);
+    while (todo) {
+        const uint32_t tile = tile0 + (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1ULL;
+        const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+        if (x >= (uint32_t)fb.width || y >= (uint32_t)fb.height) continue;
+        const uint32_t idx = y * (uint32_t)fb.width + x;
+        Pcg32 rng;
+        rng.state = fd.rng_state;
+        rng.inc = fd.rng_inc;
+        pcg_advance_tab(rng, idx * (uint32_t)SPP, jump);
+        float dst[SPP];
 #pragma unroll
-    for (int i = 0; i < SPP; ++i) fhits[hit_index<SPP>(idx, (uint32_t)i, SIZE)] = __float_as_uint(dst[i]) & ~kHitValid;
+        for (int n = 0; n < SPP; ++n) {
+            float tv = -det_log_one_minus(pcg_next_float(rng));
+#pragma unroll
+            for (int i = 0; i < n; ++i) {  // static-index insertion: same sorted array
+                // (v_min_f32 / v_max_f32: the draws are never NaN, and the only zero a draw can be is -0.0 = -log(1 - 0), so
+                //  these return what the reference's `a < b ? a : b` forms do -- in half the instructions)
+                const float lo = __builtin_fminf(dst[i], tv), hi = __builtin_fmaxf(dst[i], tv);
+                dst[i] = lo;
+                tv = hi;
+            }
+            dst[n] = tv;
+        }
+        // (-log(1 - 0) = -0.0: the thresholds are only ever compared, so +0.0 serves; its clear top bit is what the
+        //  shading kernel ends a hit list on)
+#pragma unroll
+        for (int i = 0; i < SPP; ++i) fhits[hit_index<SPP>(idx, (uint32_t)i, SIZE)] = __float_as_uint(dst[i]) & ~kHitValid;
+    }
 }
 
 // Staged hit lists (round 4, VERDICT r3 task 5; -DRTO_HITS_DIRECT restores the store per hit): a ray's hit entries wait in LDS -- in the rows of its threshold column that
@@ -2246,7 +2262,7 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
     hipLaunchKernelGGL(queue_count_kernel, dim3(n_chunks), dim3(kQueueChunk), 0, stream, fb);
     hipLaunchKernelGGL(queue_scan_kernel, dim3(1), dim3(256), 0, stream, fb);
     hipLaunchKernelGGL(queue_write_kernel, dim3(n_chunks), dim3(kQueueChunk), 0, stream, fb);
-    hipLaunchKernelGGL(sample_kernel<SPP>, dim3((unsigned)((tiles / fb.n + kSampleWaves - 1) / kSampleWaves), fb.n), dim3(64 * kSampleWaves), 0, stream, fb, jump);
+    hipLaunchKernelGGL(sample_kernel<SPP>, dim3((unsigned)(((tiles / fb.n + kSampleTiles - 1) / kSampleTiles + kSampleWaves - 1) / kSampleWaves), fb.n), dim3(64 * kSampleWaves), 0, stream, fb, jump);
     // arm the ray queues on the launch stream (576 B): a launch never depends on how the previous one on
     // this context ended
     if (hipMemsetAsync(queue, 0, kQueueWords * sizeof(unsigned long long), stream) != hipSuccess) return hipErrorLaunchFailure;

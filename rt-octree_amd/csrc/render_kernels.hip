@@ -1032,11 +1032,18 @@ __global__ void __launch_bounds__(256) mark_tiles_kernel(const TreeDev tree, con
         for (int i = threadIdx.x; i < fb.mask_words; i += 256) s_mask[i] = 0u;
         __syncthreads();
     }
-    for (int c = (int)blockIdx.x * kMarkCells + (int)threadIdx.x; c < tree.n_occ_cells && c < ((int)blockIdx.x + 1) * kMarkCells; c += 256)
+    // (round 6: a thread takes a RUN of kMarkCells / 256 consecutive cells, not every 256th: the cells come in Morton order, so the
+    //  64 lanes of a wave then mark 64 different neighbourhoods instead of one -- their ds_or_b32 land on different words instead
+    //  of serialising on a few: 0.104 -> 0.07 ms per 100 C2 frames, profiles/r6_zz_ab_mark_cells.txt)
+    static_assert(kMarkCells % 256 == 0, "a run per thread");
+    for (int i = 0; i < kMarkCells / 256; ++i) {
+        const int c = (int)blockIdx.x * kMarkCells + (int)threadIdx.x * (kMarkCells / 256) + i;
+        if (c >= tree.n_occ_cells) break;
         if (LDS_MASK)
             mark_cell(tree.occ_cells[c], fd, fb, [&](uint32_t w, uint32_t bits) { atomicOr(&s_mask[w], bits); });  // ds_or_b32
         else
             mark_cell(tree.occ_cells[c], fd, fb, [&](uint32_t w, uint32_t bits) { atomicOr(gm + w, bits); });
+    }
     if (LDS_MASK) {
         __syncthreads();
         for (int i = threadIdx.x; i < fb.mask_words; i += 256)
@@ -1103,11 +1110,14 @@ __global__ void __launch_bounds__(256) mark_tiles_one_kernel(const TreeDev tree,
         for (int i = threadIdx.x; i < mask_words; i += 256) s_mask[i] = 0u;
         __syncthreads();
     }
-    for (int c = (int)blockIdx.x * kMarkCells + (int)threadIdx.x; c < tree.n_occ_cells && c < ((int)blockIdx.x + 1) * kMarkCells; c += 256)
+    for (int i = 0; i < kMarkCells / 256; ++i) {  // (runs of consecutive cells per thread, as in mark_tiles_kernel)
+        const int c = (int)blockIdx.x * kMarkCells + (int)threadIdx.x * (kMarkCells / 256) + i;
+        if (c >= tree.n_occ_cells) break;
         if (lds)
             mark_cell(tree.occ_cells[c], fd, fb, [&](uint32_t w, uint32_t bits) { atomicOr(&s_mask[w], bits); });
         else
             mark_cell(tree.occ_cells[c], fd, fb, [&](uint32_t w, uint32_t bits) { atomicOr(mask + w, bits); });
+    }
     if (lds) {
         __syncthreads();
         for (int i = threadIdx.x; i < mask_words; i += 256)

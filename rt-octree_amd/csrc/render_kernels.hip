@@ -1182,33 +1182,30 @@ __global__ void __launch_bounds__(kQueueChunk) queue_count_kernel(const FrameBat
     }
 }
 
-// exclusive scan of the chunk counts, queue by queue (one workgroup: a few thousand chunks)
-__global__ void __launch_bounds__(256) queue_scan_kernel(const FrameBatch fb) {
-    __shared__ uint32_t s_v[256];
-    __shared__ uint32_t s_carry;
-    for (int k = 0; k < fb.n_queues; ++k) {
-        if (threadIdx.x == 0) s_carry = 0;
-        __syncthreads();
-        for (int c0 = fb.qchunk[k]; c0 < fb.qchunk[k + 1]; c0 += 256) {
-            const int c = c0 + (int)threadIdx.x;
-            const uint32_t v = c < fb.qchunk[k + 1] ? fb.chunk_count[c] : 0u;
-            s_v[threadIdx.x] = v;
-            __syncthreads();
-            for (int d = 1; d < 256; d <<= 1) {  // Hillis-Steele inclusive scan
-                const uint32_t t = threadIdx.x >= (unsigned)d ? s_v[threadIdx.x - d] : 0u;
-                __syncthreads();
-                s_v[threadIdx.x] += t;
-                __syncthreads();
-            }
-            const uint32_t carry = s_carry;
-            if (c < fb.qchunk[k + 1]) fb.chunk_base[c] = carry + s_v[threadIdx.x] - v;
-            __syncthreads();
-            if (threadIdx.x == 255) s_carry = carry + s_v[255];
-            __syncthreads();
+// exclusive scan of the chunk counts (a few thousand chunks): one WAVE per queue, lane shuffles, no barrier (round 6: the
+// one-workgroup Hillis-Steele scan, queue after queue, was ~320 barrier rounds = 22 us on the launch chain in front of the
+// traversal).  The kernel also arms the ray queues (kQueueWords u64: a launch never depends on how the previous one on its
+// context ended) -- one fill launch less on that chain.
+static_assert(kQueueWords <= 64 * kMaxQueues, "queue words zeroed by the scan's threads");
+__global__ void __launch_bounds__(64 * kMaxQueues) queue_scan_kernel(const FrameBatch fb, unsigned long long* __restrict__ queue) {
+    if (threadIdx.x < (unsigned)kQueueWords) queue[threadIdx.x] = 0ULL;
+    const int k = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+    if (k >= fb.n_queues) return;
+    const int c1 = fb.qchunk[k + 1];
+    uint32_t carry = 0;
+    for (int c0 = fb.qchunk[k]; c0 < c1; c0 += 64) {
+        const int c = c0 + lane;
+        const uint32_t v = c < c1 ? fb.chunk_count[c] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= d) incl += t;
         }
-        if (threadIdx.x == 0) fb.qcount[k] = s_carry;
-        __syncthreads();
+        if (c < c1) fb.chunk_base[c] = carry + incl - v;
+        carry += (uint32_t)__shfl((int)incl, 63, 64);
     }
+    if (lane == 0) fb.qcount[k] = carry;
 }
 
 __global__ void __launch_bounds__(kQueueChunk) queue_write_kernel(const FrameBatch fb) {
@@ -2270,12 +2267,9 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
     }
     const unsigned n_chunks = (unsigned)fb.qchunk[fb.n_queues];
     hipLaunchKernelGGL(queue_count_kernel, dim3(n_chunks), dim3(kQueueChunk), 0, stream, fb);
-    hipLaunchKernelGGL(queue_scan_kernel, dim3(1), dim3(256), 0, stream, fb);
+    hipLaunchKernelGGL(queue_scan_kernel, dim3(1), dim3(64 * kMaxQueues), 0, stream, fb, queue);  // (+ arms the ray queues)
     hipLaunchKernelGGL(queue_write_kernel, dim3(n_chunks), dim3(kQueueChunk), 0, stream, fb);
     hipLaunchKernelGGL(sample_kernel<SPP>, dim3((unsigned)(((tiles / fb.n + kSampleTiles - 1) / kSampleTiles + kSampleWaves - 1) / kSampleWaves), fb.n), dim3(64 * kSampleWaves), 0, stream, fb, jump);
-    // arm the ray queues on the launch stream (576 B): a launch never depends on how the previous one on
-    // this context ended
-    if (hipMemsetAsync(queue, 0, kQueueWords * sizeof(unsigned long long), stream) != hipSuccess) return hipErrorLaunchFailure;
     if (ev) (void)hipEventRecord(ev[1], stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, tree, opt, fb, queue, hits, chunk);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;

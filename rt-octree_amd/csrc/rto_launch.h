@@ -53,7 +53,7 @@ struct OccupancyCache {
 };
 
 // persistent batched renderer (N == 2 trees): fb.n frames in one launch (traversal kernel, then the
-// shading kernel); `queue` = kQueueWords u64 (zeroed on the stream before every launch); ev = nullptr or 4 events recorded before the thresholds kernel, before / after the traversal, after the shading
+// shading kernel); `queue` = kQueueWords u64 (zeroed by queue_scan_kernel on the stream before every traversal launch); ev = nullptr or 4 events recorded before the thresholds kernel, before / after the traversal, after the shading
 hipError_t launch_render_batch(int spp, const TreeDev& tree, const OptDev& opt, const FrameBatch& fb,
                                const PcgJumpEntry* jump, unsigned long long* queue, uint32_t* hits, int num_cus,
                                int refill, bool cull, OccupancyCache* occ, hipEvent_t* ev, hipStream_t stream);

@@ -2250,8 +2250,10 @@ static hipError_t launch_batch_impl(const TreeDev& tree, const OptDev& opt, cons
     // small enough that every wave draws several times (a wave that draws twice while its
     // neighbour draws three times is a 33 % imbalance)
     const int64_t rays_per_wave = (int64_t)tiles * 64 / ((int64_t)grid * 4);
-    const uint32_t chunk = chunk_override > 0 ? (uint32_t)chunk_override
-                                              : (rays_per_wave >= 2048 ? 256u : rays_per_wave >= 512 ? 128u : 64u);
+    // (round 6, with the band queues: two tiles per dequeue beat four on every configuration -- C2 3.83 -> 3.74 ms per 100 frames,
+    //  C5 2.44 -> 2.41, C4 11.85 -> 11.71, 8 scenes 3.26 -> 3.13; one tile 3.74 / 2.48 / 11.73 / 3.14, eight 3.90 on C2:
+    //  profiles/r6_zz_ab_chunk_*.txt)
+    const uint32_t chunk = chunk_override > 0 ? (uint32_t)chunk_override : (rays_per_wave >= 512 ? 128u : 64u);
     const int64_t size = (int64_t)fb.width * fb.height;
     if (ev) (void)hipEventRecord(ev[0], stream);
     // tile marks (empty-space culling; all ones when it is off), then the ray queues as lists of the marked tile slots
